@@ -1,0 +1,203 @@
+/*
+ * percival_hip.h -- C ABI of libpercival_hip.so (gfx950 / MI355X).
+ *
+ * This is the drop-in boundary "B2" of SURVEY.md section 8(b): the arithmetic that the
+ * reference delegates to TensorFlow/Keras on its WGAN-GP training hot path
+ * (reference: percivaltts/optimizertts_wgan.py:107-241, networks_critic.py:44-96,
+ * modeltts_common.py:65-126, networktts.py:59-134) is provided here as hand-written HIP
+ * kernels.  The reference has no FFI of its own (it is pure Python on tf.keras), so each
+ * entry point cites the Keras call site it replaces.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no framework types.
+ *   - every pointer is a DEVICE pointer unless the name ends in _host.
+ *   - every function is asynchronous on `stream` (a hipStream_t passed as void*),
+ *     never allocates or frees, never synchronises, and is safe to capture in a hipGraph.
+ *   - return value: 0 = ok, negative = PTTS_E* (see ptts_last_error()).
+ *   - tensors are fp32, channel-last, C-contiguous:
+ *       frames      [B, T, D]
+ *       conv2d maps [B, T, F, C]           (Keras channels_last)
+ *       conv2d kernels [KT, KF, Cin, Cout] (Keras HWIO)
+ *       dense / conv1d kernels [K, N] resp. [KW, Cin, N]  (Keras layout)
+ *   - "input transform": the layers of the reference are Linear -> (BatchNorm) -> LeakyReLU
+ *     (networktts.py:59-63,116-126).  We keep the PRE-activation tensor z in HBM and apply
+ *     a = act(scale*z + shift) while the next linear op loads it, so an activation is never
+ *     written and re-read.  PTTS_IN_* selects that transform.
+ */
+#ifndef PERCIVAL_HIP_H
+#define PERCIVAL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTTS_OK            0
+#define PTTS_EINVAL       -1   /* bad argument / unsupported shape */
+#define PTTS_ELAUNCH      -2   /* hipLaunch failed */
+#define PTTS_EWORKSPACE   -3   /* workspace too small */
+
+/* input transforms (applied on load; x is what lies in HBM) */
+#define PTTS_IN_NONE     0   /* a = x                                   */
+#define PTTS_IN_LRELU    1   /* p = x*scale[c]+shift[c]; a = p>0?p:alpha*p  (scale/shift may be NULL) */
+#define PTTS_IN_MASKMUL  2   /* a = x * (mask_src>0 ? 1 : alpha)        (second-order sweep of the gradient penalty) */
+
+/* conv2d padding modes along time (frequency is always 'same') */
+#define PTTS_PAD_SAME    0
+#define PTTS_PAD_CAUSAL  1
+
+/* output activations of ptts_affine_act */
+#define PTTS_ACT_NONE    0
+#define PTTS_ACT_LRELU   1
+#define PTTS_ACT_SIGMOID 2
+#define PTTS_ACT_TANH    3
+
+const char* ptts_version(void);
+const char* ptts_device_arch(void);     /* "gfx950" : the only code object in the library */
+const char* ptts_last_error(void);      /* thread-local message of the last failure */
+
+/* ---------------------------------------------------------------------------------------
+ * 2D convolution over (time x frequency), NHWC, stride 1.
+ * Replaces kl.Conv2D at networks_critic.py:67, networktts.py:123,129-130, modeltts_common.py:100.
+ *   y[b,t,f,:] = bias + sum_{kt,kf} a[b, t+kt*dil_t-pad_t, f+kf-pad_f, :] . w[kt,kf,:,:]
+ *   a = transform(x) inside the image, 0 outside ('same' zero padding is in the activation domain).
+ * ------------------------------------------------------------------------------------- */
+int ptts_conv2d_fwd(const float* x, const float* w, const float* bias /*[Cout] or NULL*/,
+                    const float* in_scale /*[Cin] or NULL*/, const float* in_shift /*[Cin] or NULL*/,
+                    const float* mask_src /*[B,T,F,Cin], PTTS_IN_MASKMUL only*/,
+                    float* y,
+                    int B, int T, int F, int Cin, int Cout, int KT, int KF,
+                    int dil_t, int pad_mode, int in_mode, float alpha, void* stream);
+
+/* Fused backward of the layer above: given dy = dL/dy and the same (x, transform) as the forward,
+ *   da = conv^T(dy, w);  dx = da * d(a)/d(x)          -> dx   (skipped when dx == NULL)
+ *   dw = corr(a, dy), dbias = sum dy                  -> dw, dbias (skipped when dw == NULL)
+ *   dscale[c] = sum da*lrelu'(p)*x ; dshift[c] = sum da*lrelu'(p)   (PTTS_IN_LRELU with scale; skipped when NULL)
+ * One pass over HBM: reads dy, x (and mask_src), writes dx.  Weight-shaped results are reduced
+ * deterministically through `workspace` (ptts_conv2d_bwd_workspace_bytes) -- no float atomics. */
+size_t ptts_conv2d_bwd_workspace_bytes(int B, int T, int F, int Cin, int Cout, int KT, int KF, int dil_t);
+int ptts_conv2d_bwd(const float* dy, const float* x, const float* w,
+                    const float* in_scale, const float* in_shift, const float* mask_src,
+                    float* dx, float* dw, float* dbias, float* dscale, float* dshift,
+                    void* workspace, size_t workspace_bytes,
+                    int B, int T, int F, int Cin, int Cout, int KT, int KF,
+                    int dil_t, int pad_mode, int in_mode, float alpha, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * fp32 GEMM on the MFMA pipe (v_mfma_f32_32x32x2_f32), with implicit-convolution row
+ * addressing for the context Conv1D.  Replaces keras Dense (networktts.py:60; heads at
+ * modeltts_common.py:84,95,121; networks_critic.py:96) and kl.Conv1D (networktts.py:117).
+ *
+ *   C[M,N] (+)= opA(A)[M,K] . opB(B)[K,N] (+ bias[N])
+ *
+ * A element (m,k):   transA==0:  A[(m / rows_per_seg)*seg_stride + (m % rows_per_seg)*lda + k]
+ *                    transA==1:  A[(k / rows_per_seg)*seg_stride + (k % rows_per_seg)*lda + m]
+ *   (rows_per_seg = T, seg_stride = (T+KW-1)*Cin, lda = Cin, K = KW*Cin walks a zero-padded
+ *    [B, T+KW-1, Cin] frame buffer as the im2col matrix of a 'same' Conv1D without building it;
+ *    a plain matrix has rows_per_seg = its row count, seg_stride = 0.)
+ * B element (k,n):   transB==0: B[k*ldb + n] ;  transB==1: B[n*ldb + k]
+ * The input transform acts on the stored A element; its channel index is the stored column.
+ * accumulate != 0 adds to C (beta = 1). */
+int ptts_gemm(const float* A, const float* Bm, const float* bias, float* C,
+              int M, int N, int K,
+              int transA, long long lda, long long rows_per_seg, long long seg_stride,
+              int transB, long long ldb, long long ldc,
+              int in_mode, const float* in_scale, const float* in_shift, const float* mask_src,
+              float alpha, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * channel-last reductions and elementwise passes
+ * ------------------------------------------------------------------------------------- */
+/* sums[0:C] = sum_r a[r,c], sums[C:2C] = sum_r a[r,c]^2 in fp64, a = transform(x); deterministic two-stage. */
+size_t ptts_colstats_workspace_bytes(long long rows, int C);
+int ptts_colstats(const float* x, long long rows, int C,
+                  int in_mode, const float* in_scale, const float* in_shift, const float* mask_src, float alpha,
+                  double* sums /*[2C]*/, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Keras BatchNormalization (axis=-1, eps, momentum) statistics -> per-channel affine.
+ * Replaces kl.BatchNormalization at networktts.py:61,118,124,132.
+ *   training: mean,var from sums (biased var); scale = gamma*rsqrt(var+eps); shift = beta-mean*scale;
+ *             moving stats updated in place with `momentum` (moving_var uses var*count/(count-1) when unbiased_moving!=0)
+ *             when update_moving != 0.   inference: same from moving stats. */
+int ptts_bn_finalize(const double* sums, long long count, const float* gamma, const float* beta,
+                     float* moving_mean, float* moving_var, float eps, float momentum,
+                     int training, int update_moving, int unbiased_moving, int C,
+                     float* scale, float* shift, float* mean /*[C] out*/, float* rstd /*[C] out*/, void* stream);
+
+/* BatchNorm backward through the batch statistics.  Given dscale/dshift (gradients w.r.t. the affine that
+ * ptts_bn_finalize produced in training mode):  dgamma = (dscale - dshift*mean)*rstd ;  dbeta = dshift ;
+ *   dmean = -dshift*gamma*rstd ;  dvar = -0.5*(dscale - dshift*mean)*gamma*rstd^3 ;
+ *   c2 = 2*dvar/count ;  c0 = dmean/count - c2*mean      so that   dz[r,c] += c0[c] + c2[c]*z[r,c]. */
+int ptts_bn_bwd_coefs(const float* dscale, const float* dshift, const float* mean, const float* rstd,
+                      const float* gamma /*NULL = 1*/, long long count, int C,
+                      float* dgamma, float* dbeta, float* c0, float* c2, void* stream);
+
+/* y = act(x*scale[c]+shift[c]) materialised (used where no consumer can fuse it: LSTM input, final outputs). */
+int ptts_affine_act(const float* x, const float* scale, const float* shift, float* y,
+                    long long rows, int C, int act, float alpha, void* stream);
+/* dx = dy * act'(.) * scale ; dscale/dshift reductions (NULL to skip).  `y` is the forward output (sigmoid/tanh use it). */
+int ptts_affine_act_bwd(const float* dy, const float* x, const float* y, const float* scale, const float* shift,
+                        float* dx, double* dsums /*[2C]: dscale, dshift; or NULL*/,
+                        void* workspace, size_t workspace_bytes,
+                        long long rows, int C, int act, float alpha, void* stream);
+
+/* out[r,c] = (acc? out : 0) + a[r,c]*c1[c] + x[r,c]*c2[c] + c0[c]   (BatchNorm backward fix-up: dz += dmean/N + dvar*2(z-mean)/N) */
+int ptts_axpby_cols(const float* a, const float* c1, const float* x, const float* c2, const float* c0,
+                    float* out, long long rows, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * WGAN-GP pieces (optimizertts_wgan.py:44-79)
+ * ------------------------------------------------------------------------------------- */
+/* RandomWeightedAverage (:44-51): out = alpha_b*real + (1-alpha_b)*fake, alpha per sample */
+int ptts_gp_interpolate(const float* real, const float* fake, const float* alpha_b /*[B]*/, float* out,
+                        int B, long long TD, void* stream);
+/* per-sample squared L2 norm over (T, D) (:58-62), wavefront-reduced; out[B] */
+int ptts_gp_sqnorm(const float* g, float* out, int B, long long TD, void* stream);
+/* penalty = mean_b (1 - sqrt(sq_b))^2 (:64-68);  coef[b] = dPenalty/dg scale = 2*(n_b-1)/(n_b*B)  (inf/nan at n_b=0 as in the reference) */
+int ptts_gp_penalty(const float* sq /*[B]*/, float* penalty /*[1]*/, float* coef /*[B]*/, int B, void* stream);
+/* dg = upstream[0] * coef[b] * g */
+int ptts_gp_scale_rows(const float* g, const float* coef, const float* upstream /*[1] or NULL(=1)*/, float* dg,
+                       int B, long long TD, void* stream);
+
+/* wasserstein_loss (:70-71): out[0] = sign * mean(v) ; specweighted_lse_loss (:73-79): out[0] = mean((y-yhat)^2 * w[d]) */
+int ptts_mean_scaled(const float* v, long long n, float sign, float* out, void* stream);
+int ptts_wlse_fwd(const float* y, const float* yhat, const float* w /*[D] or NULL*/, float* out,
+                  long long rows, int D, void* stream);
+/* dyhat = upstream[0] * 2*(yhat-y)*w[d]/(rows*D) */
+int ptts_wlse_bwd(const float* y, const float* yhat, const float* w, const float* upstream, float* dyhat,
+                  long long rows, int D, void* stream);
+
+/* weight clipping (north_star extra; the reference has no counterpart): p = clamp(p, lo, hi) */
+int ptts_weight_clip(float* p, long long n, float lo, float hi, void* stream);
+
+/* Keras-2.2 Adam (keras.optimizers.Adam, optimizertts_wgan.py:145,172):
+ *   t = ++(*step);  lr_t = lr*sqrt(1-b2^t)/(1-b1^t);  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+ *   p -= lr_t * m / (sqrt(v) + eps).   `step` lives on the device so the launch is graph-replayable;
+ *   gscale multiplies g first (1/world_size after an all-reduce(sum)). */
+int ptts_adam_keras_step(float* p, const float* g, float* m, float* v, long long n,
+                         float lr, float b1, float b2, float eps, float gscale,
+                         int* step /*device int, incremented by the kernel*/, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Keras LSTM (gates i,f,c,o; activation tanh, recurrent_activation sigmoid; networktts.py:72-96).
+ * ndir = 1: one direction (reverse != 0 walks time backwards); ndir = 2: kl.Bidirectional(concat),
+ * direction 0 forwards and direction 1 backwards in the SAME launches (networktts.py:85-96).
+ *   xproj [B,T,ndir*4H] = x.[W_d0 | W_d1] + b (one ptts_gemm);  U [ndir,H,4H]
+ *   h_out [B,T,ndir*H] (the Bidirectional concat layout), gates (post-nonlinearity) [B,T,ndir*4H]
+ *   and cell states c_out [B,T,ndir*H] are kept for the backward.
+ * ------------------------------------------------------------------------------------- */
+int ptts_lstm_fwd(const float* xproj, const float* U, float* h_out, float* gates, float* c_out,
+                  int B, int T, int H, int ndir, int reverse, void* stream);
+/* dgates [B,T,ndir*4H] out: gradients w.r.t. the gate PRE-activations; dW, dU, db and dx follow from
+ * them as ptts_gemm products.  workspace: ptts_lstm_bwd_workspace_bytes */
+size_t ptts_lstm_bwd_workspace_bytes(int B, int T, int H, int ndir);
+int ptts_lstm_bwd(const float* dh_out /*[B,T,ndir*H]*/, const float* U, const float* gates, const float* c_out,
+                  float* dgates, void* workspace, size_t workspace_bytes,
+                  int B, int T, int H, int ndir, int reverse, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PERCIVAL_HIP_H */

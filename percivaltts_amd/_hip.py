@@ -1,0 +1,107 @@
+"""ctypes binding of libpercival_hip.so (the C ABI declared in include/percival_hip.h).
+
+There is NO fallback: if the library is missing or a kernel reports an error the call raises.
+The reference reaches its arithmetic through tf.keras (percivaltts/backend_tensorflow.py:38-39
+opens the TF session); this module is the counterpart for the MI355X build.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libpercival_hip.so')
+
+c_f = ctypes.c_float
+c_i = ctypes.c_int
+c_ll = ctypes.c_longlong
+c_p = ctypes.c_void_p
+c_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); must mirror include/percival_hip.h exactly
+SIGNATURES = {
+    'ptts_version': (ctypes.c_char_p, []),
+    'ptts_device_arch': (ctypes.c_char_p, []),
+    'ptts_last_error': (ctypes.c_char_p, []),
+    'ptts_conv2d_fwd': (c_i, [c_p] * 7 + [c_i] * 10 + [c_f, c_p]),
+    'ptts_conv2d_bwd_workspace_bytes': (c_sz, [c_i] * 8),
+    'ptts_conv2d_bwd': (c_i, [c_p] * 11 + [c_p, c_sz] + [c_i] * 10 + [c_f, c_p]),
+    'ptts_gemm': (c_i, [c_p] * 4 + [c_i] * 3 + [c_i, c_ll, c_ll, c_ll, c_i, c_ll, c_ll, c_i, c_p, c_p, c_p, c_f, c_i, c_p]),
+    'ptts_colstats_workspace_bytes': (c_sz, [c_ll, c_i]),
+    'ptts_colstats': (c_i, [c_p, c_ll, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_sz, c_p]),
+    'ptts_bn_finalize': (c_i, [c_p, c_ll, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    'ptts_bn_bwd_coefs': (c_i, [c_p] * 5 + [c_ll, c_i] + [c_p] * 4 + [c_p]),
+    'ptts_affine_act': (c_i, [c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_f, c_p]),
+    'ptts_affine_act_bwd': (c_i, [c_p] * 7 + [c_p, c_sz, c_ll, c_i, c_i, c_f, c_p]),
+    'ptts_axpby_cols': (c_i, [c_p] * 6 + [c_ll, c_i, c_p]),
+    'ptts_gp_interpolate': (c_i, [c_p] * 4 + [c_i, c_ll, c_p]),
+    'ptts_gp_sqnorm': (c_i, [c_p, c_p, c_i, c_ll, c_p]),
+    'ptts_gp_penalty': (c_i, [c_p, c_p, c_p, c_i, c_p]),
+    'ptts_gp_scale_rows': (c_i, [c_p] * 4 + [c_i, c_ll, c_p]),
+    'ptts_mean_scaled': (c_i, [c_p, c_ll, c_f, c_p, c_p]),
+    'ptts_wlse_fwd': (c_i, [c_p] * 4 + [c_ll, c_i, c_p]),
+    'ptts_wlse_bwd': (c_i, [c_p] * 5 + [c_ll, c_i, c_p]),
+    'ptts_weight_clip': (c_i, [c_p, c_ll, c_f, c_f, c_p]),
+    'ptts_adam_keras_step': (c_i, [c_p] * 4 + [c_ll] + [c_f] * 5 + [c_p, c_p]),
+    'ptts_lstm_fwd': (c_i, [c_p] * 5 + [c_i] * 5 + [c_p]),
+    'ptts_lstm_bwd_workspace_bytes': (c_sz, [c_i] * 4),
+    'ptts_lstm_bwd': (c_i, [c_p] * 5 + [c_p, c_sz] + [c_i] * 5 + [c_p]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the library once; raise loudly if it is absent (no CPU path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                'libpercival_hip.so not found at {}: run `python -c "import __graft_entry__ as g; g.build()"` '
+                '(or `make -C percivaltts_amd/csrc`). There is no CPU fallback.'.format(LIB_PATH))
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)   # AttributeError if the symbol is missing -> loud
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def last_error():
+    return lib().ptts_last_error().decode('utf8', 'replace')
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point and raise on a non-zero status."""
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise HipLibraryError('{} failed (rc={}): {}'.format(name, rc, last_error()))
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  The tensor must be fp32/fp64/int32 CUDA memory."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipLibraryError('percivaltts_amd kernels need device tensors (got a {} tensor); there is no CPU path'
+                              .format(t.device))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def f32c(t, name='tensor'):
+    """Validate: CUDA, float32, contiguous."""
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise HipLibraryError('{}: expected a contiguous float32 device tensor, got {} {} contiguous={}'.format(
+            name, t.device, t.dtype, t.is_contiguous()))
+    return t

@@ -1,0 +1,48 @@
+// Shared helpers for the gfx950 kernels of libpercival_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdarg>
+#include "../../include/percival_hip.h"
+
+namespace ptts {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return PTTS_ELAUNCH;
+    }
+    return PTTS_OK;
+}
+
+#define PTTS_REQUIRE(cond, ...)                         \
+    do {                                                \
+        if (!(cond)) {                                  \
+            ptts::set_error(__VA_ARGS__);               \
+            return PTTS_EINVAL;                         \
+        }                                               \
+    } while (0)
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float lrelu(float p, float alpha) { return p > 0.f ? p : alpha * p; }
+__device__ __forceinline__ float lrelu_d(float p, float alpha) { return p > 0.f ? 1.f : alpha; }
+
+// wave64 butterfly sums
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace ptts

@@ -1,0 +1,722 @@
+// 2D convolution over (time x frequency) for gfx950: forward and fused backward.
+//
+// Role on the hot path: the 8-deep 5x5 Conv2D stacks of the critic (reference
+// networks_critic.py:66-68) and of the generator's spectral branch (modeltts_common.py:97-100,
+// networktts.py:122-126).  Channel counts are tiny (C = 1..4) so this is a vector-ALU stencil,
+// not a GEMM: one lane owns a strip of KF consecutive frequency bins x all output channels,
+// the input tile (full frequency width + time halo) is staged once in LDS with the
+// BatchNorm-affine/LeakyReLU of the PREVIOUS layer applied on load, weights are wave-uniform
+// (scalar loads), HBM is touched exactly once per element per pass.
+//
+// Backward is one kernel per layer: it reads dy (with halo) and x once, produces dx with the
+// LeakyReLU mask of the previous layer already applied, and per-workgroup partial sums of
+// dw / dbias / dscale / dshift that a second tiny kernel reduces in a fixed order
+// (deterministic, no float atomics).
+#include "common.h"
+
+namespace ptts {
+
+template <int C> struct VecIO;
+template <> struct VecIO<1> {
+    static __device__ __forceinline__ void ld(const float* p, float* v) { v[0] = p[0]; }
+    static __device__ __forceinline__ void st(float* p, const float* v) { p[0] = v[0]; }
+};
+template <> struct VecIO<2> {
+    static __device__ __forceinline__ void ld(const float* p, float* v) {
+        float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[1] = t.y; }
+    static __device__ __forceinline__ void st(float* p, const float* v) {
+        *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]); }
+};
+template <> struct VecIO<4> {
+    static __device__ __forceinline__ void ld(const float* p, float* v) {
+        float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    static __device__ __forceinline__ void st(float* p, const float* v) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+
+constexpr int CONV_THREADS = 256;
+
+// a = transform(x) for one pixel (CIN channels)
+template <int CIN>
+__device__ __forceinline__ void in_transform(float* a, const float* __restrict__ in_scale,
+                                             const float* __restrict__ in_shift,
+                                             const float* __restrict__ mask_src, long long off,
+                                             int in_mode, float alpha) {
+    if (in_mode == PTTS_IN_LRELU) {
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) {
+            float p = a[c];
+            if (in_scale) p = p * in_scale[c] + in_shift[c];
+            a[c] = lrelu(p, alpha);
+        }
+    } else if (in_mode == PTTS_IN_MASKMUL) {
+        float m[CIN];
+        VecIO<CIN>::ld(mask_src + off, m);
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) a[c] *= lrelu_d(m[c], alpha);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward
+// grid (ceil(T/TT), B), 256 threads.  LDS: [TT + (KT-1)*dil_t][Fp + KF-1][CIN] floats, Fp = ceil(F/KF)*KF
+// ------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int KT, int KF>
+__global__ __launch_bounds__(CONV_THREADS) void conv2d_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+    const float* __restrict__ mask_src, float* __restrict__ y,
+    int T, int F, int TT, int dil_t, int pad_t, int in_mode, float alpha) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int P = KF;                 // outputs per lane along frequency
+    constexpr int PF = (KF - 1) / 2;      // 'same' padding, low side (TF: total//2)
+    const int nspr = (F + P - 1) / P;     // strips per row
+    const int cols = nspr * P + KF - 1;
+    const int rows = TT + (KT - 1) * dil_t;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * TT;
+    const long long img = (long long)b * T * F;
+
+    for (int idx = threadIdx.x; idx < rows * cols; idx += CONV_THREADS) {
+        const int r = idx / cols, c = idx - r * cols;
+        const int t = t0 + r - pad_t, f = c - PF;
+        float a[CIN];
+        if (t >= 0 && t < T && f >= 0 && f < F) {
+            const long long off = (img + (long long)t * F + f) * CIN;
+            VecIO<CIN>::ld(x + off, a);
+            in_transform<CIN>(a, in_scale, in_shift, mask_src, off, in_mode, alpha);
+        } else {
+#pragma unroll
+            for (int c2 = 0; c2 < CIN; ++c2) a[c2] = 0.f;
+        }
+        VecIO<CIN>::st(smem + (size_t)idx * CIN, a);
+    }
+    __syncthreads();
+
+    const int nstrips = TT * nspr;
+    for (int s = threadIdx.x; s < nstrips; s += CONV_THREADS) {
+        const int r = s / nspr;
+        const int fs = (s - r * nspr) * P;
+        const int t = t0 + r;
+        if (t >= T) continue;
+        float acc[P][COUT];
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) acc[p][co] = bias ? bias[co] : 0.f;
+#pragma unroll 1   // keep one kernel row (KF*CIN*COUT weights) in SGPRs at a time; full unroll spills SGPRs
+        for (int kt = 0; kt < KT; ++kt) {
+            const float* row = smem + ((size_t)(r + kt * dil_t) * cols + fs) * CIN;
+#pragma unroll
+            for (int j = 0; j < P + KF - 1; ++j) {
+                float a[CIN];
+                VecIO<CIN>::ld(row + j * CIN, a);
+#pragma unroll
+                for (int kf = 0; kf < KF; ++kf) {
+                    const int p = j - kf;
+                    if (p < 0 || p >= P) continue;
+                    const float* wk = w + ((kt * KF + kf) * CIN) * COUT;
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                        for (int co = 0; co < COUT; ++co)
+                            acc[p][co] = fmaf(a[ci], wk[ci * COUT + co], acc[p][co]);
+                }
+            }
+        }
+        float* yo = y + (img + (long long)t * F + fs) * COUT;
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+            if (fs + p < F) VecIO<COUT>::st(yo + p * COUT, acc[p]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fused backward
+// LDS: dyt [TT + (KT-1)*dil_t][Fp + KF-1][COUT] | at [TT][Fp][CIN] | xt [TT][Fp][CIN] (affine only)
+// partials[block][NW + COUT + 2*CIN]
+// ------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int KT, int KF>
+__global__ __launch_bounds__(CONV_THREADS) void conv2d_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ w,
+    const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+    const float* __restrict__ mask_src, float* __restrict__ dx, float* __restrict__ partials,
+    int want_dx, int want_dw, int want_affine,
+    int T, int F, int TT, int dil_t, int pad_t, int in_mode, float alpha) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int P = KF;
+    constexpr int PF = (KF - 1) / 2;
+    constexpr int LO_F = (KF - 1) - PF;   // low-side halo of dy along frequency
+    constexpr int NW = KT * KF * CIN * COUT;
+    constexpr int NPART = NW + COUT + 2 * CIN;
+    const int nspr = (F + P - 1) / P;
+    const int Fp = nspr * P;
+    const int cols = Fp + KF - 1;
+    const int halo_t = (KT - 1) * dil_t;
+    const int lo_t = halo_t - pad_t;      // dyt row 0 <-> t = t0 - lo_t
+    const int rows = TT + halo_t;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * TT;
+    const long long img = (long long)b * T * F;
+
+    float* dyt = smem;
+    float* at = dyt + (size_t)rows * cols * COUT;
+    float* xt = at + (size_t)TT * Fp * CIN;
+    const int tid = threadIdx.x;
+
+    for (int idx = tid; idx < rows * cols; idx += CONV_THREADS) {
+        const int r = idx / cols, c = idx - r * cols;
+        const int t = t0 + r - lo_t, f = c - LO_F;
+        float v[COUT];
+        if (t >= 0 && t < T && f >= 0 && f < F) {
+            VecIO<COUT>::ld(dy + (img + (long long)t * F + f) * COUT, v);
+        } else {
+#pragma unroll
+            for (int c2 = 0; c2 < COUT; ++c2) v[c2] = 0.f;
+        }
+        VecIO<COUT>::st(dyt + (size_t)idx * COUT, v);
+    }
+    for (int idx = tid; idx < TT * Fp; idx += CONV_THREADS) {
+        const int r = idx / Fp, f = idx - r * Fp;
+        const int t = t0 + r;
+        float a[CIN], xr[CIN];
+        if (t < T && f < F) {
+            const long long off = (img + (long long)t * F + f) * CIN;
+            VecIO<CIN>::ld(x + off, a);
+#pragma unroll
+            for (int c2 = 0; c2 < CIN; ++c2) xr[c2] = a[c2];
+            in_transform<CIN>(a, in_scale, in_shift, mask_src, off, in_mode, alpha);
+        } else {
+#pragma unroll
+            for (int c2 = 0; c2 < CIN; ++c2) { a[c2] = 0.f; xr[c2] = 0.f; }
+        }
+        VecIO<CIN>::st(at + (size_t)idx * CIN, a);
+        if (want_affine) VecIO<CIN>::st(xt + (size_t)idx * CIN, xr);
+    }
+    __syncthreads();
+
+    // ---- phase 1: dx = conv^T(dy, w) * d(a)/d(x), plus dscale/dshift sums --------------------
+    float s_scale[CIN], s_shift[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) { s_scale[c] = 0.f; s_shift[c] = 0.f; }
+    if (want_dx || want_affine) {
+        const int nstrips = TT * nspr;
+        for (int s = tid; s < nstrips; s += CONV_THREADS) {
+            const int r = s / nspr;
+            const int fs = (s - r * nspr) * P;
+            const int t = t0 + r;
+            if (t >= T) continue;
+            float da[P][CIN];
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) da[p][ci] = 0.f;
+#pragma unroll 1
+            for (int kt = 0; kt < KT; ++kt) {
+                const float* row = dyt + ((size_t)(r + (KT - 1 - kt) * dil_t) * cols + fs) * COUT;
+#pragma unroll
+                for (int j = 0; j < P + KF - 1; ++j) {
+                    float g[COUT];
+                    VecIO<COUT>::ld(row + j * COUT, g);
+#pragma unroll
+                    for (int kf = 0; kf < KF; ++kf) {
+                        const int p = j - (KF - 1 - kf);
+                        if (p < 0 || p >= P) continue;
+                        const float* wk = w + ((kt * KF + kf) * CIN) * COUT;
+#pragma unroll
+                        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                            for (int co = 0; co < COUT; ++co)
+                                da[p][ci] = fmaf(g[co], wk[ci * COUT + co], da[p][ci]);
+                    }
+                }
+            }
+            const float* arow = at + ((size_t)r * Fp + fs) * CIN;
+            const float* xrow = xt + ((size_t)r * Fp + fs) * CIN;
+            float* dxo = dx + (img + (long long)t * F + fs) * CIN;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                if (fs + p >= F) continue;
+                float o[CIN];
+                if (in_mode == PTTS_IN_LRELU) {
+                    float a[CIN];
+                    VecIO<CIN>::ld(arow + p * CIN, a);
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) {
+                        const float gd = da[p][ci] * (a[ci] > 0.f ? 1.f : alpha);
+                        o[ci] = in_scale ? gd * in_scale[ci] : gd;
+                        da[p][ci] = gd;
+                    }
+                    if (want_affine) {
+                        float xr[CIN];
+                        VecIO<CIN>::ld(xrow + p * CIN, xr);
+#pragma unroll
+                        for (int ci = 0; ci < CIN; ++ci) {
+                            s_shift[ci] += da[p][ci];
+                            s_scale[ci] += da[p][ci] * xr[ci];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) o[ci] = da[p][ci];
+                }
+                if (want_dx) VecIO<CIN>::st(dxo + p * CIN, o);
+            }
+        }
+    }
+
+    // ---- phase 2: dw partials.  lane role = (kt, ci); it owns acc[kf][co] and marches along f ----
+    constexpr int NROLE = KT * CIN;
+    constexpr int NGRP = CONV_THREADS / NROLE;
+    float accw[KF][COUT];
+#pragma unroll
+    for (int kf = 0; kf < KF; ++kf)
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) accw[kf][co] = 0.f;
+    const int grp = tid / NROLE;
+    const int role = tid - grp * NROLE;
+    const int rkt = role / CIN, rci = role - rkt * CIN;
+    if (want_dw && grp < NGRP) {
+        for (int r = grp; r < TT; r += NGRP) {
+            if (t0 + r >= T) break;
+            const float* drow = dyt + (size_t)(r + (KT - 1 - rkt) * dil_t) * cols * COUT;
+            const float* arow = at + (size_t)r * Fp * CIN + rci;
+            float win[KF][COUT];
+#pragma unroll
+            for (int k = 0; k < KF - 1; ++k) VecIO<COUT>::ld(drow + k * COUT, win[k]);
+            for (int f0 = 0; f0 < Fp; f0 += KF) {
+#pragma unroll
+                for (int u = 0; u < KF; ++u) {
+                    const int fq = f0 + u;
+                    // newest column fq+KF-1 goes to slot (u+KF-1)%KF
+                    VecIO<COUT>::ld(drow + (size_t)(fq + KF - 1) * COUT, win[(u + KF - 1) % KF]);
+                    const float av = arow[(size_t)fq * CIN];
+#pragma unroll
+                    for (int kf = 0; kf < KF; ++kf) {
+                        // dy column fq + (KF-1-kf) lives in slot (u + KF-1-kf) % KF
+                        const int slot = (u + KF - 1 - kf) % KF;
+#pragma unroll
+                        for (int co = 0; co < COUT; ++co)
+                            accw[kf][co] = fmaf(av, win[slot][co], accw[kf][co]);
+                    }
+                }
+            }
+        }
+    }
+    // ---- phase 3: dbias partial (sum of dy over the pixels this block owns) -------------------
+    float s_b[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) s_b[co] = 0.f;
+    if (want_dw) {
+        for (int idx = tid; idx < TT * F; idx += CONV_THREADS) {
+            const int r = idx / F, f = idx - r * F;
+            if (t0 + r >= T) break;
+            float g[COUT];
+            VecIO<COUT>::ld(dyt + ((size_t)(r + lo_t) * cols + f + LO_F) * COUT, g);
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) s_b[co] += g[co];
+        }
+    }
+    __syncthreads();   // everyone is done with dyt/at: reuse LDS as reduction scratch
+
+    float* red = smem;                        // [NGRP][NW]
+    float* red2 = smem + (size_t)NGRP * NW;   // [4 waves][COUT + 2*CIN]
+    if (want_dw && grp < NGRP) {
+#pragma unroll
+        for (int kf = 0; kf < KF; ++kf)
+#pragma unroll
+            for (int co = 0; co < COUT; ++co)
+                red[(size_t)grp * NW + ((rkt * KF + kf) * CIN + rci) * COUT + co] = accw[kf][co];
+    }
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            const float v = wave_sum(s_b[co]);
+            if (lane == 0) red2[wave * (COUT + 2 * CIN) + co] = v;
+        }
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+            const float v1 = wave_sum(s_scale[ci]);
+            const float v2 = wave_sum(s_shift[ci]);
+            if (lane == 0) {
+                red2[wave * (COUT + 2 * CIN) + COUT + ci] = v1;
+                red2[wave * (COUT + 2 * CIN) + COUT + CIN + ci] = v2;
+            }
+        }
+    }
+    __syncthreads();
+    float* out = partials + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NPART;
+    if (want_dw) {
+        for (int j = tid; j < NW; j += CONV_THREADS) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < NGRP; ++g) s += red[(size_t)g * NW + j];
+            out[j] = s;
+        }
+    }
+    if (tid < COUT + 2 * CIN) {
+        float s = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < CONV_THREADS / 64; ++wv) s += red2[wv * (COUT + 2 * CIN) + tid];
+        out[NW + tid] = s;
+    }
+}
+
+// out[j] = sum over blocks of partials[blk][j], fixed order -> deterministic. grid = npart, 256 threads.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials,
+                                                              int nblocks, int npart,
+                                                              float* __restrict__ dw, int nw,
+                                                              float* __restrict__ dbias, int cout,
+                                                              float* __restrict__ dscale,
+                                                              float* __restrict__ dshift, int cin) {
+    __shared__ double sh[4];
+    const int j = blockIdx.x;
+    double s = 0.0;
+    for (int blk = threadIdx.x; blk < nblocks; blk += 256) s += (double)partials[(size_t)blk * npart + j];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+        if (j < nw) { if (dw) dw[j] = v; }
+        else if (j < nw + cout) { if (dbias) dbias[j - nw] = v; }
+        else if (j < nw + cout + cin) { if (dscale) dscale[j - nw - cout] = v; }
+        else { if (dshift) dshift[j - nw - cout - cin] = v; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// generic fallbacks (any Cin/Cout/KT/KF): correct, unoptimised, global-memory only.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gen_in(const float* __restrict__ x, const float* __restrict__ in_scale,
+                                        const float* __restrict__ in_shift,
+                                        const float* __restrict__ mask_src, long long off, int c,
+                                        int in_mode, float alpha) {
+    float v = x[off];
+    if (in_mode == PTTS_IN_LRELU) {
+        if (in_scale) v = v * in_scale[c] + in_shift[c];
+        v = lrelu(v, alpha);
+    } else if (in_mode == PTTS_IN_MASKMUL) {
+        v *= lrelu_d(mask_src[off], alpha);
+    }
+    return v;
+}
+
+__global__ void conv2d_fwd_generic(const float* __restrict__ x, const float* __restrict__ w,
+                                   const float* __restrict__ bias, const float* __restrict__ in_scale,
+                                   const float* __restrict__ in_shift, const float* __restrict__ mask_src,
+                                   float* __restrict__ y, long long total, int T, int F, int Cin, int Cout,
+                                   int KT, int KF, int dil_t, int pad_t, int in_mode, float alpha) {
+    const int PF = (KF - 1) / 2;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cout);
+        long long pix = i / Cout;
+        const int f = (int)(pix % F);
+        pix /= F;
+        const int t = (int)(pix % T);
+        const long long b = pix / T;
+        float acc = bias ? bias[co] : 0.f;
+        for (int kt = 0; kt < KT; ++kt) {
+            const int tt = t + kt * dil_t - pad_t;
+            if (tt < 0 || tt >= T) continue;
+            for (int kf = 0; kf < KF; ++kf) {
+                const int ff = f + kf - PF;
+                if (ff < 0 || ff >= F) continue;
+                const long long base = ((b * T + tt) * F + ff) * Cin;
+                for (int ci = 0; ci < Cin; ++ci)
+                    acc = fmaf(gen_in(x, in_scale, in_shift, mask_src, base + ci, ci, in_mode, alpha),
+                               w[((kt * KF + kf) * Cin + ci) * Cout + co], acc);
+            }
+        }
+        y[i] = acc;
+    }
+}
+
+// dx and (per-element, non-reduced) affine terms; one thread per (pixel, ci)
+__global__ void conv2d_bwd_dx_generic(const float* __restrict__ dy, const float* __restrict__ x,
+                                      const float* __restrict__ w, const float* __restrict__ in_scale,
+                                      const float* __restrict__ in_shift, float* __restrict__ dx,
+                                      long long total, int T, int F, int Cin, int Cout, int KT, int KF,
+                                      int dil_t, int pad_t, int in_mode, float alpha) {
+    const int PF = (KF - 1) / 2;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin);
+        long long pix = i / Cin;
+        const int f = (int)(pix % F);
+        pix /= F;
+        const int t = (int)(pix % T);
+        const long long b = pix / T;
+        float da = 0.f;
+        for (int kt = 0; kt < KT; ++kt) {
+            const int tt = t - kt * dil_t + pad_t;
+            if (tt < 0 || tt >= T) continue;
+            for (int kf = 0; kf < KF; ++kf) {
+                const int ff = f - kf + PF;
+                if (ff < 0 || ff >= F) continue;
+                const long long base = ((b * T + tt) * F + ff) * Cout;
+                for (int co = 0; co < Cout; ++co)
+                    da = fmaf(dy[base + co], w[((kt * KF + kf) * Cin + ci) * Cout + co], da);
+            }
+        }
+        if (in_mode == PTTS_IN_LRELU) {
+            float p = x[i];
+            if (in_scale) p = p * in_scale[ci] + in_shift[ci];
+            da *= lrelu_d(p, alpha);
+            if (in_scale) da *= in_scale[ci];
+        }
+        dx[i] = da;
+    }
+}
+
+// one block per weight element (or per bias / dscale / dshift channel); fixed-order reduction.
+__global__ __launch_bounds__(256) void conv2d_bwd_w_generic(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ w,
+    const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+    const float* __restrict__ mask_src, float* __restrict__ dw, float* __restrict__ dbias,
+    float* __restrict__ dscale, float* __restrict__ dshift, long long npix, int T, int F, int Cin,
+    int Cout, int KT, int KF, int dil_t, int pad_t, int in_mode, float alpha) {
+    __shared__ double sh[4];
+    const int PF = (KF - 1) / 2;
+    const int NW = KT * KF * Cin * Cout;
+    const int j = blockIdx.x;
+    double s = 0.0;
+    if (j < NW) {
+        const int co = j % Cout, ci = (j / Cout) % Cin, kf = (j / (Cout * Cin)) % KF, kt = j / (Cout * Cin * KF);
+        for (long long pix = threadIdx.x; pix < npix; pix += 256) {
+            const int f = (int)(pix % F);
+            const int t = (int)((pix / F) % T);
+            const long long b = pix / ((long long)F * T);
+            const int tt = t + kt * dil_t - pad_t, ff = f + kf - PF;
+            if (tt < 0 || tt >= T || ff < 0 || ff >= F) continue;
+            const long long off = ((b * T + tt) * F + ff) * Cin + ci;
+            s += (double)(gen_in(x, in_scale, in_shift, mask_src, off, ci, in_mode, alpha) * dy[pix * Cout + co]);
+        }
+    } else if (j < NW + Cout) {
+        const int co = j - NW;
+        for (long long pix = threadIdx.x; pix < npix; pix += 256) s += (double)dy[pix * Cout + co];
+    } else {
+        // dscale (first Cin) / dshift (next Cin): recompute da at each pixel
+        const int which = (j - NW - Cout) / Cin, ci = (j - NW - Cout) % Cin;
+        for (long long pix = threadIdx.x; pix < npix; pix += 256) {
+            const int f = (int)(pix % F);
+            const int t = (int)((pix / F) % T);
+            const long long b = pix / ((long long)F * T);
+            float da = 0.f;
+            for (int kt = 0; kt < KT; ++kt) {
+                const int tt = t - kt * dil_t + pad_t;
+                if (tt < 0 || tt >= T) continue;
+                for (int kf = 0; kf < KF; ++kf) {
+                    const int ff = f - kf + PF;
+                    if (ff < 0 || ff >= F) continue;
+                    const long long base = ((b * T + tt) * F + ff) * Cout;
+                    for (int co = 0; co < Cout; ++co)
+                        da = fmaf(dy[base + co], w[((kt * KF + kf) * Cin + ci) * Cout + co], da);
+                }
+            }
+            const float xr = x[pix * Cin + ci];
+            const float p = xr * in_scale[ci] + in_shift[ci];
+            da *= lrelu_d(p, alpha);
+            s += (double)(which == 0 ? da * xr : da);
+        }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+        if (j < NW) { if (dw) dw[j] = v; }
+        else if (j < NW + Cout) { if (dbias) dbias[j - NW] = v; }
+        else if (j < NW + Cout + Cin) { if (dscale) dscale[j - NW - Cout] = v; }
+        else { if (dshift) dshift[j - NW - Cout - Cin] = v; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: tile choice + dispatch
+// ------------------------------------------------------------------------------------------
+constexpr size_t LDS_BUDGET = 64 * 1024;   // keep >= 2 workgroups per CU (160 KiB LDS)
+
+struct Tile { int TT; int ntiles; };
+
+// Pick the time-tile height: maximise (useful rows / launched rows) x (busy lanes / launched lanes)
+// under the LDS budget.  Strips per tile = TT * ceil(F/KF); 256 lanes take them round-robin.
+static Tile pick_tile(int T, int F, int KT, int KF, int dil_t, size_t bytes_per_row_fixed,
+                      size_t bytes_per_halo_row) {
+    const int nspr = (F + KF - 1) / KF;
+    const int halo = (KT - 1) * dil_t;
+    Tile best{0, 0};
+    double best_score = -1.0;
+    for (int TT = 4; TT <= 128; ++TT) {
+        const size_t lds = (size_t)TT * bytes_per_row_fixed + (size_t)(TT + halo) * bytes_per_halo_row;
+        if (lds > LDS_BUDGET && best.TT > 0) break;
+        const int ntiles = (T + TT - 1) / TT;
+        const int strips = TT * nspr;
+        const int rounds = (strips + CONV_THREADS - 1) / CONV_THREADS;
+        const double lane_eff = (double)strips / (rounds * CONV_THREADS);
+        const double row_eff = (double)T / ((double)ntiles * TT);
+        const double halo_eff = (double)TT / (TT + halo);
+        const double score = lane_eff * row_eff * (0.75 + 0.25 * halo_eff);
+        if (score > best_score + 1e-9) { best_score = score; best = Tile{TT, ntiles}; }
+    }
+    return best;
+}
+
+struct ConvGeom {
+    int pad_t;
+    bool ok;
+};
+static ConvGeom geom(int KT, int dil_t, int pad_mode) {
+    ConvGeom g;
+    const int span = (KT - 1) * dil_t;
+    g.pad_t = pad_mode == PTTS_PAD_CAUSAL ? span : span / 2;
+    g.ok = true;
+    return g;
+}
+
+#define PTTS_CONV_CASES(M)                                                                    \
+    M(1, 1, 3, 3) M(1, 2, 3, 3) M(1, 4, 3, 3) M(2, 1, 3, 3) M(2, 2, 3, 3) M(2, 4, 3, 3)       \
+    M(4, 1, 3, 3) M(4, 2, 3, 3) M(4, 4, 3, 3)                                                 \
+    M(1, 1, 5, 5) M(1, 2, 5, 5) M(1, 4, 5, 5) M(2, 1, 5, 5) M(2, 2, 5, 5) M(2, 4, 5, 5)       \
+    M(4, 1, 5, 5) M(4, 2, 5, 5) M(4, 4, 5, 5)
+
+}  // namespace ptts
+
+using namespace ptts;
+
+extern "C" int ptts_conv2d_fwd(const float* x, const float* w, const float* bias, const float* in_scale,
+                               const float* in_shift, const float* mask_src, float* y, int B, int T, int F,
+                               int Cin, int Cout, int KT, int KF, int dil_t, int pad_mode, int in_mode,
+                               float alpha, void* stream) {
+    PTTS_REQUIRE(x && w && y, "conv2d_fwd: null tensor");
+    PTTS_REQUIRE(B > 0 && T > 0 && F > 0 && Cin > 0 && Cout > 0 && KT > 0 && KF > 0 && dil_t > 0,
+                 "conv2d_fwd: bad dims B=%d T=%d F=%d Cin=%d Cout=%d KT=%d KF=%d dil=%d", B, T, F, Cin, Cout, KT, KF, dil_t);
+    PTTS_REQUIRE(in_mode >= 0 && in_mode <= 2, "conv2d_fwd: bad in_mode %d", in_mode);
+    PTTS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_fwd: scale/shift must come together");
+    PTTS_REQUIRE(in_mode != PTTS_IN_MASKMUL || mask_src, "conv2d_fwd: MASKMUL needs mask_src");
+    PTTS_REQUIRE(B <= 65535, "conv2d_fwd: B too large");
+    hipStream_t st = (hipStream_t)stream;
+    const ConvGeom g = geom(KT, dil_t, pad_mode);
+#define FWD_CASE(CI, CO, KTT, KFF)                                                                       \
+    if (Cin == CI && Cout == CO && KT == KTT && KF == KFF) {                                             \
+        const int nspr = (F + KFF - 1) / KFF;                                                            \
+        const size_t rowb = (size_t)(nspr * KFF + KFF - 1) * CI * sizeof(float);                         \
+        const Tile tl = pick_tile(T, F, KTT, KFF, dil_t, 0, rowb);                                       \
+        const size_t lds = (size_t)(tl.TT + (KTT - 1) * dil_t) * rowb;                                   \
+        if (lds <= 160 * 1024 - 256) {                                                                   \
+            hipLaunchKernelGGL((conv2d_fwd_kernel<CI, CO, KTT, KFF>), dim3(tl.ntiles, B), dim3(CONV_THREADS), \
+                               lds, st, x, w, bias, in_scale, in_shift, mask_src, y, T, F, tl.TT, dil_t, \
+                               g.pad_t, in_mode, alpha);                                                 \
+            return check_launch("conv2d_fwd");                                                           \
+        }                                                                                                \
+    }
+    PTTS_CONV_CASES(FWD_CASE)
+#undef FWD_CASE
+    const long long total = (long long)B * T * F * Cout;
+    const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(conv2d_fwd_generic, dim3(blocks), dim3(256), 0, st, x, w, bias, in_scale, in_shift,
+                       mask_src, y, total, T, F, Cin, Cout, KT, KF, dil_t, g.pad_t, in_mode, alpha);
+    return check_launch("conv2d_fwd_generic");
+}
+
+namespace {
+struct BwdPlan { bool fast; Tile tl; size_t lds; int npart; };
+template <int CI, int CO, int KTT, int KFF>
+BwdPlan plan_bwd(int T, int F, int dil_t) {
+    BwdPlan p;
+    const int nspr = (F + KFF - 1) / KFF;
+    const int Fp = nspr * KFF;
+    const size_t halo_row = (size_t)(Fp + KFF - 1) * CO * sizeof(float);
+    const size_t fixed_row = (size_t)Fp * CI * sizeof(float) * 2;   // at + xt
+    p.tl = pick_tile(T, F, KTT, KFF, dil_t, fixed_row, halo_row);
+    p.lds = (size_t)p.tl.TT * fixed_row + (size_t)(p.tl.TT + (KTT - 1) * dil_t) * halo_row;
+    constexpr int NW = KTT * KFF * CI * CO;
+    constexpr int NGRP = CONV_THREADS / (KTT * CI);
+    const size_t red = ((size_t)NGRP * NW + 4 * (CO + 2 * CI)) * sizeof(float);
+    if (p.lds < red) p.lds = red;
+    p.npart = NW + CO + 2 * CI;
+    p.fast = p.lds <= 160 * 1024 - 256;
+    return p;
+}
+}  // namespace
+
+extern "C" size_t ptts_conv2d_bwd_workspace_bytes(int B, int T, int F, int Cin, int Cout, int KT, int KF,
+                                                  int dil_t) {
+#define WS_CASE(CI, CO, KTT, KFF)                                                      \
+    if (Cin == CI && Cout == CO && KT == KTT && KF == KFF) {                           \
+        const BwdPlan p = plan_bwd<CI, CO, KTT, KFF>(T, F, dil_t);                     \
+        if (p.fast) return (size_t)B * p.tl.ntiles * p.npart * sizeof(float);          \
+    }
+    PTTS_CONV_CASES(WS_CASE)
+#undef WS_CASE
+    return 16;
+}
+
+extern "C" int ptts_conv2d_bwd(const float* dy, const float* x, const float* w, const float* in_scale,
+                               const float* in_shift, const float* mask_src, float* dx, float* dw,
+                               float* dbias, float* dscale, float* dshift, void* workspace,
+                               size_t workspace_bytes, int B, int T, int F, int Cin, int Cout, int KT, int KF,
+                               int dil_t, int pad_mode, int in_mode, float alpha, void* stream) {
+    PTTS_REQUIRE(dy && x && w, "conv2d_bwd: null tensor");
+    PTTS_REQUIRE(B > 0 && T > 0 && F > 0 && Cin > 0 && Cout > 0 && KT > 0 && KF > 0 && dil_t > 0,
+                 "conv2d_bwd: bad dims");
+    PTTS_REQUIRE(in_mode >= 0 && in_mode <= 2, "conv2d_bwd: bad in_mode %d", in_mode);
+    PTTS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_bwd: scale/shift must come together");
+    PTTS_REQUIRE(in_mode != PTTS_IN_MASKMUL || mask_src, "conv2d_bwd: MASKMUL needs mask_src");
+    PTTS_REQUIRE(!(in_mode == PTTS_IN_MASKMUL && dx), "conv2d_bwd: dx is not defined for MASKMUL (weight-only sweep)");
+    PTTS_REQUIRE((dscale == nullptr) == (dshift == nullptr), "conv2d_bwd: dscale/dshift must come together");
+    PTTS_REQUIRE(!dscale || (in_mode == PTTS_IN_LRELU && in_scale), "conv2d_bwd: dscale needs LRELU with scale/shift");
+    PTTS_REQUIRE((dw == nullptr) || true, "");
+    PTTS_REQUIRE(B <= 65535, "conv2d_bwd: B too large");
+    hipStream_t st = (hipStream_t)stream;
+    const ConvGeom g = geom(KT, dil_t, pad_mode);
+    const int want_dx = dx != nullptr, want_dw = (dw != nullptr || dbias != nullptr), want_aff = dscale != nullptr;
+    if (!want_dx && !want_dw && !want_aff) return PTTS_OK;
+#define BWD_CASE(CI, CO, KTT, KFF)                                                                         \
+    if (Cin == CI && Cout == CO && KT == KTT && KF == KFF) {                                               \
+        const BwdPlan p = plan_bwd<CI, CO, KTT, KFF>(T, F, dil_t);                                         \
+        if (p.fast) {                                                                                      \
+            const int nblocks = B * p.tl.ntiles;                                                           \
+            const size_t need = (size_t)nblocks * p.npart * sizeof(float);                                 \
+            if ((want_dw || want_aff) && (!workspace || workspace_bytes < need)) {                         \
+                set_error("conv2d_bwd: workspace %zu < %zu", workspace_bytes, need);                       \
+                return PTTS_EWORKSPACE;                                                                    \
+            }                                                                                              \
+            hipLaunchKernelGGL((conv2d_bwd_kernel<CI, CO, KTT, KFF>), dim3(p.tl.ntiles, B),                \
+                               dim3(CONV_THREADS), p.lds, st, dy, x, w, in_scale, in_shift, mask_src, dx,  \
+                               (float*)workspace, want_dx, want_dw, want_aff, T, F, p.tl.TT, dil_t,        \
+                               g.pad_t, in_mode, alpha);                                                   \
+            int rc = check_launch("conv2d_bwd");                                                           \
+            if (rc) return rc;                                                                             \
+            if (want_dw || want_aff) {                                                                     \
+                hipLaunchKernelGGL(reduce_partials_kernel, dim3(p.npart), dim3(256), 0, st,                \
+                                   (const float*)workspace, nblocks, p.npart, want_dw ? dw : nullptr,      \
+                                   KTT * KFF * CI * CO, want_dw ? dbias : nullptr, CO, dscale, dshift, CI);\
+                rc = check_launch("conv2d_bwd_reduce");                                                    \
+            }                                                                                              \
+            return rc;                                                                                     \
+        }                                                                                                  \
+    }
+    PTTS_CONV_CASES(BWD_CASE)
+#undef BWD_CASE
+    const long long npix = (long long)B * T * F;
+    if (want_dx) {
+        const long long total = npix * Cin;
+        const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+        hipLaunchKernelGGL(conv2d_bwd_dx_generic, dim3(blocks), dim3(256), 0, st, dy, x, w, in_scale, in_shift,
+                           dx, total, T, F, Cin, Cout, KT, KF, dil_t, g.pad_t, in_mode, alpha);
+        int rc = check_launch("conv2d_bwd_dx_generic");
+        if (rc) return rc;
+    }
+    if (want_dw || want_aff) {
+        const int nw = KT * KF * Cin * Cout;
+        const int nblk = nw + Cout + (want_aff ? 2 * Cin : 0);
+        hipLaunchKernelGGL(conv2d_bwd_w_generic, dim3(nblk), dim3(256), 0, st, dy, x, w, in_scale, in_shift,
+                           mask_src, want_dw ? dw : nullptr, want_dw ? dbias : nullptr, dscale, dshift, npix, T,
+                           F, Cin, Cout, KT, KF, dil_t, g.pad_t, in_mode, alpha);
+        return check_launch("conv2d_bwd_w_generic");
+    }
+    return PTTS_OK;
+}

@@ -1,0 +1,529 @@
+// Channel-last reductions, BatchNorm statistics, activations, WGAN-GP pieces, losses, Adam, clip.
+// All of these are HBM-bound single-pass kernels over [rows, C] tensors (C innermost).
+#include "common.h"
+
+namespace ptts {
+
+constexpr int EW_THREADS = 256;
+
+static inline int ew_blocks(long long n, int per_thread = 4) {
+    long long b = (n + (long long)EW_THREADS * per_thread - 1) / ((long long)EW_THREADS * per_thread);
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;   // 256 CUs x 8: grid-stride the rest
+    return (int)b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// two-quantity column reduction over [rows, C]: deterministic two-stage, fp64 accumulation
+// ---------------------------------------------------------------------------------------------
+constexpr int MAXC_SLOTS = 8;   // C <= 2048
+
+template <class Op>
+__global__ __launch_bounds__(EW_THREADS) void colreduce2_kernel(Op op, long long rows, int C,
+                                                                double* __restrict__ partials) {
+    __shared__ double sh[2][EW_THREADS];
+    const int tid = threadIdx.x;
+    double* out = partials + (size_t)blockIdx.x * 2 * C;
+    if (C <= EW_THREADS) {
+        const int R = EW_THREADS / C;
+        const int r = tid / C, c = tid - r * C;
+        double q1 = 0.0, q2 = 0.0;
+        if (r < R) {
+            for (long long row = (long long)blockIdx.x * R + r; row < rows; row += (long long)gridDim.x * R) {
+                float a, b;
+                op(row * C + c, c, a, b);
+                q1 += (double)a;
+                q2 += (double)b;
+            }
+        }
+        sh[0][tid] = q1;
+        sh[1][tid] = q2;
+        __syncthreads();
+        if (tid < C) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int rr = 0; rr < R; ++rr) { s1 += sh[0][rr * C + tid]; s2 += sh[1][rr * C + tid]; }
+            out[tid] = s1;
+            out[C + tid] = s2;
+        }
+    } else {
+        double q1[MAXC_SLOTS], q2[MAXC_SLOTS];
+#pragma unroll
+        for (int s = 0; s < MAXC_SLOTS; ++s) { q1[s] = 0.0; q2[s] = 0.0; }
+        for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+#pragma unroll
+            for (int s = 0; s < MAXC_SLOTS; ++s) {
+                const int c = tid + s * EW_THREADS;
+                if (c < C) {
+                    float a, b;
+                    op(row * C + c, c, a, b);
+                    q1[s] += (double)a;
+                    q2[s] += (double)b;
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < MAXC_SLOTS; ++s) {
+            const int c = tid + s * EW_THREADS;
+            if (c < C) { out[c] = q1[s]; out[C + c] = q2[s]; }
+        }
+    }
+}
+
+__global__ void colreduce_final_kernel(const double* __restrict__ partials, int nblocks, int n2c,
+                                       double* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n2c) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * n2c + j];
+    out[j] = s;
+}
+
+static int colreduce_blocks(long long rows, int C) {
+    const int R = C <= EW_THREADS ? EW_THREADS / C : 1;
+    long long b = (rows + (long long)R * 8 - 1) / ((long long)R * 8);
+    if (b < 1) b = 1;
+    if (b > 1024) b = 1024;
+    return (int)b;
+}
+
+struct StatsOp {
+    const float* x; int in_mode; const float* in_scale; const float* in_shift; const float* mask_src; float alpha;
+    __device__ __forceinline__ void operator()(long long i, int c, float& a, float& b) const {
+        float v = x[i];
+        if (in_mode == PTTS_IN_LRELU) {
+            if (in_scale) v = v * in_scale[c] + in_shift[c];
+            v = lrelu(v, alpha);
+        } else if (in_mode == PTTS_IN_MASKMUL) {
+            v *= lrelu_d(mask_src[i], alpha);
+        }
+        a = v;
+        b = v * v;
+    }
+};
+
+__device__ __forceinline__ float act_fwd(float p, int act, float alpha) {
+    switch (act) {
+        case PTTS_ACT_LRELU: return lrelu(p, alpha);
+        case PTTS_ACT_SIGMOID: return 1.f / (1.f + __expf(-p));
+        case PTTS_ACT_TANH: return tanhf(p);
+        default: return p;
+    }
+}
+
+struct ActBwdOp {
+    const float* dy; const float* x; const float* y; const float* scale; const float* shift; float* dx;
+    int act; float alpha;
+    __device__ __forceinline__ void operator()(long long i, int c, float& a, float& b) const {
+        const float xv = x[i];
+        const float sc = scale ? scale[c] : 1.f;
+        float d;
+        if (act == PTTS_ACT_LRELU) {
+            const float p = scale ? xv * sc + shift[c] : xv;
+            d = lrelu_d(p, alpha);
+        } else if (act == PTTS_ACT_SIGMOID) {
+            const float yv = y[i];
+            d = yv * (1.f - yv);
+        } else if (act == PTTS_ACT_TANH) {
+            const float yv = y[i];
+            d = 1.f - yv * yv;
+        } else {
+            d = 1.f;
+        }
+        const float gd = dy[i] * d;
+        if (dx) dx[i] = gd * sc;
+        a = gd * xv;   // dscale
+        b = gd;        // dshift
+    }
+};
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, long long count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ moving_mean, float* __restrict__ moving_var, float eps,
+                                   float momentum, int training, int update_moving, int unbiased_moving, int C,
+                                   float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        double mean, var;
+        if (training) {
+            mean = sums[c] / (double)count;
+            var = sums[C + c] / (double)count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            if (update_moving) {
+                const double vm = (unbiased_moving && count > 1) ? var * (double)count / (double)(count - 1) : var;
+                moving_mean[c] = (float)(moving_mean[c] * (double)momentum + mean * (1.0 - (double)momentum));
+                moving_var[c] = (float)(moving_var[c] * (double)momentum + vm * (1.0 - (double)momentum));
+            }
+        } else {
+            mean = moving_mean[c];
+            var = moving_var[c];
+        }
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        const double g = gamma ? (double)gamma[c] : 1.0;
+        const double bt = beta ? (double)beta[c] : 0.0;
+        scale[c] = (float)(g * rstd);
+        shift[c] = (float)(bt - mean * g * rstd);
+        if (mean_out) mean_out[c] = (float)mean;
+        if (rstd_out) rstd_out[c] = (float)rstd;
+    }
+}
+
+__global__ void bn_bwd_coefs_kernel(const float* __restrict__ dscale, const float* __restrict__ dshift,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                    const float* __restrict__ gamma, long long count, int C,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                    float* __restrict__ c0, float* __restrict__ c2) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        const double g = gamma ? (double)gamma[c] : 1.0;
+        const double mu = mean[c], rs = rstd[c];
+        const double dsc = (double)dscale[c] - (double)dshift[c] * mu;   // total gradient w.r.t. scale
+        const double dmean = -(double)dshift[c] * g * rs;
+        const double dvar = -0.5 * dsc * g * rs * rs * rs;
+        const double k2 = 2.0 * dvar / (double)count;
+        if (dgamma) dgamma[c] = (float)(dsc * rs);
+        if (dbeta) dbeta[c] = dshift[c];
+        c2[c] = (float)k2;
+        c0[c] = (float)(dmean / (double)count - k2 * mu);
+    }
+}
+
+__global__ void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                  const float* __restrict__ shift, float* __restrict__ y, long long n, int C,
+                                  int act, float alpha) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        float p = x[i];
+        if (scale) { const int c = (int)(i % C); p = p * scale[c] + shift[c]; }
+        y[i] = act_fwd(p, act, alpha);
+    }
+}
+
+// C % 4 == 0: one float4 per lane
+__global__ void affine_act_kernel4(const float4* __restrict__ x, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, float4* __restrict__ y, long long n4, int C,
+                                   int act, float alpha) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
+         i += (long long)gridDim.x * blockDim.x) {
+        float4 v = x[i];
+        float p[4] = {v.x, v.y, v.z, v.w};
+        if (scale) {
+            const int c = (int)((i * 4) % C);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) p[e] = p[e] * scale[c + e] + shift[c + e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p[e] = act_fwd(p[e], act, alpha);
+        y[i] = make_float4(p[0], p[1], p[2], p[3]);
+    }
+}
+
+__global__ void axpby_cols_kernel(const float* __restrict__ a, const float* __restrict__ c1,
+                                  const float* __restrict__ x, const float* __restrict__ c2,
+                                  const float* __restrict__ c0, float* __restrict__ out, long long n, int C) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        float v = c0 ? c0[c] : 0.f;
+        if (a) v += a[i] * (c1 ? c1[c] : 1.f);
+        if (x) v += x[i] * (c2 ? c2[c] : 1.f);
+        out[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// WGAN-GP
+// ---------------------------------------------------------------------------------------------
+__global__ void gp_interpolate_kernel(const float* __restrict__ real, const float* __restrict__ fake,
+                                      const float* __restrict__ alpha_b, float* __restrict__ out,
+                                      long long TD) {
+    const int b = blockIdx.y;
+    const float a = alpha_b[b];
+    const long long base = (long long)b * TD;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < TD;
+         i += (long long)gridDim.x * blockDim.x)
+        out[base + i] = a * real[base + i] + (1.f - a) * fake[base + i];
+}
+
+// one workgroup of 1024 lanes per sample: per-lane partial -> wave64 butterfly -> 16 wave sums in LDS
+__global__ __launch_bounds__(1024) void gp_sqnorm_kernel(const float* __restrict__ g, float* __restrict__ out,
+                                                         long long TD) {
+    __shared__ double sh[16];
+    const int b = blockIdx.x;
+    const float* p = g + (long long)b * TD;
+    double s = 0.0;
+    for (long long i = threadIdx.x; i < TD; i += 1024) { const float v = p[i]; s += (double)v * (double)v; }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += sh[w];
+        out[b] = (float)t;
+    }
+}
+
+__global__ __launch_bounds__(256) void gp_penalty_kernel(const float* __restrict__ sq, float* __restrict__ penalty,
+                                                         float* __restrict__ coef, int B) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float n = sqrtf(sq[b]);
+        const float d = 1.f - n;
+        s += (double)d * (double)d;
+        // d/dg (1-n)^2 = 2 (n-1)/n * g ; mean over B.  n == 0 gives inf/nan exactly like K.sqrt's gradient.
+        if (coef) coef[b] = 2.f * (n - 1.f) / (n * (float)B);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) penalty[0] = (float)((sh[0] + sh[1] + sh[2] + sh[3]) / (double)B);
+}
+
+__global__ void gp_scale_rows_kernel(const float* __restrict__ g, const float* __restrict__ coef,
+                                     const float* __restrict__ upstream, float* __restrict__ dg, long long TD) {
+    const int b = blockIdx.y;
+    const float s = coef[b] * (upstream ? upstream[0] : 1.f);
+    const long long base = (long long)b * TD;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < TD;
+         i += (long long)gridDim.x * blockDim.x)
+        dg[base + i] = s * g[base + i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// losses: block partials in fp64, combined with one float atomic per workgroup into a zeroed scalar
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mean_scaled_kernel(const float* __restrict__ v, long long n, float scale,
+                                                          float* __restrict__ out) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += (double)v[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (float)((sh[0] + sh[1] + sh[2] + sh[3]) * (double)scale));
+}
+
+__global__ __launch_bounds__(256) void wlse_fwd_kernel(const float* __restrict__ y, const float* __restrict__ yhat,
+                                                       const float* __restrict__ w, long long n, int D,
+                                                       float scale, float* __restrict__ out) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float d = y[i] - yhat[i];
+        s += (double)(d * d * (w ? w[i % D] : 1.f));
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (float)((sh[0] + sh[1] + sh[2] + sh[3]) * (double)scale));
+}
+
+__global__ void wlse_bwd_kernel(const float* __restrict__ y, const float* __restrict__ yhat,
+                                const float* __restrict__ w, const float* __restrict__ upstream,
+                                float* __restrict__ dyhat, long long n, int D, float scale) {
+    const float up = (upstream ? upstream[0] : 1.f) * scale;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        dyhat[i] = up * 2.f * (yhat[i] - y[i]) * (w ? w[i % D] : 1.f);
+}
+
+__global__ void weight_clip_kernel(float* __restrict__ p, long long n, float lo, float hi) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        p[i] = fminf(fmaxf(p[i], lo), hi);
+}
+
+__global__ void adam_tick_kernel(int* step) { *step += 1; }
+
+__global__ void adam_keras_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                  float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                                  float gscale, const int* __restrict__ step) {
+    const float t = (float)(*step);
+    const float lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+}  // namespace ptts
+
+using namespace ptts;
+
+extern "C" size_t ptts_colstats_workspace_bytes(long long rows, int C) {
+    return (size_t)colreduce_blocks(rows, C) * 2 * (size_t)C * sizeof(double);
+}
+
+template <class Op>
+static int run_colreduce(const Op& op, long long rows, int C, double* out, void* workspace,
+                         size_t workspace_bytes, hipStream_t st, const char* what) {
+    PTTS_REQUIRE(C > 0 && C <= MAXC_SLOTS * EW_THREADS, "%s: C=%d unsupported", what, C);
+    PTTS_REQUIRE(rows > 0, "%s: rows=%lld", what, rows);
+    const int nb = colreduce_blocks(rows, C);
+    const size_t need = (size_t)nb * 2 * C * sizeof(double);
+    if (!workspace || workspace_bytes < need) {
+        set_error("%s: workspace %zu < %zu", what, workspace_bytes, need);
+        return PTTS_EWORKSPACE;
+    }
+    hipLaunchKernelGGL((colreduce2_kernel<Op>), dim3(nb), dim3(EW_THREADS), 0, st, op, rows, C, (double*)workspace);
+    int rc = check_launch(what);
+    if (rc) return rc;
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st,
+                       (const double*)workspace, nb, 2 * C, out);
+    return check_launch(what);
+}
+
+extern "C" int ptts_colstats(const float* x, long long rows, int C, int in_mode, const float* in_scale,
+                             const float* in_shift, const float* mask_src, float alpha, double* sums,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    PTTS_REQUIRE(x && sums, "colstats: null tensor");
+    PTTS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "colstats: scale/shift must come together");
+    StatsOp op{x, in_mode, in_scale, in_shift, mask_src, alpha};
+    return run_colreduce(op, rows, C, sums, workspace, workspace_bytes, (hipStream_t)stream, "colstats");
+}
+
+extern "C" int ptts_bn_finalize(const double* sums, long long count, const float* gamma, const float* beta,
+                                float* moving_mean, float* moving_var, float eps, float momentum, int training,
+                                int update_moving, int unbiased_moving, int C, float* scale, float* shift,
+                                float* mean, float* rstd, void* stream) {
+    PTTS_REQUIRE(scale && shift && C > 0, "bn_finalize: null output");
+    PTTS_REQUIRE(!training || sums, "bn_finalize: training needs sums");
+    PTTS_REQUIRE(training || (moving_mean && moving_var), "bn_finalize: inference needs moving stats");
+    PTTS_REQUIRE(!(training && update_moving) || (moving_mean && moving_var), "bn_finalize: update needs moving stats");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count,
+                       gamma, beta, moving_mean, moving_var, eps, momentum, training, update_moving,
+                       unbiased_moving, C, scale, shift, mean, rstd);
+    return check_launch("bn_finalize");
+}
+
+extern "C" int ptts_bn_bwd_coefs(const float* dscale, const float* dshift, const float* mean, const float* rstd,
+                                 const float* gamma, long long count, int C, float* dgamma, float* dbeta,
+                                 float* c0, float* c2, void* stream) {
+    PTTS_REQUIRE(dscale && dshift && mean && rstd && c0 && c2 && C > 0 && count > 0, "bn_bwd_coefs: bad args");
+    hipLaunchKernelGGL(bn_bwd_coefs_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, dscale, dshift,
+                       mean, rstd, gamma, count, C, dgamma, dbeta, c0, c2);
+    return check_launch("bn_bwd_coefs");
+}
+
+extern "C" int ptts_affine_act(const float* x, const float* scale, const float* shift, float* y, long long rows,
+                               int C, int act, float alpha, void* stream) {
+    PTTS_REQUIRE(x && y && rows > 0 && C > 0, "affine_act: bad args");
+    PTTS_REQUIRE((scale == nullptr) == (shift == nullptr), "affine_act: scale/shift must come together");
+    const long long n = rows * C;
+    hipStream_t st = (hipStream_t)stream;
+    if (C % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0)) {
+        hipLaunchKernelGGL(affine_act_kernel4, dim3(ew_blocks(n / 4, 2)), dim3(EW_THREADS), 0, st, (const float4*)x,
+                           scale, shift, (float4*)y, n / 4, C, act, alpha);
+    } else {
+        hipLaunchKernelGGL(affine_act_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, st, x, scale, shift, y, n, C,
+                           act, alpha);
+    }
+    return check_launch("affine_act");
+}
+
+extern "C" int ptts_affine_act_bwd(const float* dy, const float* x, const float* y, const float* scale,
+                                   const float* shift, float* dx, double* dsums, void* workspace,
+                                   size_t workspace_bytes, long long rows, int C, int act, float alpha,
+                                   void* stream) {
+    PTTS_REQUIRE(dy && x && rows > 0 && C > 0, "affine_act_bwd: bad args");
+    PTTS_REQUIRE((scale == nullptr) == (shift == nullptr), "affine_act_bwd: scale/shift must come together");
+    PTTS_REQUIRE((act != PTTS_ACT_SIGMOID && act != PTTS_ACT_TANH) || y, "affine_act_bwd: sigmoid/tanh need y");
+    PTTS_REQUIRE(dsums, "affine_act_bwd: dsums required (the reduction is fused with the dx pass)");
+    ActBwdOp op{dy, x, y, scale, shift, dx, act, alpha};
+    return run_colreduce(op, rows, C, dsums, workspace, workspace_bytes, (hipStream_t)stream, "affine_act_bwd");
+}
+
+extern "C" int ptts_axpby_cols(const float* a, const float* c1, const float* x, const float* c2, const float* c0,
+                               float* out, long long rows, int C, void* stream) {
+    PTTS_REQUIRE(out && rows > 0 && C > 0, "axpby_cols: bad args");
+    const long long n = rows * C;
+    hipLaunchKernelGGL(axpby_cols_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, a, c1, x, c2,
+                       c0, out, n, C);
+    return check_launch("axpby_cols");
+}
+
+extern "C" int ptts_gp_interpolate(const float* real, const float* fake, const float* alpha_b, float* out, int B,
+                                   long long TD, void* stream) {
+    PTTS_REQUIRE(real && fake && alpha_b && out && B > 0 && B <= 65535 && TD > 0, "gp_interpolate: bad args");
+    int bx = (int)((TD + 1023) / 1024);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(gp_interpolate_kernel, dim3(bx, B), dim3(EW_THREADS), 0, (hipStream_t)stream, real, fake,
+                       alpha_b, out, TD);
+    return check_launch("gp_interpolate");
+}
+
+extern "C" int ptts_gp_sqnorm(const float* g, float* out, int B, long long TD, void* stream) {
+    PTTS_REQUIRE(g && out && B > 0 && TD > 0, "gp_sqnorm: bad args");
+    hipLaunchKernelGGL(gp_sqnorm_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, g, out, TD);
+    return check_launch("gp_sqnorm");
+}
+
+extern "C" int ptts_gp_penalty(const float* sq, float* penalty, float* coef, int B, void* stream) {
+    PTTS_REQUIRE(sq && penalty && B > 0, "gp_penalty: bad args");
+    hipLaunchKernelGGL(gp_penalty_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sq, penalty, coef, B);
+    return check_launch("gp_penalty");
+}
+
+extern "C" int ptts_gp_scale_rows(const float* g, const float* coef, const float* upstream, float* dg, int B,
+                                  long long TD, void* stream) {
+    PTTS_REQUIRE(g && coef && dg && B > 0 && B <= 65535 && TD > 0, "gp_scale_rows: bad args");
+    int bx = (int)((TD + 1023) / 1024);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(gp_scale_rows_kernel, dim3(bx, B), dim3(EW_THREADS), 0, (hipStream_t)stream, g, coef,
+                       upstream, dg, TD);
+    return check_launch("gp_scale_rows");
+}
+
+extern "C" int ptts_mean_scaled(const float* v, long long n, float sign, float* out, void* stream) {
+    PTTS_REQUIRE(v && out && n > 0, "mean_scaled: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) { set_error("mean_scaled: memset"); return PTTS_ELAUNCH; }
+    int nb = (int)((n + 4095) / 4096);
+    if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(mean_scaled_kernel, dim3(nb), dim3(256), 0, st, v, n, sign / (float)n, out);
+    return check_launch("mean_scaled");
+}
+
+extern "C" int ptts_wlse_fwd(const float* y, const float* yhat, const float* w, float* out, long long rows, int D,
+                             void* stream) {
+    PTTS_REQUIRE(y && yhat && out && rows > 0 && D > 0, "wlse_fwd: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) { set_error("wlse_fwd: memset"); return PTTS_ELAUNCH; }
+    const long long n = rows * D;
+    int nb = (int)((n + 4095) / 4096);
+    if (nb > 512) nb = 512;
+    hipLaunchKernelGGL(wlse_fwd_kernel, dim3(nb), dim3(256), 0, st, y, yhat, w, n, D, 1.f / (float)n, out);
+    return check_launch("wlse_fwd");
+}
+
+extern "C" int ptts_wlse_bwd(const float* y, const float* yhat, const float* w, const float* upstream,
+                             float* dyhat, long long rows, int D, void* stream) {
+    PTTS_REQUIRE(y && yhat && dyhat && rows > 0 && D > 0, "wlse_bwd: bad args");
+    const long long n = rows * D;
+    hipLaunchKernelGGL(wlse_bwd_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, y, yhat, w,
+                       upstream, dyhat, n, D, 1.f / (float)n);
+    return check_launch("wlse_bwd");
+}
+
+extern "C" int ptts_weight_clip(float* p, long long n, float lo, float hi, void* stream) {
+    PTTS_REQUIRE(p && n > 0 && lo <= hi, "weight_clip: bad args");
+    hipLaunchKernelGGL(weight_clip_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, p, n, lo, hi);
+    return check_launch("weight_clip");
+}
+
+extern "C" int ptts_adam_keras_step(float* p, const float* g, float* m, float* v, long long n, float lr, float b1,
+                                    float b2, float eps, float gscale, int* step, void* stream) {
+    PTTS_REQUIRE(p && g && m && v && step && n > 0, "adam: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, step);
+    int rc = check_launch("adam_tick");
+    if (rc) return rc;
+    hipLaunchKernelGGL(adam_keras_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, st, p, g, m, v, n, lr, b1, b2,
+                       eps, gscale, (const int*)step);
+    return check_launch("adam");
+}

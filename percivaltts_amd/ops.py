@@ -1,0 +1,683 @@
+"""torch.autograd.Functions over the HIP kernels of libpercival_hip.so.
+
+Every numeric op of the WGAN-GP hot path goes through the C ABI (include/percival_hip.h); torch
+supplies device memory, the autograd tape and streams only.  There is no CPU path.
+
+The layers of the reference are Linear -> (BatchNorm) -> LeakyReLU (networktts.py:59-63,116-126,
+networks_critic.py:66-68).  Here a layer's output is kept as its PRE-activation `z`; the pending
+`a = lrelu(scale*z + shift)` travels as a `Lazy` and is applied by the next linear op while it
+loads its input, so activations are never written to HBM.
+
+Second-order support (the gradient penalty differentiates a gradient,
+optimizertts_wgan.py:53-68): LeakyReLU is piecewise linear, so the backward of a
+(lrelu -> linear) layer is linear in the incoming gradient with the same masks; Conv2dBwdData /
+DenseBwdData are therefore Functions of their own whose backward is one masked forward sweep and
+one weight-gradient sweep.
+"""
+import contextlib
+import ctypes
+
+import torch
+
+from . import _hip
+from ._hip import call, ptr, stream, f32c
+
+IN_NONE, IN_LRELU, IN_MASKMUL = 0, 1, 2
+PAD_SAME, PAD_CAUSAL = 0, 1
+ACT_NONE, ACT_LRELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
+ACT_CODES = {None: ACT_NONE, 'linear': ACT_NONE, 'lrelu': ACT_LRELU, 'sigmoid': ACT_SIGMOID, 'tanh': ACT_TANH}
+
+
+class Lazy(object):
+    """A pending activation: a = act(scale*z + shift), act in {none, lrelu(alpha)}; scale/shift per channel or None."""
+    __slots__ = ('z', 'scale', 'shift', 'lrelu', 'alpha')
+
+    def __init__(self, z, scale=None, shift=None, lrelu=False, alpha=0.3):
+        self.z, self.scale, self.shift, self.lrelu, self.alpha = z, scale, shift, lrelu, alpha
+
+    @property
+    def shape(self):
+        return self.z.shape
+
+    def tensor(self):
+        """Materialise (only where no consumer can fuse the transform)."""
+        if self.scale is None and not self.lrelu:
+            return self.z
+        return affine_act(self.z, self.scale, self.shift, 'lrelu' if self.lrelu else None, self.alpha)
+
+
+def as_lazy(v):
+    return v if isinstance(v, Lazy) else Lazy(v)
+
+
+def as_tensor(v):
+    return v.tensor() if isinstance(v, Lazy) else v
+
+
+def _fusable(lz):
+    """(mode, scale, shift) a linear kernel can apply on load, or None if it must be materialised first."""
+    if lz.lrelu:
+        return IN_LRELU, lz.scale, lz.shift
+    if lz.scale is None:
+        return IN_NONE, None, None
+    return None   # affine without LeakyReLU: not a fused mode
+
+
+def _prep(v):
+    lz = as_lazy(v)
+    f = _fusable(lz)
+    if f is None:
+        return lz.tensor(), IN_NONE, None, None, lz.alpha
+    return lz.z, f[0], f[1], f[2], lz.alpha
+
+
+# ----------------------------------------------------------------------------------------------
+# g-pass switch: while the gradient penalty takes d(sum v)/d(x_hat) with create_graph=True the
+# parameter gradients of that pass are not wanted (they are not loss gradients); skipping them
+# halves the work of the pass.
+# ----------------------------------------------------------------------------------------------
+class _Flags(object):
+    skip_param_grads = False
+
+
+@contextlib.contextmanager
+def input_grad_only():
+    old = _Flags.skip_param_grads
+    _Flags.skip_param_grads = True
+    try:
+        yield
+    finally:
+        _Flags.skip_param_grads = old
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    """One growing scratch buffer per device and stream (kernels on one stream are ordered)."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream, torch.cuda.is_current_stream_capturing())
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+# ----------------------------------------------------------------------------------------------
+# raw kernel wrappers (no autograd)
+# ----------------------------------------------------------------------------------------------
+def _conv2d_fwd_raw(x, w, b, scale, shift, mask_src, mode, alpha, dil_t, pad_mode):
+    f32c(x, 'conv2d.x'); f32c(w, 'conv2d.w'); f32c(b, 'conv2d.b'); f32c(scale); f32c(shift); f32c(mask_src)
+    B, T, F, Cin = x.shape
+    KT, KF, Ci2, Cout = w.shape
+    assert Ci2 == Cin, 'conv2d: kernel Cin {} != input {}'.format(Ci2, Cin)
+    assert b is None or b.numel() == Cout
+    assert scale is None or (scale.numel() == Cin and shift.numel() == Cin)
+    assert mask_src is None or mask_src.shape == x.shape
+    y = torch.empty((B, T, F, Cout), dtype=torch.float32, device=x.device)
+    call('ptts_conv2d_fwd', ptr(x), ptr(w), ptr(b), ptr(scale), ptr(shift), ptr(mask_src), ptr(y),
+         B, T, F, Cin, Cout, KT, KF, dil_t, pad_mode, mode, alpha, stream())
+    return y
+
+
+def _conv2d_bwd_raw(dy, x, w, scale, shift, mask_src, mode, alpha, dil_t, pad_mode,
+                    want_dx, want_dw, want_db, want_affine):
+    f32c(dy, 'conv2d_bwd.dy'); f32c(x, 'conv2d_bwd.x'); f32c(w); f32c(scale); f32c(shift); f32c(mask_src)
+    B, T, F, Cin = x.shape
+    KT, KF, _, Cout = w.shape
+    assert dy.shape == (B, T, F, Cout), 'conv2d_bwd: dy shape {} vs {}'.format(tuple(dy.shape), (B, T, F, Cout))
+    assert mask_src is None or mask_src.shape == x.shape
+    dev = x.device
+    dx = torch.empty_like(x) if want_dx else None
+    dw = torch.empty_like(w) if (want_dw or want_db) else None
+    db = torch.empty(Cout, dtype=torch.float32, device=dev) if want_db else None
+    dscale = torch.empty(Cin, dtype=torch.float32, device=dev) if want_affine else None
+    dshift = torch.empty(Cin, dtype=torch.float32, device=dev) if want_affine else None
+    nws = _hip.lib().ptts_conv2d_bwd_workspace_bytes(B, T, F, Cin, Cout, KT, KF, dil_t)
+    ws = _workspace(nws, dev)
+    call('ptts_conv2d_bwd', ptr(dy), ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(mask_src),
+         ptr(dx), ptr(dw), ptr(db), ptr(dscale), ptr(dshift), ptr(ws), ws.numel(),
+         B, T, F, Cin, Cout, KT, KF, dil_t, pad_mode, mode, alpha, stream())
+    return dx, (dw if want_dw else None), db, dscale, dshift
+
+
+def gemm_raw(A, Bm, C, M, N, K, transA=0, lda=None, rows_per_seg=None, seg_stride=0, transB=0, ldb=None, ldc=None,
+             bias=None, mode=IN_NONE, scale=None, shift=None, mask_src=None, alpha=0.3, accumulate=0):
+    """C[M,N] (+)= opA(A).opB(B) (+bias).  Pointers may be views with offsets; dims are the caller's contract."""
+    for t in (A, Bm, C, bias, scale, shift, mask_src):
+        if t is not None:
+            assert t.is_cuda and t.dtype == torch.float32
+    if lda is None:
+        lda = K if transA == 0 else M
+    if rows_per_seg is None:
+        rows_per_seg = M if transA == 0 else K
+    if ldb is None:
+        ldb = N if transB == 0 else K
+    if ldc is None:
+        ldc = N
+    call('ptts_gemm', ptr(A), ptr(Bm), ptr(bias), ptr(C), M, N, K, transA, lda, rows_per_seg, seg_stride,
+         transB, ldb, ldc, mode, ptr(scale), ptr(shift), ptr(mask_src), alpha, accumulate, stream())
+    return C
+
+
+def colsums(x2d, mode=IN_NONE, scale=None, shift=None, mask_src=None, alpha=0.3):
+    """fp64 [2C]: column sums and sums of squares of transform(x)."""
+    f32c(x2d, 'colsums.x')
+    rows, C = x2d.shape
+    sums = torch.empty(2 * C, dtype=torch.float64, device=x2d.device)
+    nws = _hip.lib().ptts_colstats_workspace_bytes(rows, C)
+    ws = _workspace(nws, x2d.device)
+    call('ptts_colstats', ptr(x2d), rows, C, mode, ptr(scale), ptr(shift), ptr(mask_src), alpha, ptr(sums),
+         ptr(ws), ws.numel(), stream())
+    return sums
+
+
+def _colsum_f32(x2d):
+    return colsums(x2d)[:x2d.shape[1]].to(torch.float32)
+
+
+def _affine_act_bwd_raw(dy, x, y, scale, shift, act, alpha, want_dx=True):
+    f32c(dy, 'act_bwd.dy'); f32c(x, 'act_bwd.x')
+    C = x.shape[-1]
+    rows = x.numel() // C
+    dx = torch.empty_like(x) if want_dx else None
+    dsums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+    nws = _hip.lib().ptts_colstats_workspace_bytes(rows, C)
+    ws = _workspace(nws, x.device)
+    call('ptts_affine_act_bwd', ptr(dy), ptr(x), ptr(y), ptr(scale), ptr(shift), ptr(dx), ptr(dsums), ptr(ws),
+         ws.numel(), rows, C, act, alpha, stream())
+    return dx, dsums[:C].to(torch.float32), dsums[C:].to(torch.float32)
+
+
+# ----------------------------------------------------------------------------------------------
+# Conv2D  (kl.Conv2D: networks_critic.py:67; networktts.py:123; modeltts_common.py:100)
+# ----------------------------------------------------------------------------------------------
+class Conv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, scale, shift, mode, alpha, dil_t, pad_mode):
+        ctx.save_for_backward(x, w, scale, shift)
+        ctx.has_b = b is not None
+        ctx.cfg = (mode, alpha, dil_t, pad_mode)
+        return _conv2d_fwd_raw(x, w, b, scale, shift, None, mode, alpha, dil_t, pad_mode)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, scale, shift = ctx.saved_tensors
+        mode, alpha, dil_t, pad_mode = ctx.cfg
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_b and ctx.needs_input_grad[2]
+        need_aff = scale is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+        dy = dy.contiguous()
+        if _Flags.skip_param_grads:
+            need_w = need_b = need_aff = False
+        if torch.is_grad_enabled() and need_x:
+            # differentiable backward (gradient penalty): dx is itself a Function of (dy, w)
+            if scale is not None:
+                raise RuntimeError('second-order gradients through a BatchNorm-fused conv2d are not supported')
+            dx = Conv2dBwdDataFn.apply(dy, x, w, mode, alpha, dil_t, pad_mode)
+            dw = db = None
+            if need_w or need_b:
+                with torch.no_grad():
+                    _, dw, db, _, _ = _conv2d_bwd_raw(dy, x, w, None, None, None, mode, alpha, dil_t, pad_mode,
+                                                      False, need_w, need_b, False)
+            return dx, dw, db, None, None, None, None, None, None
+        dx, dw, db, dscale, dshift = _conv2d_bwd_raw(dy, x, w, scale, shift, None, mode, alpha, dil_t, pad_mode,
+                                                     need_x, need_w, need_b, need_aff)
+        return dx, dw, db, dscale, dshift, None, None, None, None
+
+
+class Conv2dBwdDataFn(torch.autograd.Function):
+    """dx = d(a)/d(x) * conv^T(dy, w).  Linear in dy and in w; its backward is the second-order sweep."""
+    @staticmethod
+    def forward(ctx, dy, x, w, mode, alpha, dil_t, pad_mode):
+        ctx.save_for_backward(dy, x, w)
+        ctx.cfg = (mode, alpha, dil_t, pad_mode)
+        dx, _, _, _, _ = _conv2d_bwd_raw(dy, x, w, None, None, None, mode, alpha, dil_t, pad_mode,
+                                         True, False, False, False)
+        return dx
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, u):
+        dy, x, w = ctx.saved_tensors
+        mode, alpha, dil_t, pad_mode = ctx.cfg
+        u = u.contiguous()
+        m2, msk = (IN_MASKMUL, x) if mode == IN_LRELU else (IN_NONE, None)
+        cot_dy = cot_w = None
+        if ctx.needs_input_grad[0]:
+            cot_dy = _conv2d_fwd_raw(u, w, None, None, None, msk, m2, alpha, dil_t, pad_mode)
+        if ctx.needs_input_grad[2]:
+            _, cot_w, _, _, _ = _conv2d_bwd_raw(dy, u, w, None, None, msk, m2, alpha, dil_t, pad_mode,
+                                                False, True, False, False)
+        return cot_dy, None, cot_w, None, None, None, None
+
+
+def conv2d(v, w, b=None, dil_t=1, pad_mode=PAD_SAME):
+    """z_out = conv2d(act(v), w) + b on [B,T,F,Cin]; `v` is a tensor or a Lazy."""
+    z, mode, scale, shift, alpha = _prep(v)
+    return Conv2dFn.apply(z, w, b, scale, shift, mode, alpha, dil_t, pad_mode)
+
+
+# ----------------------------------------------------------------------------------------------
+# Dense  (keras Dense: networktts.py:60 and the heads)
+# ----------------------------------------------------------------------------------------------
+def _dense_bwd_data(dy2, x2, w, mode, scale, shift, alpha, want_affine):
+    """da = dy.W^T then dx = da * lrelu'(p) * scale (+ dscale/dshift sums)."""
+    M, N = dy2.shape
+    K = w.shape[0]
+    da = torch.empty((M, K), dtype=torch.float32, device=dy2.device)
+    gemm_raw(dy2, w, da, M, K, N, transB=1, ldb=N)
+    if mode == IN_NONE:
+        return da, None, None
+    dx, dscale, dshift = _affine_act_bwd_raw(da, x2, None, scale, shift, ACT_LRELU, alpha)
+    if not want_affine:
+        dscale = dshift = None
+    return dx, dscale, dshift
+
+
+class DenseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, scale, shift, mode, alpha):
+        f32c(x, 'dense.x'); f32c(w, 'dense.w')
+        K, N = w.shape
+        assert x.shape[-1] == K, 'dense: input width {} != kernel rows {}'.format(x.shape[-1], K)
+        M = x.numel() // K
+        y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+        gemm_raw(x, w, y, M, N, K, bias=b, mode=mode, scale=scale, shift=shift, alpha=alpha)
+        ctx.save_for_backward(x, w, scale, shift)
+        ctx.has_b = b is not None
+        ctx.cfg = (mode, alpha)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, scale, shift = ctx.saved_tensors
+        mode, alpha = ctx.cfg
+        K, N = w.shape
+        M = x.numel() // K
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_b and ctx.needs_input_grad[2]
+        need_aff = scale is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+        if _Flags.skip_param_grads:
+            need_w = need_b = need_aff = False
+        dy = dy.contiguous()
+        dy2, x2 = dy.view(M, N), x.view(M, K)
+        second_order = torch.is_grad_enabled() and need_x
+        dx = dw = db = dscale = dshift = None
+        if second_order:
+            if scale is not None:
+                raise RuntimeError('second-order gradients through a BatchNorm-fused dense layer are not supported')
+            dx = DenseBwdDataFn.apply(dy, x, w, mode, alpha)
+        with torch.no_grad():
+            if need_x and not second_order:
+                dx2, dscale, dshift = _dense_bwd_data(dy2, x2, w, mode, scale, shift, alpha, need_aff)
+                dx = dx2.view(x.shape)
+            elif need_aff:
+                _, dscale, dshift = _dense_bwd_data(dy2, x2, w, mode, scale, shift, alpha, True)
+            if need_w:
+                dw = torch.empty_like(w)
+                gemm_raw(x2, dy2, dw, K, N, M, transA=1, lda=K, rows_per_seg=M,
+                         mode=mode, scale=scale, shift=shift, alpha=alpha)
+            if need_b:
+                db = _colsum_f32(dy2)
+        return dx, dw, db, dscale, dshift, None, None
+
+
+class DenseBwdDataFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dy, x, w, mode, alpha):
+        K, N = w.shape
+        M = x.numel() // K
+        ctx.save_for_backward(dy, x, w)
+        ctx.cfg = (mode, alpha)
+        dx2, _, _ = _dense_bwd_data(dy.view(M, N), x.view(M, K), w, mode, None, None, alpha, False)
+        return dx2.view(x.shape)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, u):
+        dy, x, w = ctx.saved_tensors
+        mode, alpha = ctx.cfg
+        K, N = w.shape
+        M = x.numel() // K
+        u2 = u.contiguous().view(M, K)
+        m2, msk = (IN_MASKMUL, x.view(M, K)) if mode == IN_LRELU else (IN_NONE, None)
+        cot_dy = cot_w = None
+        if ctx.needs_input_grad[0]:
+            cot_dy = torch.empty((M, N), dtype=torch.float32, device=u.device)
+            gemm_raw(u2, w, cot_dy, M, N, K, mode=m2, mask_src=msk, alpha=alpha)
+            cot_dy = cot_dy.view(dy.shape)
+        if ctx.needs_input_grad[2]:
+            cot_w = torch.empty_like(w)
+            gemm_raw(u2, dy.view(M, N), cot_w, K, N, M, transA=1, lda=K, rows_per_seg=M,
+                     mode=m2, mask_src=msk, alpha=alpha)
+        return cot_dy, None, cot_w, None, None
+
+
+def dense(v, w, b=None):
+    """z_out = act(v).W + b over the last axis."""
+    z, mode, scale, shift, alpha = _prep(v)
+    return DenseFn.apply(z, w, b, scale, shift, mode, alpha)
+
+
+# ----------------------------------------------------------------------------------------------
+# Conv1D over time as an implicit GEMM  (kl.Conv1D: networktts.py:117)
+# ----------------------------------------------------------------------------------------------
+def _pad_time(a, lo, hi):
+    B, T, C = a.shape
+    ap = torch.zeros((B, T + lo + hi, C), dtype=torch.float32, device=a.device)
+    ap[:, lo:lo + T].copy_(a)
+    return ap
+
+
+class Conv1dFn(torch.autograd.Function):
+    """y[b,t,:] = b + sum_k a[b,t+k-pl,:].w[k];  `a` (already activated) is given, 'same' zero padding."""
+    @staticmethod
+    def forward(ctx, a, w, b):
+        f32c(a, 'conv1d.a'); f32c(w, 'conv1d.w')
+        B, T, Cin = a.shape
+        KW, Ci2, N = w.shape
+        assert Ci2 == Cin
+        pl = (KW - 1) // 2
+        ap = _pad_time(a, pl, KW - 1 - pl)
+        y = torch.empty((B, T, N), dtype=torch.float32, device=a.device)
+        gemm_raw(ap, w, y, B * T, N, KW * Cin, lda=Cin, rows_per_seg=T, seg_stride=(T + KW - 1) * Cin, bias=b)
+        ctx.save_for_backward(ap, w)
+        ctx.has_b = b is not None
+        ctx.dims = (B, T, Cin, KW, N, pl)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        ap, w = ctx.saved_tensors
+        B, T, Cin, KW, N, pl = ctx.dims
+        dy = dy.contiguous()
+        da = dw = db = None
+        if ctx.needs_input_grad[1] and not _Flags.skip_param_grads:
+            dw = torch.empty_like(w)
+            gemm_raw(ap, dy, dw, KW * Cin, N, B * T, transA=1, lda=Cin, rows_per_seg=T,
+                     seg_stride=(T + KW - 1) * Cin)
+        if ctx.has_b and ctx.needs_input_grad[2] and not _Flags.skip_param_grads:
+            db = _colsum_f32(dy.view(B * T, N))
+        if ctx.needs_input_grad[0]:
+            # da[b,t,:] = sum_j dyp[b,t+j,:] . wf[j],  wf[j,n,ci] = w[KW-1-j,ci,n],  dyp padded (KW-1-pl, pl)
+            dyp = _pad_time(dy, KW - 1 - pl, pl)
+            wf = w.flip(0).permute(0, 2, 1).contiguous()
+            da = torch.empty((B, T, Cin), dtype=torch.float32, device=dy.device)
+            gemm_raw(dyp, wf, da, B * T, Cin, KW * N, lda=N, rows_per_seg=T, seg_stride=(T + KW - 1) * N)
+        return da, dw, db
+
+
+def conv1d(v, w, b=None):
+    return Conv1dFn.apply(as_tensor(v), w, b)
+
+
+# ----------------------------------------------------------------------------------------------
+# BatchNormalization(axis=-1)  (networktts.py:61,118,124,132) -> per-channel affine for the consumer
+# ----------------------------------------------------------------------------------------------
+BN_EPS, BN_MOMENTUM = 1e-3, 0.99   # Keras defaults
+
+
+class BatchNormTrainFn(torch.autograd.Function):
+    """(scale, shift) from the batch statistics of z [.., C]; updates the moving statistics in place."""
+    @staticmethod
+    def forward(ctx, z, gamma, beta, moving_mean, moving_var, update_moving, unbiased_moving):
+        f32c(z, 'bn.z')
+        C = z.shape[-1]
+        rows = z.numel() // C
+        sums = colsums(z.view(rows, C))
+        dev = z.device
+        scale = torch.empty(C, dtype=torch.float32, device=dev)
+        shift = torch.empty(C, dtype=torch.float32, device=dev)
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        rstd = torch.empty(C, dtype=torch.float32, device=dev)
+        call('ptts_bn_finalize', ptr(sums), rows, ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var),
+             BN_EPS, BN_MOMENTUM, 1, 1 if update_moving else 0, 1 if unbiased_moving else 0, C,
+             ptr(scale), ptr(shift), ptr(mean), ptr(rstd), stream())
+        ctx.save_for_backward(z, gamma, mean, rstd)
+        return scale, shift
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dscale, dshift):
+        z, gamma, mean, rstd = ctx.saved_tensors
+        C = z.shape[-1]
+        rows = z.numel() // C
+        dev = z.device
+        dscale = dscale.contiguous() if dscale is not None else torch.zeros(C, dtype=torch.float32, device=dev)
+        dshift = dshift.contiguous() if dshift is not None else torch.zeros(C, dtype=torch.float32, device=dev)
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        c0 = torch.empty(C, dtype=torch.float32, device=dev)
+        c2 = torch.empty(C, dtype=torch.float32, device=dev)
+        call('ptts_bn_bwd_coefs', ptr(dscale), ptr(dshift), ptr(mean), ptr(rstd), ptr(gamma), rows, C,
+             ptr(dgamma), ptr(dbeta), ptr(c0), ptr(c2), stream())
+        dz = None
+        if ctx.needs_input_grad[0]:
+            dz = torch.empty_like(z)
+            call('ptts_axpby_cols', None, None, ptr(z), ptr(c2), ptr(c0), ptr(dz), rows, C, stream())
+        return dz, dgamma, dbeta, None, None, None, None
+
+
+def batchnorm_affine(z, gamma, beta, moving_mean, moving_var, training, update_moving=True, unbiased_moving=False):
+    """Returns (scale, shift) such that BN(z) = scale*z + shift."""
+    if training:
+        return BatchNormTrainFn.apply(z, gamma, beta, moving_mean, moving_var, update_moving, unbiased_moving)
+    C = z.shape[-1]
+    scale = torch.empty(C, dtype=torch.float32, device=z.device)
+    shift = torch.empty(C, dtype=torch.float32, device=z.device)
+    call('ptts_bn_finalize', None, 1, ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var), BN_EPS, BN_MOMENTUM,
+         0, 0, 0, C, ptr(scale), ptr(shift), None, None, stream())
+    return scale, shift
+
+
+# ----------------------------------------------------------------------------------------------
+# materialised activation
+# ----------------------------------------------------------------------------------------------
+class AffineActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale, shift, act, alpha):
+        f32c(x, 'affine_act.x')
+        C = x.shape[-1]
+        rows = x.numel() // C
+        y = torch.empty_like(x)
+        call('ptts_affine_act', ptr(x), ptr(scale), ptr(shift), ptr(y), rows, C, act, alpha, stream())
+        ctx.save_for_backward(x, y, scale, shift)
+        ctx.cfg = (act, alpha)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, y, scale, shift = ctx.saved_tensors
+        act, alpha = ctx.cfg
+        dx, dscale, dshift = _affine_act_bwd_raw(dy.contiguous(), x, y, scale, shift, act, alpha,
+                                                 want_dx=ctx.needs_input_grad[0])
+        if scale is None:
+            dscale = dshift = None
+        return dx, dscale, dshift, None, None
+
+
+def affine_act(x, scale=None, shift=None, act=None, alpha=0.3):
+    return AffineActFn.apply(x.contiguous(), scale, shift, ACT_CODES[act], alpha)
+
+
+# ----------------------------------------------------------------------------------------------
+# LSTM / Bidirectional LSTM (networktts.py:72-96)
+# ----------------------------------------------------------------------------------------------
+class LSTMFn(torch.autograd.Function):
+    """x [B,T,In]; W [In, ndir*4H]; U [ndir,H,4H]; b [ndir*4H] -> h [B,T,ndir*H] (Keras gate order i,f,c,o)."""
+    @staticmethod
+    def forward(ctx, x, W, U, b, reverse):
+        f32c(x, 'lstm.x'); f32c(W); f32c(U); f32c(b)
+        B, T, In = x.shape
+        ndir, H, G4 = U.shape
+        assert G4 == 4 * H and W.shape == (In, ndir * G4)
+        dev = x.device
+        xproj = torch.empty((B, T, ndir * G4), dtype=torch.float32, device=dev)
+        gemm_raw(x, W, xproj, B * T, ndir * G4, In, bias=b)
+        h = torch.empty((B, T, ndir * H), dtype=torch.float32, device=dev)
+        c = torch.empty((B, T, ndir * H), dtype=torch.float32, device=dev)
+        gates = torch.empty((B, T, ndir * G4), dtype=torch.float32, device=dev)
+        call('ptts_lstm_fwd', ptr(xproj), ptr(U), ptr(h), ptr(gates), ptr(c), B, T, H, ndir, int(reverse), stream())
+        ctx.save_for_backward(x, W, U, h, c, gates)
+        ctx.reverse = int(reverse)
+        return h
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dh):
+        x, W, U, h, c, gates = ctx.saved_tensors
+        B, T, In = x.shape
+        ndir, H, G4 = U.shape
+        dev = x.device
+        dh = dh.contiguous()
+        dgates = torch.empty_like(gates)
+        nws = _hip.lib().ptts_lstm_bwd_workspace_bytes(B, T, H, ndir)
+        ws = _workspace(nws, dev)
+        call('ptts_lstm_bwd', ptr(dh), ptr(U), ptr(gates), ptr(c), ptr(dgates), ptr(ws), ws.numel(),
+             B, T, H, ndir, ctx.reverse, stream())
+        M = B * T
+        dx = dW = dU = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm_raw(dgates, W, dx, M, In, ndir * G4, transB=1, ldb=ndir * G4)
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty_like(W)
+            gemm_raw(x, dgates, dW, In, ndir * G4, M, transA=1, lda=In, rows_per_seg=M)
+        if ctx.needs_input_grad[3]:
+            db = _colsum_f32(dgates.view(M, ndir * G4))
+        if ctx.needs_input_grad[2]:
+            # dU[d] = sum_t h_prev[d]^T . dgates[d]; h_prev is h shifted by one step in the walking direction
+            hprev = torch.zeros_like(h)
+            for d in range(ndir):
+                rev = (d == 1) if ndir == 2 else bool(ctx.reverse)
+                sl = slice(d * H, (d + 1) * H)
+                if T > 1:
+                    if rev:
+                        hprev[:, :-1, sl].copy_(h[:, 1:, sl])
+                    else:
+                        hprev[:, 1:, sl].copy_(h[:, :-1, sl])
+            dU = torch.empty_like(U)
+            for d in range(ndir):
+                gemm_raw(hprev.view(M, ndir * H)[:, d * H:], dgates.view(M, ndir * G4)[:, d * G4:], dU[d],
+                         H, G4, M, transA=1, lda=ndir * H, rows_per_seg=M, ldb=ndir * G4)
+        return dx, dW, dU, db, None
+
+
+def lstm(v, W, U, b, reverse=False):
+    return LSTMFn.apply(as_tensor(v).contiguous(), W, U, b, reverse)
+
+
+# ----------------------------------------------------------------------------------------------
+# WGAN-GP pieces (optimizertts_wgan.py:44-79)
+# ----------------------------------------------------------------------------------------------
+def gp_interpolate(real, fake, alpha_b):
+    """RandomWeightedAverage: alpha_b [B] per-sample weights (optimizertts_wgan.py:44-51)."""
+    f32c(real, 'gp.real'); f32c(fake, 'gp.fake'); f32c(alpha_b, 'gp.alpha')
+    assert real.shape == fake.shape and alpha_b.numel() == real.shape[0]
+    out = torch.empty_like(real)
+    B = real.shape[0]
+    call('ptts_gp_interpolate', ptr(real), ptr(fake), ptr(alpha_b), ptr(out), B, real.numel() // B, stream())
+    return out
+
+
+class GradPenaltyFn(torch.autograd.Function):
+    """mean_b (1 - ||g_b||_2)^2 (gradient_penalty_loss, optimizertts_wgan.py:53-68)."""
+    @staticmethod
+    def forward(ctx, g):
+        f32c(g, 'gp.g')
+        B = g.shape[0]
+        TD = g.numel() // B
+        sq = torch.empty(B, dtype=torch.float32, device=g.device)
+        pen = torch.empty(1, dtype=torch.float32, device=g.device)
+        coef = torch.empty(B, dtype=torch.float32, device=g.device)
+        call('ptts_gp_sqnorm', ptr(g), ptr(sq), B, TD, stream())
+        call('ptts_gp_penalty', ptr(sq), ptr(pen), ptr(coef), B, stream())
+        ctx.save_for_backward(g, coef)
+        return pen.view(())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, up):
+        g, coef = ctx.saved_tensors
+        B = g.shape[0]
+        dg = torch.empty_like(g)
+        up = up.contiguous().view(1)
+        call('ptts_gp_scale_rows', ptr(g), ptr(coef), ptr(up), ptr(dg), B, g.numel() // B, stream())
+        return dg
+
+
+def grad_penalty(g):
+    return GradPenaltyFn.apply(g.contiguous())
+
+
+class MeanScaledFn(torch.autograd.Function):
+    """sign * mean(v): wasserstein_loss with a constant +-1 target (optimizertts_wgan.py:70-71,152-153)."""
+    @staticmethod
+    def forward(ctx, v, sign):
+        f32c(v, 'wasserstein.v')
+        out = torch.empty(1, dtype=torch.float32, device=v.device)
+        call('ptts_mean_scaled', ptr(v), v.numel(), float(sign), ptr(out), stream())
+        ctx.sign, ctx.shape = float(sign), v.shape
+        return out.view(())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, up):
+        n = 1
+        for s in ctx.shape:
+            n *= s
+        return (up * (ctx.sign / n)).expand(ctx.shape).contiguous(), None
+
+
+def wasserstein(v, sign):
+    return MeanScaledFn.apply(v.contiguous(), sign)
+
+
+class WLSEFn(torch.autograd.Function):
+    """mean((y - yhat)^2 * w[d]) (specweighted_lse_loss :73-79; w=None gives lse_loss optimizertts.py:56-57)."""
+    @staticmethod
+    def forward(ctx, yhat, y, w):
+        f32c(yhat, 'wlse.yhat'); f32c(y, 'wlse.y'); f32c(w)
+        assert yhat.shape == y.shape
+        D = y.shape[-1]
+        rows = y.numel() // D
+        out = torch.empty(1, dtype=torch.float32, device=y.device)
+        call('ptts_wlse_fwd', ptr(y), ptr(yhat), ptr(w), ptr(out), rows, D, stream())
+        ctx.save_for_backward(yhat, y, w)
+        return out.view(())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, up):
+        yhat, y, w = ctx.saved_tensors
+        D = y.shape[-1]
+        rows = y.numel() // D
+        d = torch.empty_like(yhat)
+        up = up.contiguous().view(1)
+        call('ptts_wlse_bwd', ptr(y), ptr(yhat), ptr(w), ptr(up), ptr(d), rows, D, stream())
+        return d, None, None
+
+
+def wlse(yhat, y, w=None):
+    return WLSEFn.apply(yhat.contiguous(), y.contiguous(), w)
+
+
+# ----------------------------------------------------------------------------------------------
+# optimiser-side kernels
+# ----------------------------------------------------------------------------------------------
+def weight_clip_(p, lo, hi):
+    """In-place clamp of a flat parameter buffer (north_star extra; no reference counterpart)."""
+    f32c(p, 'clip.p')
+    call('ptts_weight_clip', ptr(p), p.numel(), float(lo), float(hi), stream())
+    return p
+
+
+def adam_keras_step_(p, g, m, v, step, lr, b1, b2, eps, gscale=1.0):
+    """Keras-2.2 Adam on flat buffers; `step` is a device int32 scalar incremented by the kernel."""
+    for t in (p, g, m, v):
+        f32c(t, 'adam')
+    assert p.numel() == g.numel() == m.numel() == v.numel()
+    assert step.is_cuda and step.dtype == torch.int32
+    call('ptts_adam_keras_step', ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(b1), float(b2),
+         float(eps), float(gscale), ptr(step), stream())

@@ -1,0 +1,413 @@
+"""GPU parity of every HIP op (through the C ABI) against the CPU oracle, on seeded inputs.
+fp32 kernels vs fp64 oracle: rtol 1e-4 / atol 1e-5 unless a test states otherwise
+(the north star's bar is 1e-3 rtol)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import percival_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RT, AT = 1e-4, 1e-5
+
+
+def dev(t, grad=False):
+    return t.detach().to(torch.float32).cuda().contiguous().requires_grad_(grad)
+
+
+def ref(t, grad=False):
+    return t.detach().to(torch.float64).cpu().requires_grad_(grad)
+
+
+def close(got, want, rtol=RT, atol=AT, what=''):
+    got = got.detach().cpu().to(torch.float64)
+    want = want.detach().to(torch.float64)
+    assert got.shape == want.shape, '{}: shape {} vs {}'.format(what, tuple(got.shape), tuple(want.shape))
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    bad = err > tol
+    if bad.any():
+        i = int(torch.argmax(err - tol))
+        raise AssertionError('{}: {} / {} mismatches, worst |err|={:.3e} at flat {} (got {:.6e}, want {:.6e}), max|want|={:.3e}'.format(
+            what, int(bad.sum()), bad.numel(), float(err.flatten()[i]), i, float(got.flatten()[i]),
+            float(want.flatten()[i]), float(want.abs().max())))
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from percivaltts_amd import ops as _ops
+    return _ops
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def test_library_identity():
+    from percivaltts_amd import _hip
+    assert _hip.lib().ptts_device_arch() == b'gfx950'
+    assert torch.cuda.is_available()
+
+
+CONV_CASES = [
+    # B, T, F, Cin, Cout, KT, KF, dil, causal
+    (2, 12, 9, 1, 4, 5, 5, 1, False),
+    (2, 12, 9, 4, 4, 5, 5, 1, False),
+    (2, 12, 9, 4, 1, 5, 5, 1, False),
+    (2, 12, 9, 1, 2, 3, 3, 1, False),
+    (2, 12, 9, 2, 2, 3, 3, 1, False),
+    (2, 12, 9, 2, 1, 3, 3, 1, False),
+    (3, 100, 65, 4, 4, 5, 5, 1, False),     # several time tiles, real frequency width
+    (1, 37, 129, 4, 4, 5, 5, 1, False),     # reference-shaped F
+    (2, 50, 65, 4, 4, 5, 5, 2, True),       # dilated causal (config 5 extension)
+    (2, 10, 7, 3, 5, 3, 3, 1, False),       # generic fallback kernels
+    (1, 3, 2, 1, 4, 5, 5, 1, False),        # image smaller than the kernel
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+@pytest.mark.parametrize('mode', ['none', 'lrelu', 'affine'])
+def test_conv2d_forward_backward(ops, case, mode):
+    B, T, F, Cin, Cout, KT, KF, dil, causal = case
+    g = gen(1)
+    x = torch.randn(B, T, F, Cin, generator=g, dtype=torch.float64)
+    w = torch.randn(KT, KF, Cin, Cout, generator=g, dtype=torch.float64) * 0.3
+    b = torch.randn(Cout, generator=g, dtype=torch.float64)
+    sc = torch.rand(Cin, generator=g, dtype=torch.float64) + 0.5
+    sh = torch.randn(Cin, generator=g, dtype=torch.float64) * 0.3
+    dy = torch.randn(B, T, F, Cout, generator=g, dtype=torch.float64)
+
+    xr, wr, br, scr, shr = ref(x, True), ref(w, True), ref(b, True), ref(sc, True), ref(sh, True)
+    if mode == 'none':
+        a = xr
+    elif mode == 'lrelu':
+        a = O.lrelu(xr)
+    else:
+        a = O.lrelu(xr * scr + shr)
+    yr = O.conv2d_nhwc(a, wr, br, dil_t=dil, causal=causal)
+    yr.backward(dy)
+
+    xd, wd, bd, scd, shd = dev(x, True), dev(w, True), dev(b, True), dev(sc, True), dev(sh, True)
+    if mode == 'none':
+        v = xd
+    elif mode == 'lrelu':
+        v = ops.Lazy(xd, lrelu=True)
+    else:
+        v = ops.Lazy(xd, scd, shd, lrelu=True)
+    yd = ops.conv2d(v, wd, bd, dil_t=dil, pad_mode=ops.PAD_CAUSAL if causal else ops.PAD_SAME)
+    close(yd, yr, what='y')
+    yd.backward(dev(dy))
+    close(xd.grad, xr.grad, what='dx')
+    close(wd.grad, wr.grad, rtol=2e-4, atol=1e-4, what='dw')
+    close(bd.grad, br.grad, rtol=2e-4, atol=1e-4, what='db')
+    if mode == 'affine':
+        close(scd.grad, scr.grad, rtol=2e-4, atol=1e-4, what='dscale')
+        close(shd.grad, shr.grad, rtol=2e-4, atol=1e-4, what='dshift')
+
+
+@pytest.mark.parametrize('case', [(2, 12, 9, 2, 3, 3), (2, 40, 65, 4, 5, 5)])
+def test_conv2d_stack_second_order(ops, case):
+    """The gradient-penalty pattern: differentiate ||d(sum v)/dx||^2 w.r.t. the kernels of a
+    (conv -> lrelu -> conv -> lrelu -> conv) stack (optimizertts_wgan.py:53-68)."""
+    B, T, F, C, KT, KF = case
+    g = gen(2)
+    x = torch.randn(B, T, F, 1, generator=g, dtype=torch.float64)
+    ws = [torch.randn(KT, KF, 1, C, generator=g, dtype=torch.float64) * 0.4,
+          torch.randn(KT, KF, C, C, generator=g, dtype=torch.float64) * 0.3,
+          torch.randn(KT, KF, C, 1, generator=g, dtype=torch.float64) * 0.3]
+    bs = [torch.randn(s.shape[-1], generator=g, dtype=torch.float64) * 0.2 for s in ws]
+
+    xr = ref(x, True); wr = [ref(w, True) for w in ws]; br = [ref(b, True) for b in bs]
+    h = O.conv2d_nhwc(xr, wr[0], br[0])
+    h = O.conv2d_nhwc(O.lrelu(h), wr[1], br[1])
+    v = O.conv2d_nhwc(O.lrelu(h), wr[2], br[2])
+    gr = torch.autograd.grad(v.sum(), xr, create_graph=True)[0]
+    lossr = (gr * gr).sum() + v.mean()
+    lossr.backward()
+
+    xd = dev(x, True); wd = [dev(w, True) for w in ws]; bd = [dev(b, True) for b in bs]
+    h = ops.conv2d(xd, wd[0], bd[0])
+    h = ops.conv2d(ops.Lazy(h, lrelu=True), wd[1], bd[1])
+    vd = ops.conv2d(ops.Lazy(h, lrelu=True), wd[2], bd[2])
+    with ops.input_grad_only():
+        gd = torch.autograd.grad(vd, xd, grad_outputs=torch.ones_like(vd), create_graph=True)[0]
+    close(gd, gr, what='g')
+    lossd = (gd * gd).sum() + vd.mean()
+    lossd.backward()
+    for i in range(3):
+        close(wd[i].grad, wr[i].grad, rtol=3e-4, atol=1e-4, what='dw%d' % i)
+        close(bd[i].grad, br[i].grad, rtol=3e-4, atol=1e-4, what='db%d' % i)
+
+
+GEMM_CASES = [
+    # M, N, K, transA, transB
+    (128, 128, 16, 0, 0), (130, 70, 33, 0, 0), (257, 129, 100, 0, 1), (64, 300, 77, 1, 0), (50, 40, 30, 1, 1),
+    (256, 256, 4096, 1, 0),      # split-K path (weight-gradient shape)
+    (1000, 1, 256, 0, 0), (256, 1, 1000, 1, 0),
+]
+
+
+@pytest.mark.parametrize('case', GEMM_CASES)
+def test_gemm(ops, case):
+    M, N, K, ta, tb = case
+    g = gen(3)
+    A = torch.randn(M, K, generator=g, dtype=torch.float64)
+    Bm = torch.randn(K, N, generator=g, dtype=torch.float64)
+    bias = torch.randn(N, generator=g, dtype=torch.float64)
+    want = A @ Bm + bias
+    As = dev(A.t() if ta else A)
+    Bs = dev(Bm.t() if tb else Bm)
+    C = torch.empty(M, N, dtype=torch.float32, device='cuda')
+    ops.gemm_raw(As, Bs, C, M, N, K, transA=ta, transB=tb, bias=dev(bias))
+    close(C, want, rtol=2e-4, atol=2e-4 * math.sqrt(K), what='C')
+    # accumulate
+    ops.gemm_raw(As, Bs, C, M, N, K, transA=ta, transB=tb, accumulate=1)
+    close(C, 2 * want - bias, rtol=2e-4, atol=4e-4 * math.sqrt(K), what='C+=')
+
+
+def test_gemm_transforms(ops):
+    g = gen(4)
+    M, N, K = 200, 96, 50
+    A = torch.randn(M, K, generator=g, dtype=torch.float64)
+    Bm = torch.randn(K, N, generator=g, dtype=torch.float64)
+    sc = torch.rand(K, generator=g, dtype=torch.float64) + 0.5
+    sh = torch.randn(K, generator=g, dtype=torch.float64)
+    msk = torch.randn(M, K, generator=g, dtype=torch.float64)
+    C = torch.empty(M, N, dtype=torch.float32, device='cuda')
+    ops.gemm_raw(dev(A), dev(Bm), C, M, N, K, mode=ops.IN_LRELU, scale=dev(sc), shift=dev(sh))
+    close(C, O.lrelu(A * sc + sh) @ Bm, rtol=2e-4, atol=1e-3, what='lrelu-affine')
+    ops.gemm_raw(dev(A), dev(Bm), C, M, N, K, mode=ops.IN_MASKMUL, mask_src=dev(msk))
+    close(C, (A * torch.where(msk > 0, 1.0, 0.3)) @ Bm, rtol=2e-4, atol=1e-3, what='maskmul')
+    # transA with the transform on the stored column (weight gradient of a fused layer)
+    D = torch.randn(M, N, generator=g, dtype=torch.float64)
+    W = torch.empty(K, N, dtype=torch.float32, device='cuda')
+    ops.gemm_raw(dev(A), dev(D), W, K, N, M, transA=1, lda=K, rows_per_seg=M, mode=ops.IN_LRELU, scale=dev(sc), shift=dev(sh))
+    close(W, O.lrelu(A * sc + sh).t() @ D, rtol=2e-4, atol=1e-3, what='transA-lrelu')
+
+
+@pytest.mark.parametrize('mode', ['none', 'lrelu', 'affine'])
+@pytest.mark.parametrize('shape', [(2, 8, 11, 5), (3, 50, 300, 130)])
+def test_dense_forward_backward(ops, mode, shape):
+    B, T, K, N = shape
+    g = gen(5)
+    x = torch.randn(B, T, K, generator=g, dtype=torch.float64)
+    w = torch.randn(K, N, generator=g, dtype=torch.float64) / math.sqrt(K)
+    b = torch.randn(N, generator=g, dtype=torch.float64)
+    sc = torch.rand(K, generator=g, dtype=torch.float64) + 0.5
+    sh = torch.randn(K, generator=g, dtype=torch.float64) * 0.3
+    dy = torch.randn(B, T, N, generator=g, dtype=torch.float64)
+    xr, wr, br, scr, shr = ref(x, True), ref(w, True), ref(b, True), ref(sc, True), ref(sh, True)
+    a = xr if mode == 'none' else (O.lrelu(xr) if mode == 'lrelu' else O.lrelu(xr * scr + shr))
+    yr = O.dense(a, wr, br)
+    yr.backward(dy)
+    xd, wd, bd, scd, shd = dev(x, True), dev(w, True), dev(b, True), dev(sc, True), dev(sh, True)
+    v = xd if mode == 'none' else (ops.Lazy(xd, lrelu=True) if mode == 'lrelu' else ops.Lazy(xd, scd, shd, lrelu=True))
+    yd = ops.dense(v, wd, bd)
+    close(yd, yr, rtol=2e-4, atol=1e-4, what='y')
+    yd.backward(dev(dy))
+    close(xd.grad, xr.grad, rtol=2e-4, atol=1e-4, what='dx')
+    close(wd.grad, wr.grad, rtol=2e-4, atol=2e-4, what='dw')
+    close(bd.grad, br.grad, rtol=2e-4, atol=2e-4, what='db')
+    if mode == 'affine':
+        close(scd.grad, scr.grad, rtol=2e-4, atol=2e-4, what='dscale')
+        close(shd.grad, shr.grad, rtol=2e-4, atol=2e-4, what='dshift')
+
+
+def test_dense_second_order(ops):
+    g = gen(6)
+    B, T, K, H = 2, 9, 7, 12
+    x = torch.randn(B, T, K, generator=g, dtype=torch.float64)
+    w1 = torch.randn(K, H, generator=g, dtype=torch.float64) * 0.5
+    w2 = torch.randn(H, H, generator=g, dtype=torch.float64) * 0.5
+    w3 = torch.randn(H, 1, generator=g, dtype=torch.float64) * 0.5
+    b1 = torch.randn(H, generator=g, dtype=torch.float64) * 0.2
+    xr = ref(x, True); w1r, w2r, w3r, b1r = ref(w1, True), ref(w2, True), ref(w3, True), ref(b1, True)
+    v = O.dense(O.lrelu(O.dense(O.lrelu(O.dense(xr, w1r, b1r)), w2r)), w3r)
+    gr = torch.autograd.grad(v.sum(), xr, create_graph=True)[0]
+    ((gr * gr).sum()).backward()
+    xd = dev(x, True); w1d, w2d, w3d, b1d = dev(w1, True), dev(w2, True), dev(w3, True), dev(b1, True)
+    h = ops.dense(xd, w1d, b1d)
+    h = ops.dense(ops.Lazy(h, lrelu=True), w2d)
+    vd = ops.dense(ops.Lazy(h, lrelu=True), w3d)
+    with ops.input_grad_only():
+        gd = torch.autograd.grad(vd, xd, grad_outputs=torch.ones_like(vd), create_graph=True)[0]
+    close(gd, gr, rtol=2e-4, atol=1e-4, what='g')
+    ((gd * gd).sum()).backward()
+    close(w1d.grad, w1r.grad, rtol=3e-4, atol=1e-4, what='dw1')
+    close(w2d.grad, w2r.grad, rtol=3e-4, atol=1e-4, what='dw2')
+    close(w3d.grad, w3r.grad, rtol=3e-4, atol=1e-4, what='dw3')
+    assert b1d.grad is None or float(b1d.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('case', [(2, 30, 5, 6, 3), (2, 30, 5, 6, 4), (3, 60, 37, 20, 21)])
+def test_conv1d(ops, case):
+    B, T, Cin, N, KW = case
+    g = gen(7)
+    x = torch.randn(B, T, Cin, generator=g, dtype=torch.float64)
+    w = torch.randn(KW, Cin, N, generator=g, dtype=torch.float64) * 0.2
+    b = torch.randn(N, generator=g, dtype=torch.float64)
+    dy = torch.randn(B, T, N, generator=g, dtype=torch.float64)
+    xr, wr, br = ref(x, True), ref(w, True), ref(b, True)
+    yr = O.conv1d_ntc(O.lrelu(xr), wr, br)
+    yr.backward(dy)
+    xd, wd, bd = dev(x, True), dev(w, True), dev(b, True)
+    yd = ops.conv1d(ops.Lazy(xd, lrelu=True), wd, bd)
+    close(yd, yr, rtol=2e-4, atol=2e-4, what='y')
+    yd.backward(dev(dy))
+    close(xd.grad, xr.grad, rtol=2e-4, atol=2e-4, what='dx')
+    close(wd.grad, wr.grad, rtol=2e-4, atol=3e-4, what='dw')
+    close(bd.grad, br.grad, rtol=2e-4, atol=3e-4, what='db')
+
+
+@pytest.mark.parametrize('shape', [(4, 6, 3), (2, 50, 256), (2, 10, 9, 4), (3, 7, 300)])
+def test_batchnorm_train_and_infer(ops, shape):
+    g = gen(8)
+    C = shape[-1]
+    z = torch.randn(*shape, generator=g, dtype=torch.float64) * 2 + 0.7
+    gamma = torch.rand(C, generator=g, dtype=torch.float64) + 0.5
+    beta = torch.randn(C, generator=g, dtype=torch.float64)
+    dy = torch.randn(*shape, generator=g, dtype=torch.float64)
+    fused4d = len(shape) == 4
+    zr, gr_, br = ref(z, True), ref(gamma, True), ref(beta, True)
+    mm, mv = torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64)
+    yr = O.lrelu(O.BN(gr_, br, mm, mv)(zr, True, update=True, unbiased_moving=fused4d))
+    yr.backward(dy)
+    zd, gd, bd = dev(z, True), dev(gamma, True), dev(beta, True)
+    mmd, mvd = dev(torch.zeros(C)), dev(torch.ones(C))
+    sc, sh = ops.batchnorm_affine(zd, gd, bd, mmd, mvd, True, True, fused4d)
+    yd = ops.Lazy(zd, sc, sh, lrelu=True).tensor()
+    close(yd, yr, what='y')
+    yd.backward(dev(dy))
+    close(zd.grad, zr.grad, rtol=3e-4, atol=3e-5, what='dz')
+    close(gd.grad, gr_.grad, rtol=3e-4, atol=1e-4, what='dgamma')
+    close(bd.grad, br.grad, rtol=3e-4, atol=1e-4, what='dbeta')
+    close(mmd, mm, what='moving_mean')
+    close(mvd, mv, what='moving_var')
+    # inference mode uses the moving statistics
+    sc2, sh2 = ops.batchnorm_affine(zd.detach(), gd.detach(), bd.detach(), mmd, mvd, False)
+    yi = ops.Lazy(zd.detach(), sc2, sh2, lrelu=True).tensor()
+    close(yi, O.lrelu(O.BN(ref(gamma), ref(beta), mm, mv)(ref(z), False)), what='infer')
+
+
+@pytest.mark.parametrize('act', [None, 'lrelu', 'sigmoid', 'tanh'])
+def test_affine_act(ops, act):
+    g = gen(9)
+    x = torch.randn(3, 11, 20, generator=g, dtype=torch.float64)
+    sc = torch.rand(20, generator=g, dtype=torch.float64) + 0.5
+    sh = torch.randn(20, generator=g, dtype=torch.float64)
+    dy = torch.randn(3, 11, 20, generator=g, dtype=torch.float64)
+    f = {None: lambda t: t, 'lrelu': O.lrelu, 'sigmoid': torch.sigmoid, 'tanh': torch.tanh}[act]
+    xr, scr, shr = ref(x, True), ref(sc, True), ref(sh, True)
+    yr = f(xr * scr + shr)
+    yr.backward(dy)
+    xd, scd, shd = dev(x, True), dev(sc, True), dev(sh, True)
+    yd = ops.affine_act(xd, scd, shd, act)
+    close(yd, yr, what='y')
+    yd.backward(dev(dy))
+    close(xd.grad, xr.grad, what='dx')
+    close(scd.grad, scr.grad, rtol=2e-4, atol=1e-4, what='dscale')
+    close(shd.grad, shr.grad, rtol=2e-4, atol=1e-4, what='dshift')
+    # no affine, odd channel count (scalar path)
+    x2 = torch.randn(5, 7, generator=g, dtype=torch.float64)
+    close(ops.affine_act(dev(x2), None, None, act), f(x2), what='y-noaffine')
+
+
+@pytest.mark.parametrize('case', [(3, 7, 5, 4), (16, 20, 24, 64), (5, 33, 10, 70)])
+def test_blstm(ops, case):
+    B, T, In, H = case
+    g = gen(10)
+    x = torch.randn(B, T, In, generator=g, dtype=torch.float64)
+    W = torch.randn(In, 8 * H, generator=g, dtype=torch.float64) / math.sqrt(In)
+    U = torch.randn(2, H, 4 * H, generator=g, dtype=torch.float64) / math.sqrt(H)
+    b = torch.randn(8 * H, generator=g, dtype=torch.float64) * 0.2
+    dh = torch.randn(B, T, 2 * H, generator=g, dtype=torch.float64)
+    xr, Wr, Ur, br = ref(x, True), ref(W, True), ref(U, True), ref(b, True)
+    hr = O.blstm(xr, Wr, Ur, br)
+    hr.backward(dh)
+    xd, Wd, Ud, bd = dev(x, True), dev(W, True), dev(U, True), dev(b, True)
+    hd = ops.lstm(xd, Wd, Ud, bd)
+    close(hd, hr, rtol=2e-4, atol=2e-5, what='h')
+    hd.backward(dev(dh))
+    close(xd.grad, xr.grad, rtol=3e-4, atol=1e-4, what='dx')
+    close(Wd.grad, Wr.grad, rtol=3e-4, atol=2e-4, what='dW')
+    close(Ud.grad, Ur.grad, rtol=3e-4, atol=2e-4, what='dU')
+    close(bd.grad, br.grad, rtol=3e-4, atol=2e-4, what='db')
+
+
+def test_single_direction_lstm_reverse(ops):
+    g = gen(11)
+    B, T, In, H = 2, 6, 3, 5
+    x = torch.randn(B, T, In, generator=g, dtype=torch.float64)
+    W = torch.randn(In, 4 * H, generator=g, dtype=torch.float64)
+    U = torch.randn(1, H, 4 * H, generator=g, dtype=torch.float64) * 0.5
+    b = torch.randn(4 * H, generator=g, dtype=torch.float64) * 0.2
+    for rev in (False, True):
+        close(ops.lstm(dev(x), dev(W), dev(U), dev(b), reverse=rev), O.lstm_keras(x, W, U[0], b, reverse=rev),
+              rtol=2e-4, atol=2e-5, what='h rev=%s' % rev)
+
+
+def test_gp_and_losses(ops):
+    g = gen(12)
+    B, T, D = 5, 40, 86
+    real = torch.randn(B, T, D, generator=g, dtype=torch.float64)
+    fake = torch.randn(B, T, D, generator=g, dtype=torch.float64)
+    al = torch.rand(B, generator=g, dtype=torch.float64)
+    close(ops.gp_interpolate(dev(real), dev(fake), dev(al)), O.random_weighted_average(real, fake, al), what='x_hat')
+    gg = torch.randn(B, T, D, generator=g, dtype=torch.float64) * 0.05
+    gr = ref(gg, True)
+    n = torch.sqrt((gr * gr).sum(dim=(1, 2)))
+    pr = ((1 - n) ** 2).mean()
+    (3.0 * pr).backward()
+    gd = dev(gg, True)
+    pd = ops.grad_penalty(gd)
+    close(pd, pr, what='penalty')
+    (3.0 * pd).backward()
+    close(gd.grad, gr.grad, what='dpenalty/dg')
+    v = torch.randn(B, T, 1, generator=g, dtype=torch.float64)
+    vr = ref(v, True); (O.wasserstein_loss(-1.0, vr) * 2).backward()
+    vd = dev(v, True); wl = ops.wasserstein(vd, -1.0); (wl * 2).backward()
+    close(wl, O.wasserstein_loss(-1.0, v), what='wasserstein')
+    close(vd.grad, vr.grad, what='dwasserstein')
+    w = torch.rand(D, generator=g, dtype=torch.float64)
+    yh = ref(fake, True); (O.specweighted_lse_loss(real, yh, w) * 0.7).backward()
+    yd = dev(fake, True); l = ops.wlse(yd, dev(real), dev(w)); (l * 0.7).backward()
+    close(l, O.specweighted_lse_loss(real, fake, w), what='wlse')
+    close(yd.grad, yh.grad, what='dwlse')
+    close(ops.wlse(dev(fake), dev(real)), ((real - fake) ** 2).mean(), what='lse')
+
+
+def test_adam_keras_and_clip(ops):
+    g = gen(13)
+    n = 10007
+    p = torch.randn(n, generator=g, dtype=torch.float64)
+    m, v = torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+    pd, md, vd = dev(p), dev(m), dev(v)
+    step = torch.zeros((), dtype=torch.int32, device='cuda')
+    for t in (1, 2, 3):
+        gr = torch.randn(n, generator=g, dtype=torch.float64)
+        O.adam_keras([p], [gr], [m], [v], t, 1e-3, 0.5, 0.9, 1e-7)
+        ops.adam_keras_step_(pd, dev(gr), md, vd, step, 1e-3, 0.5, 0.9, 1e-7)
+    assert int(step.item()) == 3
+    close(pd, p, rtol=1e-5, atol=1e-6, what='adam p')
+    close(md, m, rtol=1e-5, atol=1e-7, what='adam m')
+    close(vd, v, rtol=1e-5, atol=1e-7, what='adam v')
+    # gscale = 1/world (data parallel): same as averaging the gradient first
+    p2, m2, v2 = dev(p), dev(m), dev(v)
+    p3, m3, v3 = dev(p), dev(m), dev(v)
+    s2 = torch.zeros((), dtype=torch.int32, device='cuda'); s3 = torch.zeros((), dtype=torch.int32, device='cuda')
+    gr = torch.randn(n, generator=g, dtype=torch.float64)
+    ops.adam_keras_step_(p2, dev(gr * 4), m2, v2, s2, 1e-3, 0.5, 0.9, 1e-7, gscale=0.25)
+    ops.adam_keras_step_(p3, dev(gr), m3, v3, s3, 1e-3, 0.5, 0.9, 1e-7)
+    close(p2, p3.cpu(), rtol=1e-6, atol=1e-7, what='gscale')
+    ops.weight_clip_(pd, -0.01, 0.01)
+    close(pd, p.clamp(-0.01, 0.01), rtol=1e-6, atol=1e-7, what='clip')
+    assert float(pd.abs().max()) <= 0.01 + 1e-9
+
+
+def test_cpu_tensor_is_refused(ops):
+    from percivaltts_amd._hip import HipLibraryError
+    with pytest.raises(HipLibraryError):
+        ops.gp_interpolate(torch.zeros(2, 3, 4), torch.zeros(2, 3, 4), torch.zeros(2))
