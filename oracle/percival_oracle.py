@@ -137,7 +137,7 @@ def conv2d_nhwc(x, w, b=None, dil_t=1, causal=False):
     pf_lo, pf_hi = _same_pads(KF)
     xn = x.permute(0, 3, 1, 2)                                     # NCHW, H = time, W = freq
     xn = TF.pad(xn, (pf_lo, pf_hi, pt_lo, pt_hi))
-    y = TF.conv2d(xn, w.permute(3, 2, 0, 1), b, dilation=(dil_t, 1))   # HWIO -> OIHW
+    y = TF.conv2d(xn, w.permute(3, 2, 0, 1).contiguous(), b, dilation=(dil_t, 1))   # HWIO -> OIHW
     return y.permute(0, 2, 3, 1)
 
 
@@ -145,7 +145,7 @@ def conv1d_ntc(x, w, b=None):
     KW = w.shape[0]
     lo, hi = _same_pads(KW)
     xn = TF.pad(x.permute(0, 2, 1), (lo, hi))
-    return TF.conv1d(xn, w.permute(2, 1, 0), b).permute(0, 2, 1)
+    return TF.conv1d(xn, w.permute(2, 1, 0).contiguous(), b).permute(0, 2, 1)
 
 
 def dense(x, w, b=None):

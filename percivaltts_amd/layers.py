@@ -1,0 +1,575 @@
+"""A small Keras-functional-style graph layer over the HIP ops.
+
+The reference builds its networks with the tf.keras functional API (`kl.Dense(...)(x)`,
+`keras.Model(inputs, outputs)`; networktts.py:59-225, networks_critic.py:44-96,
+modeltts_common.py:36-126).  To keep those builder functions source-compatible this module offers
+the same idiom: calling a layer on a `Node` returns a `Node`; `Model(inputs, outputs)` is a
+torch.nn.Module that evaluates the graph.  Values flowing along edges are tensors, `ops.Lazy`
+(a pending BatchNorm-affine + LeakyReLU that the consumer's kernel applies on load) or `LazyConcat`.
+
+Layouts and initialisers are the Keras ones (kernel [in,out], HWIO conv kernels, glorot_uniform,
+orthogonal recurrent kernels, unit forget bias, BN gamma/beta/moving_mean/moving_variance), so
+`count_params()` agrees with the reference's known answer (tests/test_smoke_tensorflowkeras.py:53).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import Lazy
+
+
+# --------------------------------------------------------------------------------------------
+# values
+# --------------------------------------------------------------------------------------------
+class LazyConcat(object):
+    """Concatenation along the last axis that has not been materialised: a Dense consumer multiplies each
+    part with its slice of the kernel instead (and can reuse the product of a part shared by several
+    evaluations)."""
+    def __init__(self, parts):
+        self.parts = [ops.as_lazy(p) for p in parts]
+
+    @property
+    def shape(self):
+        return tuple(self.parts[0].shape[:-1]) + (sum(p.shape[-1] for p in self.parts),)
+
+    def tensor(self):
+        return torch.cat([p.tensor() for p in self.parts], dim=-1)
+
+
+def to_tensor(v):
+    if isinstance(v, (Lazy, LazyConcat)):
+        return v.tensor()
+    return v
+
+
+# --------------------------------------------------------------------------------------------
+# initialisers (numpy global RNG: the reference seeds it with 123 at import, percivaltts.py:30-33)
+# --------------------------------------------------------------------------------------------
+def glorot_uniform(shape):
+    rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+    fan_in, fan_out = shape[-2] * rf, shape[-1] * rf
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    return torch.from_numpy(np.random.uniform(-lim, lim, size=shape).astype(np.float32))
+
+
+def orthogonal(shape):
+    a = np.random.normal(0.0, 1.0, (shape[0], int(np.prod(shape[1:]))))
+    u, _, v = np.linalg.svd(a, full_matrices=False)
+    q = u if u.shape == a.shape else v
+    return torch.from_numpy(q.reshape(shape).astype(np.float32))
+
+
+# --------------------------------------------------------------------------------------------
+# graph plumbing
+# --------------------------------------------------------------------------------------------
+class Node(object):
+    """A symbolic tensor: `shape` is the tail after (batch, time), e.g. (D,) or (F, C)."""
+    def __init__(self, layer, parents, shape, name=None):
+        self.layer, self.parents, self.shape, self.name = layer, list(parents), tuple(shape), name
+
+
+class Layer(nn.Module):
+    """Base: `__call__` on Node(s) builds the graph, `compute` runs it."""
+    def __init__(self, name=None):
+        super(Layer, self).__init__()
+        self.lname = name
+        self.built = False
+
+    def build(self, in_shapes):
+        pass
+
+    def out_shape(self, in_shapes):
+        return in_shapes[0]
+
+    def connect(self, inputs):
+        single = isinstance(inputs, Node)
+        nodes = [inputs] if single else list(inputs)
+        shapes = [n.shape for n in nodes]
+        if not self.built:
+            self.build(shapes)
+            self.built = True
+        return Node(self, nodes, self.out_shape(shapes), self.lname)
+
+    def __call__(self, *args, **kwargs):
+        if len(args) == 1 and not kwargs and (isinstance(args[0], Node) or (
+                isinstance(args[0], (list, tuple)) and len(args[0]) > 0 and isinstance(args[0][0], Node))):
+            return self.connect(args[0])
+        return super(Layer, self).__call__(*args, **kwargs)
+
+    def compute(self, vals, training, memo):
+        raise NotImplementedError
+
+    def weights(self):
+        """(name, tensor) in Keras weight order: trainable first as created, BN moving statistics last."""
+        out = [(k, p) for k, p in self.named_parameters(recurse=False)]
+        out += [(k, b) for k, b in self.named_buffers(recurse=False)]
+        return out
+
+    def config(self):
+        return {}
+
+
+class InputLayer(Layer):
+    def __init__(self, shape, name=None):
+        super(InputLayer, self).__init__(name)
+        self.shape = tuple(shape)
+
+
+def Input(shape, name=None):
+    """keras.layers.Input(shape=(None, D)): the leading None is the time axis."""
+    tail = tuple(s for s in shape[1:])
+    lay = InputLayer(tail, name)
+    return Node(lay, [], tail, name)
+
+
+class Dense(Layer):
+    """keras.layers.Dense(units, use_bias, activation) on the last axis."""
+    def __init__(self, units, use_bias=True, activation=None, name=None):
+        super(Dense, self).__init__(name)
+        self.units, self.use_bias, self.activation = int(units), bool(use_bias), activation
+        assert activation in (None, 'linear', 'sigmoid', 'tanh') or callable(activation) or isinstance(activation, tuple)
+
+    def build(self, in_shapes):
+        k = in_shapes[0][-1]
+        self.kernel = nn.Parameter(glorot_uniform((k, self.units)))
+        if self.use_bias:
+            self.bias = nn.Parameter(torch.zeros(self.units))
+        else:
+            self.bias = None
+
+    def out_shape(self, in_shapes):
+        return tuple(in_shapes[0][:-1]) + (self.units,)
+
+    def compute(self, vals, training, memo):
+        v = vals[0]
+        if isinstance(v, LazyConcat):
+            z, off = None, 0
+            for i, part in enumerate(v.parts):
+                k = part.shape[-1]
+                wpart = self.kernel[off:off + k]
+                off += k
+                key = ('dense_part', id(self), i, id(part.z))
+                bias = self.bias if i == 0 else None
+                if memo is not None and i > 0 and key in memo:
+                    y = memo[key]
+                else:
+                    y = ops.dense(part, wpart, bias)
+                    if memo is not None and i > 0:
+                        memo[key] = y
+                z = y if z is None else z + y
+        else:
+            z = ops.dense(v, self.kernel, self.bias)
+        return _apply_activation(z, self.activation)
+
+
+def _apply_activation(z, activation):
+    if activation in (None, 'linear'):
+        return z
+    if activation in ('sigmoid', 'tanh'):
+        return ops.affine_act(z, None, None, activation)
+    if isinstance(activation, tuple) and activation[0] == 'tanh_saturated':
+        # nonlin_tanh_saturated (backend_tensorflow.py:78-81): coef * tanh(x)
+        return ops.affine_act(z, None, None, 'tanh') * activation[1]
+    return activation(z)
+
+
+class BatchNormalization(Layer):
+    """keras BatchNormalization(axis=-1): momentum .99, eps 1e-3.  Emits the per-channel affine as a Lazy."""
+    def __init__(self, name=None):
+        super(BatchNormalization, self).__init__(name)
+
+    def build(self, in_shapes):
+        C = in_shapes[0][-1]
+        self.gamma = nn.Parameter(torch.ones(C))
+        self.beta = nn.Parameter(torch.zeros(C))
+        self.register_buffer('moving_mean', torch.zeros(C))
+        self.register_buffer('moving_variance', torch.ones(C))
+        # TF fuses BatchNorm for 4-D inputs; the fused kernel feeds the Bessel-corrected variance to the
+        # moving average (3-D inputs take the unfused path with the biased variance).
+        self.fused4d = len(in_shapes[0]) == 2
+
+    def compute(self, vals, training, memo):
+        z = to_tensor(vals[0])
+        update = bool(training) and not (memo is not None and memo.get('freeze_bn_stats', False))
+        scale, shift = ops.batchnorm_affine(z, self.gamma, self.beta, self.moving_mean, self.moving_variance,
+                                            bool(training), update, self.fused4d)
+        return Lazy(z, scale, shift, lrelu=False)
+
+
+class LeakyReLU(Layer):
+    def __init__(self, alpha=0.3, name=None):
+        super(LeakyReLU, self).__init__(name)
+        self.alpha = float(alpha)
+
+    def compute(self, vals, training, memo):
+        v = vals[0]
+        if isinstance(v, Lazy) and not v.lrelu:
+            return Lazy(v.z, v.scale, v.shift, lrelu=True, alpha=self.alpha)
+        return Lazy(to_tensor(v), None, None, lrelu=True, alpha=self.alpha)
+
+    def config(self):
+        return {'alpha': self.alpha}
+
+
+class Conv1D(Layer):
+    """kl.Conv1D(filters, k, strides=1, padding='same', dilation_rate=1)."""
+    def __init__(self, filters, kernel_size, use_bias=True, name=None):
+        super(Conv1D, self).__init__(name)
+        self.filters, self.kernel_size, self.use_bias = int(filters), int(kernel_size), bool(use_bias)
+
+    def build(self, in_shapes):
+        cin = in_shapes[0][-1]
+        self.kernel = nn.Parameter(glorot_uniform((self.kernel_size, cin, self.filters)))
+        self.bias = nn.Parameter(torch.zeros(self.filters)) if self.use_bias else None
+
+    def out_shape(self, in_shapes):
+        return (self.filters,)
+
+    def compute(self, vals, training, memo):
+        v = vals[0]
+        a = to_tensor(v)
+        key = None
+        return ops.conv1d(a, self.kernel, self.bias)
+
+
+class Conv2D(Layer):
+    """kl.Conv2D(filters, [kt,kf], strides 1, padding 'same', channels_last); dilation/causality along time are
+    build extensions (BASELINE config 5) that reduce to the reference at dil_t=1, causal=False."""
+    def __init__(self, filters, kernel_size, use_bias=True, activation=None, dil_t=1, causal=False, name=None):
+        super(Conv2D, self).__init__(name)
+        self.filters, self.use_bias, self.activation = int(filters), bool(use_bias), activation
+        self.kt, self.kf = int(kernel_size[0]), int(kernel_size[1])
+        self.dil_t, self.causal = int(dil_t), bool(causal)
+
+    def build(self, in_shapes):
+        cin = in_shapes[0][-1]
+        self.kernel = nn.Parameter(glorot_uniform((self.kt, self.kf, cin, self.filters)))
+        self.bias = nn.Parameter(torch.zeros(self.filters)) if self.use_bias else None
+
+    def out_shape(self, in_shapes):
+        return (in_shapes[0][0], self.filters)
+
+    def compute(self, vals, training, memo):
+        v = vals[0]
+        if isinstance(v, LazyConcat):
+            v = v.tensor()
+        z = ops.conv2d(v, self.kernel, self.bias, self.dil_t, ops.PAD_CAUSAL if self.causal else ops.PAD_SAME)
+        return _apply_activation(z, self.activation)
+
+
+class LSTM(Layer):
+    """kl.LSTM(units, tanh, recurrent sigmoid, return_sequences=True), optionally kl.Bidirectional(concat).
+    Weights are held combined: kernel [In, ndir*4H] = [fwd | bwd], recurrent_kernel [ndir,H,4H], bias [ndir*4H]."""
+    def __init__(self, units, bidirectional=False, name=None):
+        super(LSTM, self).__init__(name)
+        self.units, self.ndir = int(units), 2 if bidirectional else 1
+
+    def build(self, in_shapes):
+        cin, H, nd = in_shapes[0][-1], self.units, self.ndir
+        self.kernel = nn.Parameter(torch.cat([glorot_uniform((cin, 4 * H)) for _ in range(nd)], dim=1))
+        self.recurrent_kernel = nn.Parameter(torch.stack([orthogonal((H, 4 * H)) for _ in range(nd)], dim=0))
+        b = torch.zeros(nd, 4 * H)
+        b[:, H:2 * H] = 1.0          # unit_forget_bias
+        self.bias = nn.Parameter(b.reshape(-1))
+
+    def out_shape(self, in_shapes):
+        return (self.units * self.ndir,)
+
+    def compute(self, vals, training, memo):
+        return ops.lstm(vals[0] if not isinstance(vals[0], LazyConcat) else vals[0].tensor(),
+                        self.kernel, self.recurrent_kernel, self.bias)
+
+
+class GRU(Layer):
+    """kl.GRU(reset_after=False) / Bidirectional: not on the WGAN hot path -> stock torch ops.
+    Parameter layout follows Keras (kernel [In,3H], recurrent [H,3H], bias [3H]; gates z,r,h)."""
+    def __init__(self, units, bidirectional=False, name=None):
+        super(GRU, self).__init__(name)
+        self.units, self.ndir = int(units), 2 if bidirectional else 1
+
+    def build(self, in_shapes):
+        cin, H, nd = in_shapes[0][-1], self.units, self.ndir
+        self.kernel = nn.Parameter(torch.stack([glorot_uniform((cin, 3 * H)) for _ in range(nd)], dim=0))
+        self.recurrent_kernel = nn.Parameter(torch.stack([orthogonal((H, 3 * H)) for _ in range(nd)], dim=0))
+        self.bias = nn.Parameter(torch.zeros(nd, 3 * H))
+
+    def out_shape(self, in_shapes):
+        return (self.units * self.ndir,)
+
+    def compute(self, vals, training, memo):
+        x = to_tensor(vals[0])
+        H = self.units
+        outs = []
+        for d in range(self.ndir):
+            W, U, b = self.kernel[d], self.recurrent_kernel[d], self.bias[d]
+            xp = x @ W + b
+            h = x.new_zeros((x.shape[0], H))
+            seq = [None] * x.shape[1]
+            order = range(x.shape[1] - 1, -1, -1) if d == 1 else range(x.shape[1])
+            for t in order:
+                zr = torch.sigmoid(xp[:, t, :2 * H] + h @ U[:, :2 * H])
+                z, r = zr[:, :H], zr[:, H:]
+                hh = torch.tanh(xp[:, t, 2 * H:] + (r * h) @ U[:, 2 * H:])
+                h = z * h + (1 - z) * hh
+                seq[t] = h
+            outs.append(torch.stack(seq, dim=1))
+        return outs[0] if self.ndir == 1 else torch.cat(outs, dim=-1)
+
+
+class Reshape(Layer):
+    """kl.Reshape([-1] + tail): keeps (batch, time) and re-tiles the tail."""
+    def __init__(self, tail, name=None):
+        super(Reshape, self).__init__(name)
+        self.tail = tuple(int(t) for t in tail)
+
+    def out_shape(self, in_shapes):
+        assert int(np.prod(in_shapes[0])) == int(np.prod(self.tail)), 'Reshape {} -> {}'.format(in_shapes[0], self.tail)
+        return self.tail
+
+    def compute(self, vals, training, memo):
+        v = vals[0]
+        if isinstance(v, LazyConcat):
+            v = v.tensor()
+        if isinstance(v, Lazy):
+            z = v.z
+            new = z.reshape(z.shape[0], z.shape[1], *self.tail)
+            scale, shift = v.scale, v.shift
+            if scale is not None and self.tail[-1] != z.shape[-1]:
+                rep = self.tail[-1] // z.shape[-1]
+                assert rep * z.shape[-1] == self.tail[-1], 'cannot carry a per-channel affine through this Reshape'
+                scale, shift = scale.repeat(rep), shift.repeat(rep)
+            return Lazy(new, scale, shift, v.lrelu, v.alpha)
+        return v.reshape(v.shape[0], v.shape[1], *self.tail)
+
+
+class SliceLast(Layer):
+    """kl.Lambda(lambda x: x[:, :, a:b])"""
+    def __init__(self, start, stop, name=None):
+        super(SliceLast, self).__init__(name)
+        self.start, self.stop = int(start), int(stop)
+
+    def out_shape(self, in_shapes):
+        return (self.stop - self.start,)
+
+    def compute(self, vals, training, memo):
+        return to_tensor(vals[0])[..., self.start:self.stop].contiguous()
+
+
+class Concatenate(Layer):
+    def out_shape(self, in_shapes):
+        return tuple(in_shapes[0][:-1]) + (sum(s[-1] for s in in_shapes),)
+
+    def compute(self, vals, training, memo):
+        return LazyConcat(vals)
+
+
+class Multiply(Layer):
+    def compute(self, vals, training, memo):
+        return to_tensor(vals[0]) * to_tensor(vals[1])
+
+
+class Activation(Layer):
+    def __init__(self, activation, name=None):
+        super(Activation, self).__init__(name)
+        self.activation = activation
+
+    def compute(self, vals, training, memo):
+        return _apply_activation(to_tensor(vals[0]), self.activation)
+
+
+class Dropout(Layer):
+    """kl.Dropout(rate, noise_shape=(batch,1,None)) (networktts.py:65-70): one mask per sample and feature."""
+    def __init__(self, rate, name=None):
+        super(Dropout, self).__init__(name)
+        self.rate = float(rate)
+
+    def compute(self, vals, training, memo):
+        x = to_tensor(vals[0])
+        if not training or self.rate <= 0:
+            return x
+        keep = 1.0 - self.rate
+        mask = (torch.rand(x.shape[0], 1, x.shape[2], device=x.device) < keep).to(x.dtype) / keep
+        return x * mask
+
+
+class GaussianNoiseInput(Layer):
+    """networktts.py:36-56: concatenates `width` channels of N(0, stddev) noise."""
+    def __init__(self, stddev=1.0, width=100, name=None):
+        super(GaussianNoiseInput, self).__init__(name)
+        self.stddev, self.width = float(stddev), int(width)
+
+    def out_shape(self, in_shapes):
+        return (in_shapes[0][-1] + self.width,)
+
+    def compute(self, vals, training, memo):
+        x = to_tensor(vals[0])
+        noise = torch.randn(x.shape[0], x.shape[1], self.width, device=x.device) * self.stddev
+        return torch.cat([x, noise], dim=-1)
+
+
+# --------------------------------------------------------------------------------------------
+# Model
+# --------------------------------------------------------------------------------------------
+class Model(nn.Module):
+    """keras.Model(inputs, outputs): evaluates the node graph; also the parameter container."""
+    def __init__(self, inputs, outputs):
+        super(Model, self).__init__()
+        self.inputs = [inputs] if isinstance(inputs, Node) else list(inputs)
+        self.single_output = isinstance(outputs, Node)
+        self.outputs = [outputs] if self.single_output else list(outputs)
+        order, seen = [], set()
+
+        def visit(n):
+            if id(n) in seen:
+                return
+            seen.add(id(n))
+            for p in n.parents:
+                visit(p)
+            order.append(n)
+        for o in self.outputs:
+            visit(o)
+        self.order = order
+        # unique layers in graph order (an already-registered layer is shared, e.g. a frozen sub-network)
+        lays, seen_l = [], set()
+        for n in order:
+            if id(n.layer) not in seen_l and not isinstance(n.layer, InputLayer):
+                seen_l.add(id(n.layer))
+                lays.append(n.layer)
+        self.layers_list = nn.ModuleList(lays)
+        # which inputs each node depends on
+        self.deps = {}
+        for n in order:
+            if not n.parents:
+                self.deps[id(n)] = {id(n)}
+            else:
+                s = set()
+                for p in n.parents:
+                    s |= self.deps[id(p)]
+                self.deps[id(n)] = s
+        for i in self.inputs:
+            assert id(i) in self.deps or True
+
+    def _run(self, feed, training, memo, values=None, only_dep=None):
+        values = {} if values is None else values
+        for n in self.order:
+            if id(n) in values:
+                continue
+            if not n.parents:
+                values[id(n)] = feed[id(n)]
+                continue
+            if only_dep is not None and only_dep not in self.deps[id(n)] and False:
+                continue
+            vals = [values[id(p)] for p in n.parents]
+            values[id(n)] = n.layer.compute(vals, training, memo)
+        return values
+
+    def forward(self, *xs, **kw):
+        training = kw.get('training', False)
+        memo = kw.get('memo', None)
+        if len(xs) == 1 and isinstance(xs[0], (list, tuple)):
+            xs = tuple(xs[0])
+        assert len(xs) == len(self.inputs), 'model expects {} inputs'.format(len(self.inputs))
+        feed = {id(n): x for n, x in zip(self.inputs, xs)}
+        values = self._run(feed, training, memo)
+        outs = [to_tensor(values[id(o)]) for o in self.outputs]
+        return outs[0] if self.single_output else outs
+
+    def forward_multi(self, varying_index, variants, fixed, training=False, memo=None):
+        """Evaluate the model for several values of input `varying_index` while every node that does not
+        depend on it (the critic's context branch) is computed once and shared."""
+        memo = {} if memo is None else memo
+        vin = self.inputs[varying_index]
+        feed = {}
+        fi = 0
+        for i, n in enumerate(self.inputs):
+            if i != varying_index:
+                feed[id(n)] = fixed[fi]
+                fi += 1
+        shared = {}
+        for n in self.order:
+            if id(vin) in self.deps[id(n)]:
+                continue
+            if not n.parents:
+                shared[id(n)] = feed[id(n)]
+            else:
+                shared[id(n)] = n.layer.compute([shared[id(p)] for p in n.parents], training, memo)
+        results = []
+        for x in variants:
+            values = dict(shared)
+            values[id(vin)] = x
+            values = self._run({}, training, memo, values)
+            outs = [to_tensor(values[id(o)]) for o in self.outputs]
+            results.append(outs[0] if self.single_output else outs)
+        return results
+
+    # ---- Keras-like accessors ----------------------------------------------------------------
+    def weights(self):
+        out = []
+        for li, lay in enumerate(self.layers_list):
+            for k, t in lay.weights():
+                out.append(('{}_{}/{}'.format(type(lay).__name__.lower(), li, k), t))
+        return out
+
+    def count_params(self):
+        """keras Model.count_params(): trainable + non-trainable (BN moving statistics)."""
+        return int(sum(t.numel() for _, t in self.weights()))
+
+    def trainable_weights(self):
+        return [p for p in self.parameters()]
+
+    def summary(self, printfn=print):
+        printfn('    {:<28}{:<18}{}'.format('layer', 'output tail', '#params'))
+        seen = set()
+        for n in self.order:
+            if isinstance(n.layer, InputLayer) or id(n.layer) in seen:
+                continue
+            seen.add(id(n.layer))
+            printfn('    {:<28}{:<18}{}'.format(type(n.layer).__name__, str(n.shape), sum(t.numel() for _, t in n.layer.weights())))
+        printfn('    total params: {}'.format(self.count_params()))
+
+    def to_json(self):
+        import json
+        desc = []
+        for n in self.order:
+            desc.append({'class': type(n.layer).__name__, 'shape': list(n.shape), 'name': n.name,
+                         'parents': [self.order.index(p) for p in n.parents], 'config': n.layer.config()})
+        return json.dumps({'format': 'percivaltts_amd.graph.v1', 'nodes': desc}, indent=1)
+
+    def get_weights(self):
+        return [t.detach().cpu().numpy().copy() for _, t in self.weights()]
+
+    def set_weights(self, arrays):
+        ws = self.weights()
+        assert len(ws) == len(arrays), 'set_weights: {} arrays for {} weights'.format(len(arrays), len(ws))
+        with torch.no_grad():
+            for (k, t), a in zip(ws, arrays):
+                a = torch.as_tensor(np.asarray(a), dtype=t.dtype)
+                assert tuple(a.shape) == tuple(t.shape), 'set_weights: {} {} vs {}'.format(k, tuple(a.shape), tuple(t.shape))
+                t.copy_(a.to(t.device))
+
+
+class FlatParams(object):
+    """All trainable weights of a model as views into ONE flat fp32 buffer, gradients likewise: one Adam launch and
+    one all-reduce bucket per network."""
+    def __init__(self, model, device):
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(n, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=device)
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                k = p.numel()
+                self.flat[off:off + k].copy_(p.detach().reshape(-1).to(device))
+                p.data = self.flat[off:off + k].view(p.shape)
+                p.grad = self.grad[off:off + k].view(p.shape)
+                off += k
+        self.numel = n
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, in zip(self.params):
+            pass
