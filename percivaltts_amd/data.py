@@ -1,0 +1,242 @@
+"""Host-side batch loading and cost helpers (numpy only) -- the callers' side of the hot path.
+
+Same function names, arguments and results as the reference's percivaltts/data.py:34-406 for what the
+training driver uses: `path:(shape)` selectors (:34-76), load (:96-133), croplen (:143-171),
+croplen_weight (:173-231), batching with random-shift windows (:234-284), load_inoutset (:297-322) and
+the cost helpers (:327-406).  Files are headerless float32.
+"""
+from __future__ import print_function
+
+import copy
+import os
+import re
+import time
+
+import numpy as np
+
+from .percivaltts import is_int, print_tty
+
+_SEL = re.compile(r'(.*):\((.*)\)')
+
+
+def getpath(path):
+    m = _SEL.findall(path)
+    return m[0][0] if m else path
+
+
+def getpathandshape(path, shape=None):
+    """'/dir/*.spec:(-1,60)' -> ('/dir/*.spec', (-1, 60)); a non-integer selector names a file whose length is used."""
+    m = _SEL.findall(path)
+    if not m:
+        return path, shape
+    path = m[0][0]
+    sel = ()
+    for s in m[0][1].split(','):
+        if is_int(s):
+            sel += (int(s),)
+        else:
+            sel += (np.fromfile(os.path.join(os.path.dirname(path), s), dtype=np.float32).shape[0],)
+    if shape is not None:
+        print('WARNING: shape has been set both as argument ({}) of the getpathandshape(.) function and in the file '
+              'selector ({}) (at the end of path); The one set as argument will be used: {}'.format(shape, sel, shape))
+        return path, shape
+    return path, sel
+
+
+def getlastdim(path):
+    _, size = getpathandshape(path)
+    return 1 if size is None else size[-1]
+
+
+def _read(fpath, shape):
+    if not os.path.isfile(fpath):
+        raise ValueError('{} does not exists'.format(fpath))
+    X = np.fromfile(fpath, dtype='float32')
+    if shape is not None:
+        X = X.reshape(shape)
+    if np.isnan(X).any(): raise ValueError('ERROR: There are nan in {}'.format(fpath))
+    if np.isinf(X).any(): raise ValueError('ERROR: There are inf in {}'.format(fpath))
+    return X
+
+
+def loadfile(fpath, fbase=None, shape=None):
+    if fbase is not None:
+        fpath = fpath.replace('*', fbase)
+    fpath, shape = getpathandshape(fpath, shape)
+    return _read(fpath, shape)
+
+
+def load(dirpath, fbases, shape=None, frameshift=0.005, verbose=0, label=''):
+    """List of matrices, one per file id."""
+    dirpath, shape = getpathandshape(dirpath, shape)
+    Xs, totlen, memsize = [], 0, 0.0
+    for n, fbase in enumerate(fbases):
+        if verbose > 0:
+            print_tty('\r    {}Loading file {}/{} {}: ({:.2f}% done)        '.format(label, 1 + n, len(fbases), fbase, 100.0 * n / len(fbases)))
+        X = _read(dirpath.replace('*', fbase), shape)
+        Xs.append(X)
+        totlen += X.shape[0]
+        memsize += X.size * 4 / float(1024 ** 2)
+    if verbose > 0:
+        print_tty('\r                                                                 \r')
+        print('    {}{} sentences, frames={} ({}), {} MB                     '.format(
+            label, len(fbases), totlen, time.strftime('%H:%M:%S', time.gmtime(totlen * frameshift)), memsize))
+    return Xs
+
+
+def gettotallen(Xs, axis=0):
+    return sum(x.shape[axis] for x in Xs)
+
+
+def croplen(xs, axis=0):
+    """Crop, sample by sample, every list of `xs` to the shortest length found among the lists (in place)."""
+    if axis > 2:
+        raise ValueError('Do not manage axis values bigger than 2')
+    if len(set(len(x) for x in xs)) > 1:
+        raise ValueError('the size of the data sets are not identical ({})'.format([len(x) for x in xs]))
+    for ki in range(len(xs[0])):
+        siz = min(x[ki].shape[axis] for x in xs)
+        idx = [slice(None)] * axis + [slice(0, siz)]
+        for x in xs:
+            x[ki] = x[ki][tuple(idx)]
+    return xs
+
+
+def croplen_weight(xs, w, thresh=0.5, cropmode='begend', cropsize=int(0.750 / 0.005)):
+    """Drop frames whose weight is below `thresh`: at both ends ('begend'), also inside when the silent gap is longer
+    than `cropsize` frames ('begendbigger'), or everywhere ('all')."""
+    if len(set([len(w)] + [len(x) for x in xs])) > 1:
+        raise ValueError('the size of the data sets are not identical ({})'.format([len(x) for x in xs]))
+    for ki in range(len(w)):
+        wk = w[ki][:, 0] if w[ki].ndim > 1 else w[ki]
+        keep = wk > thresh
+        if cropmode == 'begend':
+            on = np.where(keep)[0]
+            sel = slice(int(on.min()), int(on.max()))
+        elif cropmode == 'begendbigger':
+            on = np.where(keep)[0]
+            gaps = np.diff(on)
+            for gi in np.where(gaps > 1)[0]:
+                if gaps[gi] < int(cropsize):
+                    keep[on[gi]:on[gi + 1]] = True
+            sel = np.where(keep)[0]
+        elif cropmode == 'all':
+            sel = np.where(keep)[0]
+        else:
+            raise ValueError('unknown cropmode ' + str(cropmode))
+        for x in xs:
+            x[ki] = x[ki][sel,]
+        w[ki] = w[ki][sel,]
+    return xs, w
+
+
+def batching(xs, length=None, lengthmax=None, padtype='randshift', outmask=False):
+    """Stack 2-D matrices into [B, length, feat] batches.  'randshift' takes a random window of `length` frames from
+    every sample (np.random.randint, so the numpy seed makes it repeatable); 'padright' zero-pads on the right."""
+    if len(set(len(x) for x in xs)) > 1:
+        raise ValueError('the size of the data sets are not identical ({})'.format([len(x) for x in xs]))
+    nb = len(xs[0])
+    if length is None:
+        lens = [xs[0][b].shape[0] for b in range(nb)]
+        length = max(lens) if padtype == 'padright' else min(lens)
+    if lengthmax is not None and length > lengthmax:
+        length = lengthmax
+    xbs = []
+    for x in xs:
+        feat = 1 if x[0].ndim == 1 else x[0].shape[1]
+        xbs.append(np.zeros((len(x), length, feat), dtype='float32'))
+    MB = np.zeros((nb, length), dtype='float32') if outmask else None
+    shift = 0
+    for b in range(nb):
+        samplelen = xs[0][b].shape[0]
+        minlen = min(samplelen, length)
+        if padtype == 'randshift':
+            shift = np.random.randint(0, (samplelen - length) + 1)
+        for xi, x in enumerate(xs):
+            seg = x[b][shift:shift + minlen]
+            xbs[xi][b, :minlen, :] = seg.reshape(minlen, -1)
+        if outmask: MB[b, :minlen] = 1
+    return xbs, MB
+
+
+def addstop(X, value=1.0):
+    X = copy.deepcopy(X)
+    stop = np.zeros(X[0].shape[1] + 1)
+    stop[-1] = value
+    for xi in range(len(X)):
+        X[xi] = np.vstack((np.concatenate((X[xi], np.zeros((X[xi].shape[0], 1))), axis=1), stop))
+    return X
+
+
+def load_inoutset(indir, outdir, outwdir, fid_lst, inouttimesync=True, length=None, lengthmax=None,
+                  maskpadtype='padright', cropmode='begend', verbose=0):
+    """Load one batch of inputs, outputs and time weights, cropped and windowed: X [B,T,ctx], Y [B,T,out], W [B,T,1]."""
+    X = load(indir, fid_lst, verbose=verbose, label='Context labels: ')
+    Y = load(outdir, fid_lst, verbose=verbose, label='Output features: ')
+    W = load(outwdir, fid_lst, verbose=verbose, label='Time weights: ')
+    if inouttimesync:
+        X, Y, W = croplen([X, Y, W])
+        [X, Y], W = croplen_weight([X, Y], W, cropmode=cropmode)
+        [X, Y, W], _ = batching([X, Y, W], length=length, lengthmax=lengthmax, padtype=maskpadtype)
+    else:
+        X = addstop(X)
+        Y, W = croplen([Y, W])
+        [Y], W = croplen_weight([Y], W, cropmode=cropmode)
+        Y = addstop(Y)
+        [X], _ = batching([X], length=length, lengthmax=lengthmax, padtype=maskpadtype)
+        [Y], _ = batching([Y], length=length, lengthmax=lengthmax, padtype=maskpadtype)
+    return X, Y, W
+
+
+# ---- evaluation helpers ----------------------------------------------------------------------------------
+def cost_0pred_rmse(Y_val):
+    """RMSE of the all-zero prediction (the worst predictor)."""
+    if isinstance(Y_val, list):
+        return float(np.sqrt(sum(np.sum(y ** 2) for y in Y_val) / float(sum(y.size for y in Y_val))))
+    return float(np.sqrt(np.mean(Y_val ** 2)))
+
+
+def _one_by_one(Xs):
+    for xi in range(len(Xs[0])):
+        yield xi, [np.reshape(inp[xi], [1] + list(inp[xi].shape)) for inp in Xs]
+
+
+def cost_model_mfn(fn, Xs):
+    """Average of fn over the samples, one utterance at a time."""
+    if not isinstance(Xs[0], list):
+        return 0.0
+    cost = 0.0
+    for _, ins in _one_by_one(Xs):
+        cost += fn(*ins)
+    return cost / len(Xs[0])
+
+
+def cost_model_prediction_rmse(mod, Xs, Y_val, inouttimesync=True):
+    if not isinstance(Xs[0], list):
+        return 0.0
+    cost, nbel = 0.0, 0
+    for xi, ins in _one_by_one(Xs):
+        ypred = mod.predict(*ins)
+        cost += np.sum((Y_val[xi] - ypred[0,]) ** 2)
+        nbel += ypred[0,].size
+    return float(np.sqrt(cost / nbel))
+
+
+def prediction_mstd(mod, Xs):
+    if not isinstance(Xs[0], list):
+        return 0.0
+    s = 0.0
+    for _, ins in _one_by_one(Xs):
+        s += np.std(mod.predict(*ins)[0,])
+    return s / len(Xs[0])
+
+
+def prediction_rms(mod, Xs):
+    if not isinstance(Xs[0], list):
+        return 0.0
+    s, nbel = 0.0, 0
+    for _, ins in _one_by_one(Xs):
+        ypred = mod.predict(*ins)
+        s += np.sum(ypred[0,] ** 2)
+        nbel += ypred[0,].size
+    return float(np.sqrt(s / nbel))

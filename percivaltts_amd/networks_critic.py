@@ -1,0 +1,56 @@
+"""The WGAN critic D(features, context) -> per-frame score; reference: percivaltts/networks_critic.py:34-96.
+
+Spectral slice -> L x (Conv2D 5x5, C filters, bias, LeakyReLU .3) -> flatten; context -> Conv1D(k) -> 2 FC;
+concat -> 3 FC -> Dense(1).  bn=False everywhere, so every layer carries a bias.  f0 and the noise mask are
+not seen by the critic (networks_critic.py:57-59).  The three graph handles `input_features`, `input_ctx`,
+`output` keep their names because OptimizerTTSWGAN.prepare reads them (optimizertts_wgan.py:115,126,165);
+`model` is the executable module.
+"""
+from __future__ import print_function
+
+from . import layers as kl
+from .networktts import pFC, pCNN1D
+
+
+class Critic:
+
+    input_features = None
+    input_ctx = None
+    output = None
+
+    vocoder = None
+    ctxsize = -1
+    cfgarch = None
+
+    def __init__(self, vocoder, ctxsize, cfgarch):
+        self.vocoder, self.ctxsize, self.cfgarch = vocoder, ctxsize, cfgarch
+        bn = False
+
+        self.input_features = kl.Input(shape=(None, vocoder.featuressize()), name='input_features')
+
+        l_spec = kl.SliceLast(1, 1 + vocoder.specsize())(self.input_features)
+
+        if cfgarch.arch_gen_nbcnnlayers > 0:
+            l_spec = kl.Reshape([vocoder.specsize(), 1])(l_spec)
+            for _ in range(cfgarch.arch_gen_nbcnnlayers):
+                l_spec = kl.Conv2D(cfgarch.arch_gen_nbfilters, [cfgarch.arch_gen_winlen, cfgarch.arch_spec_freqlen])(l_spec)
+                l_spec = kl.LeakyReLU(alpha=0.3)(l_spec)
+            l_spec = kl.Reshape([l_spec.shape[-2] * l_spec.shape[-1]])(l_spec)
+        else:
+            for _ in range(3):
+                l_spec = pFC(l_spec, cfgarch.arch_hiddenwidth, bn=bn)
+
+        self.input_ctx = kl.Input(shape=(None, self.ctxsize), name='input_ctx')
+        l_ctx = self.input_ctx
+        for _ in range(cfgarch.arch_ctx_nbcnnlayers):
+            l_ctx = pCNN1D(l_ctx, cfgarch.arch_hiddenwidth, cfgarch.arch_ctx_winlen, bn=bn)
+        l_ctx = pFC(l_ctx, cfgarch.arch_hiddenwidth, bn=bn)
+        l_ctx = pFC(l_ctx, cfgarch.arch_hiddenwidth, bn=bn)
+
+        l_post = kl.Concatenate(name='lo_concatenation')([l_spec, l_ctx])
+        for _ in range(3):
+            l_post = pFC(l_post, cfgarch.arch_hiddenwidth, bn=bn)
+
+        self.output = kl.Dense(1, activation=None)(l_post)
+
+        self.model = kl.Model(inputs=[self.input_features, self.input_ctx], outputs=self.output)

@@ -1,0 +1,210 @@
+"""GPU parity of the networks and of the WGAN-GP critic / generator steps against the CPU oracle on identical
+weights, inputs and injected alpha (the reference draws alpha and the initial weights from TF's RNG, so both are
+injected: SURVEY.md section 7, 'RNG parity').  Bar: rtol 1e-3 (north star), checked here at 5e-4 or tighter."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import percival_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def close(got, want, rtol, atol, what=''):
+    got = torch.as_tensor(np.asarray(got.detach().cpu() if torch.is_tensor(got) else got), dtype=torch.float64)
+    want = torch.as_tensor(np.asarray(want.detach().cpu() if torch.is_tensor(want) else want), dtype=torch.float64)
+    assert got.shape == want.shape, '{}: {} vs {}'.format(what, tuple(got.shape), tuple(want.shape))
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    if (err > tol).any():
+        i = int(torch.argmax(err - tol))
+        raise AssertionError('{}: {}/{} off, worst err {:.3e} (got {:.6e} want {:.6e}) max|want| {:.3e}'.format(
+            what, int((err > tol).sum()), err.numel(), float(err.flatten()[i]), float(got.flatten()[i]),
+            float(want.flatten()[i]), float(want.abs().max())))
+
+
+GEOMS = {
+    # the geometry of the reference's DCNN/WGAN smoke test (tests/test_smoke_tensorflowkeras.py:184-203)
+    'test': dict(ctx=425, spec=65, nm=17, H=2, nctx=2, kctx=3, L=2, C=2, kt=3, kf=3, B=2, T=16),
+    # the default architecture (run.py:114-120) at reduced width/length
+    'default': dict(ctx=61, spec=65, nm=20, H=32, nctx=1, kctx=21, L=8, C=4, kt=5, kf=5, B=3, T=50),
+    # no conv layers: the critic's FC spectral branch (networks_critic.py:72-76)
+    'nocnn': dict(ctx=20, spec=9, nm=3, H=8, nctx=1, kctx=5, L=0, C=2, kt=3, kf=3, B=2, T=12),
+}
+
+
+def build(geom):
+    import percivaltts_amd
+    from percivaltts_amd import vocoders, modeltts_common, networks_critic, optimizertts_wgan
+    g = GEOMS[geom]
+    cfg = percivaltts_amd.configuration()
+    cfg.arch_hiddenwidth = g['H']; cfg.arch_ctx_nbcnnlayers = g['nctx']; cfg.arch_ctx_winlen = g['kctx']
+    cfg.arch_gen_nbcnnlayers = g['L']; cfg.arch_gen_nbfilters = g['C']; cfg.arch_gen_winlen = g['kt']
+    cfg.arch_spec_freqlen = g['kf']; cfg.train_batch_size = g['B']
+    voc = vocoders.VocoderPML(16000, 0.005, g['spec'], g['nm'])
+    mod = modeltts_common.DCNNF0SpecNoiseFeatures(g['ctx'], voc, cfg)
+    crit = networks_critic.Critic(voc, g['ctx'], cfg)
+    a = O.Arch(g['ctx'], g['spec'], g['nm'], g['H'], g['nctx'], g['kctx'], g['L'], g['C'], g['kt'], g['kf'])
+    gw = O.random_weights(O.generator_weight_shapes(a), seed=11)
+    cw = O.random_weights(O.critic_weight_shapes(a), seed=12)
+    assert mod.count_params() == O.count_params(O.generator_weight_shapes(a))
+    assert crit.model.count_params() == O.count_params(O.critic_weight_shapes(a))
+    mod.kerasmodel.set_weights([w.numpy() for w in gw])
+    crit.model.set_weights([w.numpy() for w in cw])
+    gen = torch.Generator().manual_seed(5)
+    X = torch.rand(g['B'], g['T'], g['ctx'], generator=gen, dtype=torch.float64) * 2 - 1
+    Y = torch.randn(g['B'], g['T'], a.outsize, generator=gen, dtype=torch.float64)
+    Y[:, :, 1 + g['spec']:] = torch.rand(g['B'], g['T'], g['nm'], generator=gen, dtype=torch.float64)
+    al = torch.rand(g['B'], generator=gen, dtype=torch.float64)
+    return cfg, voc, mod, crit, a, gw, cw, X, Y, al
+
+
+def f32(t):
+    return t.to(torch.float32).cuda().contiguous()
+
+
+@pytest.mark.parametrize('geom', ['test', 'default', 'nocnn'])
+def test_predict_and_critic_forward(geom):
+    cfg, voc, mod, crit, a, gw, cw, X, Y, al = build(geom)
+    want = O.generator_forward(gw, a, X, training=False)
+    got = mod.predict(X.numpy().astype(np.float32))
+    close(got, want, 5e-4, 5e-5, 'predict (BN inference)')
+    dev = mod.to_device()
+    crit.model.to(dev)
+    with torch.no_grad():
+        v = crit.model(f32(Y), f32(X), training=False)
+        gt = mod.kerasmodel(f32(X), training=True, memo={'freeze_bn_stats': True})
+    close(v, O.critic_forward(cw, a, Y, X), 5e-4, 5e-5, 'critic forward')
+    close(gt, O.generator_forward(gw, a, X, training=True), 5e-4, 5e-5, 'generator forward (BN batch statistics)')
+    # a frozen forward must not touch the moving statistics
+    for (k, t), w in zip(mod.kerasmodel.weights(), gw):
+        close(t, w, 1e-6, 1e-7, 'weights untouched ' + k)
+
+
+@pytest.mark.parametrize('errtype', ['WLSWGAN', 'WGAN'])
+@pytest.mark.parametrize('geom', ['test', 'default', 'nocnn'])
+def test_critic_and_generator_steps(geom, errtype):
+    from percivaltts_amd import optimizertts_wgan
+    cfg, voc, mod, crit, a, gw, cw, X, Y, al = build(geom)
+    cfg.train_wgan_critic_LSWGANtransidx = 30.0 if geom != 'nocnn' else 4.0
+    opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype=errtype, critic=crit)
+    opt.prepare()
+    Xd, Yd, ald = f32(X), f32(Y), f32(al)
+
+    # ---- critic: loss parts, every weight gradient, Keras-Adam update --------------------------------------
+    for w in cw: w.requires_grad_(True)
+    total, parts = O.critic_step_loss(cw, gw, a, X, Y, al, gp_lambda=10.0)
+    grads = torch.autograd.grad(total, cw)
+    opt.critic_opti.zero_grad()
+    tot_d, (lv, lf, gp) = opt.critic_loss(Xd, Yd, ald, training=True)
+    close(lv, parts['valid'], 5e-4, 1e-5, 'L valid')
+    close(lf, parts['fake'], 5e-4, 1e-5, 'L fake')
+    close(gp, parts['gp'], 5e-4, 1e-5, 'gradient penalty')
+    close(tot_d, total, 5e-4, 1e-5, 'critic loss')
+    tot_d.backward()
+    gmax = max(float(g.abs().max()) for g in grads)
+    for p, g_ in zip(opt.critic_opti.flat.params, grads):
+        close(p.grad, g_, 1e-3, 2e-5 * max(gmax, 1.0) + 1e-6, 'critic grad {}'.format(tuple(g_.shape)))
+    ms = [torch.zeros_like(w) for w in cw]; vs = [torch.zeros_like(w) for w in cw]
+    with torch.no_grad():
+        cw2 = [w.detach().clone() for w in cw]
+    O.adam_keras(cw2, grads, ms, vs, 1, 1e-4, 0.5, 0.9, 1e-7)
+    opt.critic_opti.step()
+    # Adam's first step moves every weight by ~lr*sign(g): compare the moves where the gradient is not tiny
+    for p, w_new, w_old, g_ in zip(opt.critic_opti.flat.params, cw2, cw, grads):
+        big = g_.abs() > 1e-3 * gmax
+        close((p.detach().cpu().double() - w_old.detach())[big], (w_new - w_old.detach())[big], 2e-2, 1e-7, 'critic Adam move')
+
+    # ---- generator: loss, gradients, update, BN moving statistics ----------------------------------------------
+    cw_now = [p.detach().cpu().double() for _, p in crit.model.weights()]
+    gw_t = [w.detach().clone() for w in gw]
+    shapes = O.generator_weight_shapes(a)
+    # trainable = everything except BN moving statistics (3rd/4th of each run of four equal 1-D shapes)
+    trainable, i = [], 0
+    while i < len(shapes):
+        if len(shapes[i]) == 1 and i + 3 < len(shapes) and all(shapes[i + k] == shapes[i] for k in range(4)):
+            trainable += [i, i + 1]; i += 4
+        else:
+            trainable.append(i); i += 1
+    for i in trainable: gw_t[i].requires_grad_(True)
+    w_ls, ww = O.wls_weights(a.specsize, a.noisesize, 0, 0.25, cfg.train_wgan_critic_LSWGANtransidx)
+    ltot, lparts = O.generator_step_loss(cw_now, gw_t, a, X, Y, errtype, torch.tensor(w_ls), ww, update_moving=True)
+    ggrads = torch.autograd.grad(ltot, [gw_t[i] for i in trainable], allow_unused=True)
+    opt.gen_opti.zero_grad()
+    for p in opt.critic_opti.flat.params: p.requires_grad_(False)
+    ltot_d, (lw_d, lls_d) = opt.generator_loss(Xd, Yd, training=True)
+    close(lw_d, lparts['wgan'], 5e-4, 1e-5, 'generator wgan term')
+    if errtype == 'WLSWGAN':
+        close(lls_d, lparts['ls'], 5e-4, 1e-5, 'generator ls term')
+    close(ltot_d, ltot, 5e-4, 1e-5, 'generator loss')
+    ltot_d.backward()
+    for p in opt.critic_opti.flat.params: p.requires_grad_(True)
+    ggmax = max(float(g.abs().max()) for g in ggrads if g is not None)
+    for p, g_ in zip(opt.gen_opti.flat.params, ggrads):
+        want = g_ if g_ is not None else torch.zeros_like(p, dtype=torch.float64, device='cpu')
+        close(p.grad, want, 2e-3, 5e-5 * max(ggmax, 1.0) + 1e-6, 'generator grad {}'.format(tuple(p.shape)))
+    # moving statistics after one training forward
+    for (k, t), w in zip(mod.kerasmodel.weights(), gw_t):
+        if 'moving' in k:
+            close(t, w, 5e-4, 1e-5, k)
+
+
+def test_generic_model_count_params_and_lse_step():
+    """Generic 3xFC, the reference's known answer 2195 (tests/test_smoke_tensorflowkeras.py:53), then one LSE step."""
+    import percivaltts_amd
+    from percivaltts_amd import vocoders, modeltts_common, optimizertts
+    cfg = percivaltts_amd.configuration()
+    cfg.arch_hiddenwidth = 4
+    cfg.train_batch_size = 2
+    voc = vocoders.VocoderPML(16000, 0.005, 65, 17)
+    model = modeltts_common.Generic(425, voc, layertypes=['FC', 'FC', 'FC'], cfgarch=cfg)
+    assert model.count_params() == 2195
+    opt = optimizertts.OptimizerTTS(cfg, model)
+    opt.prepare()
+    rng = np.random.RandomState(0)
+    X = rng.rand(2, 30, 425).astype(np.float32) * 2 - 1
+    Y = rng.randn(2, 30, 83).astype(np.float32)
+    c0 = opt.train_on_batch(0, X, Y)
+    for i in range(30):
+        c = opt.train_on_batch(i + 1, X, Y)
+    assert np.isfinite(c0) and np.isfinite(c) and c < c0
+    out = model.predict(X[:1])
+    assert out.shape == (1, 30, 83) and np.isfinite(out).all()
+
+
+def test_schedule_and_train_on_batch_api():
+    from percivaltts_amd import optimizertts_wgan
+    cfg, voc, mod, crit, a, gw, cw, X, Y, al = build('test')
+    opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype='WLSWGAN', critic=crit)
+    opt.prepare()
+    Xn, Yn = X.numpy().astype(np.float32), Y.numpy().astype(np.float32)
+    rets = [opt.train_on_batch(b, Xn, Yn) for b in range(12)]
+    # critic_runs = 10 while generator_updates < 25: generator steps at batchid 0 and 10 (optimizertts_wgan.py:225-231)
+    assert [r is not None for r in rets] == [True] + [False] * 9 + [True, False]
+    assert opt.generator_updates == 2 and len(opt.costs_tra_critic_batches) == 12
+    assert all(np.isfinite(c) for c in opt.costs_tra_critic_batches)
+
+
+def test_hipgraph_replay_matches_eager():
+    from percivaltts_amd import optimizertts_wgan
+    outs = []
+    for use_graph in (False, True):
+        cfg, voc, mod, crit, a, gw, cw, X, Y, al = build('default')
+        cfg.train_wgan_hipgraph = use_graph
+        opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype='WLSWGAN', critic=crit)
+        opt.prepare()
+        Xd, Yd, ald = f32(X), f32(Y), f32(al)
+        if use_graph:
+            # capture (includes 2 warm-up steps), then restore the initial state and replay 3 steps
+            opt._graphed('critic', Xd, Yd)
+            crit.model.set_weights([w.numpy() for w in cw])
+            opt.critic_opti.m.zero_(); opt.critic_opti.v.zero_(); opt.critic_opti.step_count.zero_()
+            g, sX, sY, sA, out = opt._graphs[('critic', tuple(Xd.shape), tuple(Yd.shape))]
+            losses = []
+            for _ in range(3):
+                sA.copy_(ald); g.replay(); losses.append(float(out.item()))
+        else:
+            losses = [float(opt.critic_step(Xd, Yd, ald).item()) for _ in range(3)]
+        outs.append((losses, opt.critic_opti.flat.flat.detach().cpu().clone()))
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-4, atol=1e-6)
+    close(outs[1][1], outs[0][1], 1e-3, 1e-5, 'critic weights after 3 steps, graph vs eager')
