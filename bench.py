@@ -1,0 +1,263 @@
+#!/usr/bin/env python
+"""bench.py -- acoustic frames/sec of the WGAN-GP hot path on MI355X (BASELINE.json metric).
+
+A "step" is one `train_on_batch` (reference optimizertts_wgan.py:216-241) on one resident synthetic batch:
+one critic step, plus one generator step on every 5th batch (the steady-state schedule, :225-231).
+Workload at N=1 is BASELINE.json configs[1]: [64,400,601] -> [64,400,86] (f0 1 + spec 65 + noise 20), DCNN generator
++ 2D-conv critic, fp32, errtype WLSWGAN (run.py's default), lambda = 10.  With N ranks each rank works on its own
+64-sample shard (weak scaling, global batch 64*N) and the flat gradients are all-reduced over RCCL.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline       dominant kernel (the context-Conv1D implicit GEMM on the fp32 MFMA pipe), HIP-event timed here
+  roofline_conv2d the critic's 2D-conv stack against the HBM roofline, algorithmic bytes of SURVEY.md 8(d)
+  cpu_baseline   the CPU oracle (PyTorch-CPU fp32 restatement of the reference path) on a bounded sample
+"""
+from __future__ import print_function
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_GBPS = 8000.0          # HBM3E spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--frames', type=int, default=400)
+    ap.add_argument('--ctx', type=int, default=601)
+    ap.add_argument('--errtype', default='WLSWGAN')
+    ap.add_argument('--eager', action='store_true', help='no hipGraph replay of the step')
+    ap.add_argument('--no-prune', action='store_true', help="also run G's f0/noise branches in the critic step")
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=2)
+    return ap.parse_args()
+
+
+def make_cfg(args):
+    import percivaltts_amd
+    cfg = percivaltts_amd.configuration()
+    # architecture defaults of the reference's run.py:114-120
+    cfg.arch_hiddenwidth = 256
+    cfg.arch_ctx_nbcnnlayers = 1
+    cfg.arch_ctx_winlen = 21
+    cfg.arch_gen_nbcnnlayers = 8
+    cfg.arch_gen_nbfilters = 4
+    cfg.arch_gen_winlen = 5
+    cfg.arch_spec_freqlen = 5
+    cfg.train_batch_size = args.batch
+    cfg.train_wgan_LScoef = 0.25
+    return cfg
+
+
+def synthetic(B, T, ctx, out, spec, seed, device):
+    """X ~ U(-1,1); Y: f0+spec ~ N(0,1), noise mask ~ U(0,1)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    X = torch.rand(B, T, ctx, generator=g) * 2 - 1
+    Y = torch.randn(B, T, out, generator=g)
+    Y[:, :, 1 + spec:] = torch.rand(B, T, out - 1 - spec, generator=g)
+    return X.to(device).contiguous(), Y.to(device).contiguous()
+
+
+def cpu_baseline(args, cfg_dims):
+    """The oracle, fp32, all host cores, one cycle (5 critic steps + 1 generator step) at a reduced batch."""
+    import torch
+    from oracle import percival_oracle as O
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    ctx, spec, nm = cfg_dims
+    a = O.Arch(ctx, spec, nm)
+    B, T = args.cpu_batch, args.frames
+    f32 = lambda ws: [w.to(torch.float32) for w in ws]
+    gw = f32(O.random_weights(O.generator_weight_shapes(a), seed=1))
+    cw = f32(O.random_weights(O.critic_weight_shapes(a), seed=2))
+    g = torch.Generator().manual_seed(123)
+    X = torch.rand(B, T, ctx, generator=g) * 2 - 1
+    Y = torch.randn(B, T, a.outsize, generator=g)
+    al = torch.rand(B, generator=g)
+    w_ls, ww = O.wls_weights(spec, nm, 0, 0.25, 30.0)
+    w_ls = torch.tensor(w_ls, dtype=torch.float32)
+    gshapes = O.generator_weight_shapes(a)
+    train_idx, i = [], 0
+    while i < len(gshapes):
+        if len(gshapes[i]) == 1 and i + 3 < len(gshapes) and all(gshapes[i + k] == gshapes[i] for k in range(4)):
+            train_idx += [i, i + 1]; i += 4
+        else:
+            train_idx.append(i); i += 1
+    cm = [torch.zeros_like(w) for w in cw]; cv = [torch.zeros_like(w) for w in cw]
+    gm = [torch.zeros_like(gw[i]) for i in train_idx]; gv = [torch.zeros_like(gw[i]) for i in train_idx]
+    t0 = time.time()
+    for k in range(5):
+        for w in cw: w.requires_grad_(True)
+        total, _ = O.critic_step_loss(cw, gw, a, X, Y, al)
+        grads = torch.autograd.grad(total, cw)
+        for w in cw: w.requires_grad_(False)
+        O.adam_keras(cw, grads, cm, cv, k + 1, 1e-4, 0.5, 0.9)
+    for i in train_idx: gw[i].requires_grad_(True)
+    lt, _ = O.generator_step_loss(cw, gw, a, X, Y, 'WLSWGAN', w_ls, ww)
+    gg = torch.autograd.grad(lt, [gw[i] for i in train_idx], allow_unused=True)
+    for i in train_idx: gw[i].requires_grad_(False)
+    gg = [g_ if g_ is not None else torch.zeros_like(gw[i]) for g_, i in zip(gg, train_idx)]
+    O.adam_keras([gw[i] for i in train_idx], gg, gm, gv, 1, 1e-3, 0.5, 0.9)
+    dt = time.time() - t0
+    return {'value': 5.0 * B * T / dt, 'unit': 'frames/s', 'cores': ncores, 'kind': 'port',
+            'sample': 'one cycle (5 critic + 1 generator step) at B={} T={} ctx={}, fp32 PyTorch-CPU oracle, {:.1f} s'.format(B, T, ctx, dt)}
+
+
+def roofline_leg(opt, X, Y, args):
+    """HIP-event timing of every C-ABI call of one eager critic step (and one generator step)."""
+    import torch
+    from percivaltts_amd import _hip
+    B, T = X.shape[0], X.shape[1]
+    voc = opt._model.vocoder
+    F, C, L = voc.specsize(), opt.cfg.arch_gen_nbfilters, opt.cfg.arch_gen_nbcnnlayers
+    for _ in range(2):
+        opt.critic_step(X, Y)
+    torch.cuda.synchronize()
+    reps = 5
+    recs = []
+    for _ in range(reps):
+        with _hip.KernelTimer() as kt:
+            opt.critic_step(X, Y)
+        recs.append(kt.durations_ms())
+    # average per call position
+    n = len(recs[0])
+    avg = [(recs[0][i][0], recs[0][i][1], sum(r[i][2] for r in recs) / reps) for i in range(n)]
+    M, N, K = B * T, opt.cfg.arch_hiddenwidth, opt.cfg.arch_ctx_winlen * X.shape[2]
+    conv1d_fwd = [d for (nm, tag, d) in avg if nm == 'ptts_gemm' and tag == (M, N, K, 0, 0, 1)]
+    conv1d_bww = [d for (nm, tag, d) in avg if nm == 'ptts_gemm' and tag == (K, N, M, 1, 0, 1)]
+    # the critic's conv2d stack: every conv2d call without a BatchNorm affine whose batch is B (G's convs carry scale/shift
+    # or are 1->C without bias; separate them by running G first)
+    classes = {}
+    for nm, tag, d in avg:
+        classes[nm] = classes.get(nm, 0.0) + d
+    out = {}
+    if conv1d_fwd:
+        t = sum(conv1d_fwd) / len(conv1d_fwd) * 1e-3
+        fl = 2.0 * M * N * K
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_f32_mfma_kernel<0,0,1> (context Conv1D as implicit GEMM, M={} N={} K={})'.format(M, N, K),
+                           'achieved': fl / t / 1e12, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                           'frac': fl / t / 1e12 / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                           'launch_ms': t * 1e3, 'launches_per_critic_step': len(conv1d_fwd)}
+    if conv1d_bww:
+        t = sum(conv1d_bww) / len(conv1d_bww) * 1e-3
+        out['conv1d_bwd_weight'] = {'achieved': 2.0 * M * N * K / t / 1e12, 'unit': 'TFLOP/s', 'launch_ms': t * 1e3}
+    # critic conv2d stack (HBM roofline).  Generator convs are timed separately.
+    with torch.no_grad():
+        fake = opt._fake_sample(X, True)
+    torch.cuda.synchronize()
+    crit_recs = []
+    for _ in range(reps):
+        opt.critic_opti.zero_grad()
+        with _hip.KernelTimer() as kt:
+            total, _ = opt.critic_loss(X, Y, None, training=True, fake=fake)
+            total.backward()
+        crit_recs.append(kt.durations_ms())
+    n = len(crit_recs[0])
+    t_conv2d = sum(sum(r[i][2] for r in crit_recs) / reps for i in range(n) if crit_recs[0][i][0].startswith('ptts_conv2d')) * 1e-3
+    n_conv2d = sum(1 for i in range(n) if crit_recs[0][i][0].startswith('ptts_conv2d'))
+    alg_bytes = (149.0 * C + 3.0) * B * T * F * 4.0 if L == 8 else None
+    if alg_bytes and t_conv2d > 0:
+        out['roofline_conv2d'] = {'bound': 'hbm', 'kernel': 'critic 2D-conv stack: {} conv2d fwd/bwd launches per critic step'.format(n_conv2d),
+                                  'achieved': alg_bytes / t_conv2d / 1e9, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+                                  'frac': alg_bytes / t_conv2d / 1e9 / PEAK_HBM_GBPS, 'traffic': None,
+                                  'algorithmic_bytes_per_critic_step': alg_bytes, 'time_ms': t_conv2d * 1e3}
+    out['critic_step_kernel_ms'] = {k: round(v, 4) for k, v in sorted(classes.items(), key=lambda kv: -kv[1])}
+    return out
+
+
+def main():
+    args = parse()
+    world_env = int(os.environ.get('WORLD_SIZE', '0'))
+    if args.gpus > 1 and world_env == 0:
+        # not under torchrun: start the ranks as child processes (nothing here has touched the GPU yet)
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(29500 + os.getpid() % 1000), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    import torch
+    from percivaltts_amd import vocoders, modeltts_common, networks_critic, optimizertts_wgan, parallel, backend_hip
+
+    world, rank = parallel.init()
+    dev = backend_hip.device()
+    cfg = make_cfg(args)
+    cfg.train_wgan_hipgraph = (not args.eager) and world == 1
+    cfg.train_wgan_prune_dead_branches = not args.no_prune
+    spec, nm = 65, 20
+    voc = vocoders.VocoderPML(16000, 0.005, spec, nm)
+    import io, contextlib
+    quiet = io.StringIO()
+    with contextlib.redirect_stdout(quiet):
+        mod = modeltts_common.DCNNF0SpecNoiseFeatures(args.ctx, voc, cfg)
+        crit = networks_critic.Critic(voc, args.ctx, cfg)
+        opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype=args.errtype, critic=crit)
+        opt.prepare()
+    opt.generator_updates = 26           # steady state: critic_runs = 5 (optimizertts_wgan.py:225-228)
+
+    B, T = args.batch, args.frames
+    nbuf = 3
+    batches = [synthetic(B, T, args.ctx, voc.featuressize(), spec, 123 + 17 * rank + i, dev) for i in range(nbuf)]
+
+    def run(nsteps, start):
+        for i in range(nsteps):
+            X, Y = batches[(start + i) % nbuf]
+            opt.device_step(start + i, X, Y)
+
+    run(args.warmup, 0)
+    parallel.barrier(); torch.cuda.synchronize()
+    t0 = time.time()
+    run(args.steps, 0)
+    torch.cuda.synchronize(); parallel.barrier()
+    dt = parallel.max_over_ranks(time.time() - t0, dev)
+
+    # separate timings of the two step kinds (eager or graph as configured), rank 0 only
+    extra = {}
+    if rank == 0:
+        X, Y = batches[0]
+        def timeit(fn, n):
+            fn(); torch.cuda.synchronize()
+            t = time.time()
+            for _ in range(n): fn()
+            torch.cuda.synchronize()
+            return (time.time() - t) / n * 1e3
+        use_graph = bool(cfg.train_wgan_hipgraph)
+        extra['critic_step_ms'] = timeit((lambda: opt._graphed('critic', X, Y)) if use_graph else (lambda: opt.critic_step(X, Y)), 10)
+        extra['generator_step_ms'] = timeit((lambda: opt._graphed('generator', X, Y)) if use_graph else (lambda: opt.generator_step(X, Y)), 5)
+        if not args.no_roofline:
+            extra.update(roofline_leg(opt, X, Y, args))
+        if not args.no_cpu_baseline and world == 1:
+            extra['cpu_baseline'] = cpu_baseline(args, (args.ctx, spec, nm))
+
+    if rank == 0:
+        frames = float(args.steps) * B * T * world
+        res = {
+            'metric': 'acoustic frames/sec per WGAN-GP critic+gen step', 'value': frames / dt, 'unit': 'frames/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: synthetic [{b},{t},{c}]->[{b},{t},{o}] (f0 1 + spec 65 + noise 20), DCNN generator + '
+                                   '2D-conv critic, fp32, {e}, lambda=10, schedule 5 critic steps : 1 generator step; '
+                                   'step = one train_on_batch'.format(b=B, t=T, c=args.ctx, o=voc.featuressize(), e=args.errtype),
+                       'per_gpu_batch': B, 'global_batch': B * world, 'frames_per_step_per_gpu': B * T,
+                       'parallelism': 'dp{}'.format(world), 'hipgraph': bool(cfg.train_wgan_hipgraph),
+                       'prune_dead_generator_branches_in_critic_step': bool(cfg.train_wgan_prune_dead_branches),
+                       'generator_params': mod.count_params(), 'critic_params': crit.model.count_params()},
+        }
+        res.update(extra)
+        print(json.dumps(res))
+    parallel.barrier()
+
+
+if __name__ == '__main__':
+    main()

@@ -76,9 +76,37 @@ def last_error():
     return lib().ptts_last_error().decode('utf8', 'replace')
 
 
-def call(name, *args):
-    """Invoke an int-returning entry point and raise on a non-zero status."""
+class KernelTimer(object):
+    """HIP-event timing of every C-ABI call made while it is active (bench.py's roofline leg).  Events are recorded on
+    the stream the kernels are launched on (torch's current stream).  Not usable during graph capture."""
+    active = None
+
+    def __init__(self):
+        self.records = []   # (name, tag, start_event, end_event)
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        KernelTimer.active = None
+
+    def durations_ms(self):
+        torch.cuda.synchronize()
+        return [(n, t, s.elapsed_time(e)) for n, t, s, e in self.records]
+
+
+def call(name, *args, **kw):
+    """Invoke an int-returning entry point and raise on a non-zero status.  `tag` labels the call for KernelTimer."""
+    timer = KernelTimer.active
+    if timer is not None:
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
     rc = getattr(lib(), name)(*args)
+    if timer is not None:
+        e.record()
+        timer.records.append((name, kw.get('tag'), s, e))
     if rc != 0:
         raise HipLibraryError('{} failed (rc={}): {}'.format(name, rc, last_error()))
 

@@ -153,7 +153,9 @@ __device__ __forceinline__ void store_tiles(float* As, float* Bs, const Frag& fr
     }
 }
 
-template <int TRANSA, int TRANSB>
+// CONV != 0 marks the implicit-convolution instantiation (same code; its own symbol so that a profile separates the
+// context-Conv1D products from the small Dense ones).
+template <int TRANSA, int TRANSB, int CONV>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_mfma_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float As[BK * LDA_S];
     __shared__ __attribute__((aligned(16))) float Bs[BK * LDB_S];
@@ -259,9 +261,12 @@ extern "C" int ptts_gemm(const float* A, const float* Bm, const float* bias, flo
         if (e != hipSuccess) { set_error("gemm: memset failed: %s", hipGetErrorString(e)); return PTTS_ELAUNCH; }
     }
     dim3 grid(tn, tm, splits), block(GEMM_THREADS);
-    if (transA == 0 && transB == 0) hipLaunchKernelGGL((gemm_f32_mfma_kernel<0, 0>), grid, block, 0, st, g);
-    else if (transA == 0 && transB == 1) hipLaunchKernelGGL((gemm_f32_mfma_kernel<0, 1>), grid, block, 0, st, g);
-    else if (transA == 1 && transB == 0) hipLaunchKernelGGL((gemm_f32_mfma_kernel<1, 0>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((gemm_f32_mfma_kernel<1, 1>), grid, block, 0, st, g);
+    const bool conv = seg_stride != 0;
+    if (conv && transA == 0 && transB == 0) hipLaunchKernelGGL((gemm_f32_mfma_kernel<0, 0, 1>), grid, block, 0, st, g);
+    else if (conv && transA == 1 && transB == 0) hipLaunchKernelGGL((gemm_f32_mfma_kernel<1, 0, 1>), grid, block, 0, st, g);
+    else if (transA == 0 && transB == 0) hipLaunchKernelGGL((gemm_f32_mfma_kernel<0, 0, 0>), grid, block, 0, st, g);
+    else if (transA == 0 && transB == 1) hipLaunchKernelGGL((gemm_f32_mfma_kernel<0, 1, 0>), grid, block, 0, st, g);
+    else if (transA == 1 && transB == 0) hipLaunchKernelGGL((gemm_f32_mfma_kernel<1, 0, 0>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_mfma_kernel<1, 1, 0>), grid, block, 0, st, g);
     return check_launch("gemm");
 }

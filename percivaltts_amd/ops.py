@@ -116,7 +116,7 @@ def _conv2d_fwd_raw(x, w, b, scale, shift, mask_src, mode, alpha, dil_t, pad_mod
     assert mask_src is None or mask_src.shape == x.shape
     y = torch.empty((B, T, F, Cout), dtype=torch.float32, device=x.device)
     call('ptts_conv2d_fwd', ptr(x), ptr(w), ptr(b), ptr(scale), ptr(shift), ptr(mask_src), ptr(y),
-         B, T, F, Cin, Cout, KT, KF, dil_t, pad_mode, mode, alpha, stream())
+         B, T, F, Cin, Cout, KT, KF, dil_t, pad_mode, mode, alpha, stream(), tag=(B, T, F, Cin, Cout, mode))
     return y
 
 
@@ -137,7 +137,8 @@ def _conv2d_bwd_raw(dy, x, w, scale, shift, mask_src, mode, alpha, dil_t, pad_mo
     ws = _workspace(nws, dev)
     call('ptts_conv2d_bwd', ptr(dy), ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(mask_src),
          ptr(dx), ptr(dw), ptr(db), ptr(dscale), ptr(dshift), ptr(ws), ws.numel(),
-         B, T, F, Cin, Cout, KT, KF, dil_t, pad_mode, mode, alpha, stream())
+         B, T, F, Cin, Cout, KT, KF, dil_t, pad_mode, mode, alpha, stream(),
+         tag=(B, T, F, Cin, Cout, mode, int(want_dx), int(want_dw or want_db), int(want_affine)))
     return dx, (dw if want_dw else None), db, dscale, dshift
 
 
@@ -156,7 +157,8 @@ def gemm_raw(A, Bm, C, M, N, K, transA=0, lda=None, rows_per_seg=None, seg_strid
     if ldc is None:
         ldc = N
     call('ptts_gemm', ptr(A), ptr(Bm), ptr(bias), ptr(C), M, N, K, transA, lda, rows_per_seg, seg_stride,
-         transB, ldb, ldc, mode, ptr(scale), ptr(shift), ptr(mask_src), alpha, accumulate, stream())
+         transB, ldb, ldc, mode, ptr(scale), ptr(shift), ptr(mask_src), alpha, accumulate, stream(),
+         tag=(M, N, K, transA, transB, int(seg_stride != 0)))
     return C
 
 

@@ -194,9 +194,10 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
                 return fake
             return self._model.kerasmodel(X, training=training, memo=memo)
 
-    def critic_loss(self, X, Y, alpha=None, training=True):
+    def critic_loss(self, X, Y, alpha=None, training=True, fake=None):
         """Total critic loss and its three parts on device tensors X [B,T,ctx], Y [B,T,out]."""
-        fake = self._fake_sample(X, training)
+        if fake is None:
+            fake = self._fake_sample(X, training)
         x_hat = RandomWeightedAverage(X.shape[0])([Y, fake], alpha).requires_grad_(True)
         valid, fake_v, v_hat = self.critic_net.forward_multi(0, [Y, fake, x_hat], [X], training=training)
         l_valid = wasserstein_loss(-1.0, valid)
