@@ -29,6 +29,7 @@ __global__ __launch_bounds__(EW_THREADS) void colreduce2_kernel(Op op, long long
         const int r = tid / C, c = tid - r * C;
         double q1 = 0.0, q2 = 0.0;
         if (r < R) {
+#pragma unroll 4
             for (long long row = (long long)blockIdx.x * R + r; row < rows; row += (long long)gridDim.x * R) {
                 float a, b;
                 op(row * C + c, c, a, b);
@@ -69,20 +70,30 @@ __global__ __launch_bounds__(EW_THREADS) void colreduce2_kernel(Op op, long long
     }
 }
 
-__global__ void colreduce_final_kernel(const double* __restrict__ partials, int nblocks, int n2c,
-                                       double* __restrict__ out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n2c) return;
+// out[j] = sum_b partials[b][j] in a fixed order.  grid = ceil(n2c/32), 256 lanes = 32 columns x 8 row groups.
+__global__ __launch_bounds__(256) void colreduce_final_kernel(const double* __restrict__ partials, int nblocks,
+                                                              int n2c, double* __restrict__ out) {
+    __shared__ double sh[8][32];
+    const int jj = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + jj;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * n2c + j];
-    out[j] = s;
+    if (j < n2c)
+        for (int b = g; b < nblocks; b += 8) s += partials[(size_t)b * n2c + j];
+    sh[g][jj] = s;
+    __syncthreads();
+    if (g == 0 && j < n2c) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sh[k][jj];
+        out[j] = t;
+    }
 }
 
 static int colreduce_blocks(long long rows, int C) {
     const int R = C <= EW_THREADS ? EW_THREADS / C : 1;
-    long long b = (rows + (long long)R * 8 - 1) / ((long long)R * 8);
+    long long b = (rows + (long long)R * 4 - 1) / ((long long)R * 4);
     if (b < 1) b = 1;
-    if (b > 1024) b = 1024;
+    if (b > 512) b = 512;
     return (int)b;
 }
 
@@ -373,7 +384,7 @@ static int run_colreduce(const Op& op, long long rows, int C, double* out, void*
     hipLaunchKernelGGL((colreduce2_kernel<Op>), dim3(nb), dim3(EW_THREADS), 0, st, op, rows, C, (double*)workspace);
     int rc = check_launch(what);
     if (rc) return rc;
-    hipLaunchKernelGGL(colreduce_final_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st,
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st,
                        (const double*)workspace, nb, 2 * C, out);
     return check_launch(what);
 }

@@ -128,6 +128,52 @@ __device__ __forceinline__ void load_tiles(const GemmArgs& g, int m0, int n0, in
     }
 }
 
+// Interior tiles: no bounds checks, transform selected at compile time, four 16-byte loads in flight per lane.
+template <int TRANSA, int TRANSB, int MODE>
+__device__ __forceinline__ void load_tiles_fast(const GemmArgs& g, int m0, int n0, int k0, Frag& fr) {
+    const int tid = threadIdx.x;
+    f32x4u va[2], vb[2], vm[2];
+    long long offa[2];
+    int cha[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = tid + j * GEMM_THREADS;
+        if (TRANSA == 0) {
+            const int m = m0 + (q >> 2), k = k0 + (q & 3) * 4;
+            offa[j] = (m / g.rows_per_seg) * g.seg_stride + (m % g.rows_per_seg) * g.lda + k;
+            cha[j] = k;
+        } else {
+            const int k = k0 + (q >> 5), m = m0 + (q & 31) * 4;
+            offa[j] = (k / g.rows_per_seg) * g.seg_stride + (k % g.rows_per_seg) * g.lda + m;
+            cha[j] = m;
+        }
+        va[j] = *reinterpret_cast<const f32x4u*>(g.A + offa[j]);
+        if (MODE == PTTS_IN_MASKMUL) vm[j] = *reinterpret_cast<const f32x4u*>(g.mask_src + offa[j]);
+        if (TRANSB == 0) {
+            const int k = k0 + (q >> 5), n = n0 + (q & 31) * 4;
+            vb[j] = *reinterpret_cast<const f32x4u*>(g.B + (long long)k * g.ldb + n);
+        } else {
+            const int n = n0 + (q >> 2), k = k0 + (q & 3) * 4;
+            vb[j] = *reinterpret_cast<const f32x4u*>(g.B + (long long)n * g.ldb + k);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = va[j][e];
+            if (MODE == PTTS_IN_LRELU) {
+                if (g.in_scale) v = v * g.in_scale[cha[j] + e] + g.in_shift[cha[j] + e];
+                v = lrelu(v, g.alpha);
+            } else if (MODE == PTTS_IN_MASKMUL) {
+                v *= lrelu_d(vm[j][e], g.alpha);
+            }
+            fr.a[j][e] = v;
+            fr.b[j][e] = vb[j][e];
+        }
+    }
+}
+
 template <int TRANSA, int TRANSB>
 __device__ __forceinline__ void store_tiles(float* As, float* Bs, const Frag& fr) {
     const int tid = threadIdx.x;
@@ -155,16 +201,19 @@ __device__ __forceinline__ void store_tiles(float* As, float* Bs, const Frag& fr
 
 // CONV != 0 marks the implicit-convolution instantiation (same code; its own symbol so that a profile separates the
 // context-Conv1D products from the small Dense ones).
-template <int TRANSA, int TRANSB, int CONV>
+// LDS is double-buffered: tile k+1 is written to the other buffer while tile k feeds the MFMAs -> one barrier per
+// k-step; the fragments of k-pair kk+1 are read from LDS while the four MFMAs of k-pair kk execute.
+template <int TRANSA, int TRANSB, int CONV, int MODE>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_mfma_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[BK * LDA_S];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB_S];
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA_S];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB_S];
     const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
     const int kbeg = blockIdx.z * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int l31 = lane & 31, lh = lane >> 5;
+    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -175,23 +224,39 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_mfma_kernel(GemmArgs g)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     Frag fr;
-    if (kbeg < kend) load_tiles<TRANSA, TRANSB>(g, m0, n0, kbeg, kend, fr);
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        __syncthreads();                       // previous tile's fragment reads are done
-        store_tiles<TRANSA, TRANSB>(As, Bs, fr);
-        __syncthreads();
-        if (k0 + BK < kend) load_tiles<TRANSA, TRANSB>(g, m0, n0, k0 + BK, kend, fr);   // prefetch
+    auto load = [&](int k0) {
+        if (interior && k0 + BK <= kend) load_tiles_fast<TRANSA, TRANSB, MODE>(g, m0, n0, k0, fr);
+        else load_tiles<TRANSA, TRANSB>(g, m0, n0, k0, kend, fr);
+    };
+    if (kbeg < kend) {
+        load(kbeg);
+        store_tiles<TRANSA, TRANSB>(As[0], Bs[0], fr);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK, buf ^= 1) {
+        const bool more = k0 + BK < kend;
+        if (more) load(k0 + BK);                 // global -> registers, in flight during the MFMAs below
+        const float* as = As[buf] + lh * LDA_S + wm + l31;
+        const float* bs = Bs[buf] + lh * LDB_S + wn + l31;
+        float ra[2][2], rb[2][2];
+        ra[0][0] = as[0]; ra[0][1] = as[32]; rb[0][0] = bs[0]; rb[0][1] = bs[32];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            const float a0 = As[(kk + lh) * LDA_S + wm + l31];
-            const float a1 = As[(kk + lh) * LDA_S + wm + 32 + l31];
-            const float b0 = Bs[(kk + lh) * LDB_S + wn + l31];
-            const float b1 = Bs[(kk + lh) * LDB_S + wn + 32 + l31];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            const int c = (kk >> 1) & 1, nx = c ^ 1;
+            if (kk + 2 < BK) {
+                ra[nx][0] = as[(kk + 2) * LDA_S];
+                ra[nx][1] = as[(kk + 2) * LDA_S + 32];
+                rb[nx][0] = bs[(kk + 2) * LDB_S];
+                rb[nx][1] = bs[(kk + 2) * LDB_S + 32];
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[c][0], rb[c][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[c][0], rb[c][1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[c][1], rb[c][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[c][1], rb[c][1], acc[1][1], 0, 0, 0);
         }
+        if (more) store_tiles<TRANSA, TRANSB>(As[buf ^ 1], Bs[buf ^ 1], fr);
+        __syncthreads();
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -262,11 +327,20 @@ extern "C" int ptts_gemm(const float* A, const float* Bm, const float* bias, flo
     }
     dim3 grid(tn, tm, splits), block(GEMM_THREADS);
     const bool conv = seg_stride != 0;
-    if (conv && transA == 0 && transB == 0) hipLaunchKernelGGL((gemm_f32_mfma_kernel<0, 0, 1>), grid, block, 0, st, g);
-    else if (conv && transA == 1 && transB == 0) hipLaunchKernelGGL((gemm_f32_mfma_kernel<1, 0, 1>), grid, block, 0, st, g);
-    else if (transA == 0 && transB == 0) hipLaunchKernelGGL((gemm_f32_mfma_kernel<0, 0, 0>), grid, block, 0, st, g);
-    else if (transA == 0 && transB == 1) hipLaunchKernelGGL((gemm_f32_mfma_kernel<0, 1, 0>), grid, block, 0, st, g);
-    else if (transA == 1 && transB == 0) hipLaunchKernelGGL((gemm_f32_mfma_kernel<1, 0, 0>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((gemm_f32_mfma_kernel<1, 1, 0>), grid, block, 0, st, g);
+#define PTTS_GEMM_LAUNCH(TA, TB, CV, MD) hipLaunchKernelGGL((gemm_f32_mfma_kernel<TA, TB, CV, MD>), grid, block, 0, st, g)
+#define PTTS_GEMM_MODES(TA, TB)                                                  \
+    switch (in_mode) {                                                           \
+        case PTTS_IN_LRELU: PTTS_GEMM_LAUNCH(TA, TB, 0, PTTS_IN_LRELU); break;   \
+        case PTTS_IN_MASKMUL: PTTS_GEMM_LAUNCH(TA, TB, 0, PTTS_IN_MASKMUL); break; \
+        default: PTTS_GEMM_LAUNCH(TA, TB, 0, PTTS_IN_NONE); break;               \
+    }
+    if (conv && in_mode == PTTS_IN_NONE && transA == 0 && transB == 0) PTTS_GEMM_LAUNCH(0, 0, 1, PTTS_IN_NONE);
+    else if (conv && in_mode == PTTS_IN_NONE && transA == 1 && transB == 0) PTTS_GEMM_LAUNCH(1, 0, 1, PTTS_IN_NONE);
+    else if (transA == 0 && transB == 0) { PTTS_GEMM_MODES(0, 0) }
+    else if (transA == 0 && transB == 1) { PTTS_GEMM_MODES(0, 1) }
+    else if (transA == 1 && transB == 0) { PTTS_GEMM_MODES(1, 0) }
+    else { PTTS_GEMM_MODES(1, 1) }
+#undef PTTS_GEMM_MODES
+#undef PTTS_GEMM_LAUNCH
     return check_launch("gemm");
 }
