@@ -129,6 +129,147 @@ __global__ __launch_bounds__(LX * LY) void lstm_bwd_step_kernel(
     dc_state[si] = dc * gf;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// MFMA step kernels (H % 16 == 0): v_mfma_f32_16x16x4_f32, K split over the 4 waves of a workgroup,
+// partial tiles combined through LDS, then one lane per (sample, unit) applies the gate math.
+//   forward : tile = 16 samples x 8 units x 4 gates (two MFMA column blocks: gates {i,f} and {c,o}),
+//             grid (H/8, ceil(B/16), ndir) = 256 workgroups at H = 256, B = 64 -> every CU busy.
+//   backward: tile = 16 samples x 16 units of dh_rec = da_next . U^T, grid (H/16, ceil(B/16), ndir).
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void lstm_fwd_step_mfma_kernel(
+    const float* __restrict__ xproj, const float* __restrict__ U, float* __restrict__ h_out,
+    float* __restrict__ gates, float* __restrict__ c_out, int B, int T, int H, int ndir, int reverse, int s) {
+    __shared__ float red[4][2][256];
+    const int d = blockIdx.z;
+    const bool rev = ndir == 2 ? d == 1 : reverse != 0;
+    const int t = rev ? T - 1 - s : s;
+    const int tp = rev ? t + 1 : t - 1;
+    const int j0 = blockIdx.x * 8, b0 = blockIdx.y * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const long long G4 = 4LL * H, HH = (long long)ndir * H;
+    if (s > 0) {
+        const int ksteps = H / 16;                 // k-steps of 4 per wave
+        const int kbase = wave * (H / 4);
+        const int b = b0 + r16;
+        const float* hp = h_out + ((long long)(b < B ? b : 0) * T + tp) * HH + (long long)d * H + kbase + q;
+        const float* Ud = U + (long long)d * H * G4 + (long long)(kbase + q) * G4 + j0 + (r16 & 7);
+        const int gx = (r16 >> 3) * H, gy = (2 + (r16 >> 3)) * H;
+        f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 0; s0 < ksteps; s0 += 8) {
+            float a[8], bx[8], by[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int st = s0 + i;
+                if (st < ksteps) {
+                    a[i] = b < B ? hp[4 * st] : 0.f;
+                    const float* u = Ud + (long long)(4 * st) * G4;
+                    bx[i] = u[gx];
+                    by[i] = u[gy];
+                } else { a[i] = 0.f; bx[i] = 0.f; by[i] = 0.f; }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bx[i], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], by[i], acc1, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            red[wave][0][(q * 4 + r) * 16 + r16] = acc0[r];
+            red[wave][1][(q * 4 + r) * 16 + r16] = acc1[r];
+        }
+        __syncthreads();
+    }
+    if (tid >= 128) return;
+    const int bb = tid >> 3, jj = tid & 7;
+    const int b = b0 + bb, j = j0 + jj;
+    if (b >= B) return;
+    const float* xp = xproj + (((long long)b * T + t) * ndir + d) * G4;
+    float a4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float v = xp[g * H + j];
+        if (s > 0) {
+            const int idx = bb * 16 + (g & 1) * 8 + jj;
+            v += red[0][g >> 1][idx] + red[1][g >> 1][idx] + red[2][g >> 1][idx] + red[3][g >> 1][idx];
+        }
+        a4[g] = v;
+    }
+    const float gi = sigmoidf_(a4[0]), gf = sigmoidf_(a4[1]), gc = tanhf(a4[2]), go = sigmoidf_(a4[3]);
+    const long long so = ((long long)b * T + t) * HH + (long long)d * H + j;
+    const float cp = s > 0 ? c_out[((long long)b * T + tp) * HH + (long long)d * H + j] : 0.f;
+    const float c = gf * cp + gi * gc;
+    c_out[so] = c;
+    h_out[so] = go * tanhf(c);
+    float* gp = gates + (((long long)b * T + t) * ndir + d) * G4;
+    gp[j] = gi; gp[H + j] = gf; gp[2 * H + j] = gc; gp[3 * H + j] = go;
+}
+
+__global__ __launch_bounds__(256) void lstm_bwd_step_mfma_kernel(
+    const float* __restrict__ dh_out, const float* __restrict__ UT, const float* __restrict__ gates,
+    const float* __restrict__ c_out, float* __restrict__ dgates, float* __restrict__ dc_state, int B, int T,
+    int H, int ndir, int reverse, int s) {
+    __shared__ float red[4][256];
+    const int d = blockIdx.z;
+    const bool rev = ndir == 2 ? d == 1 : reverse != 0;
+    const int t = rev ? T - 1 - s : s;
+    const int tp = rev ? t + 1 : t - 1;
+    const int tn = rev ? t - 1 : t + 1;
+    const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const long long G4 = 4LL * H, HH = (long long)ndir * H;
+    const bool has_next = s < T - 1;
+    if (has_next) {
+        const int nsteps = H / 4;                  // n-steps of 4 per wave (each wave owns H of the 4H gate columns)
+        const int nbase = wave * H;
+        const int b = b0 + r16;
+        const float* ap = dgates + (((long long)(b < B ? b : 0) * T + tn) * ndir + d) * G4 + nbase + q;
+        const float* bp = UT + (long long)d * G4 * H + (long long)(nbase + q) * H + j0 + r16;
+        f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 0; s0 < nsteps; s0 += 16) {
+            float a[16], bv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int st = s0 + i;
+                if (st < nsteps) {
+                    a[i] = b < B ? ap[4 * st] : 0.f;
+                    bv[i] = bp[(long long)(4 * st) * H];
+                } else { a[i] = 0.f; bv[i] = 0.f; }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bv[i], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][(q * 4 + r) * 16 + r16] = acc[r];
+        __syncthreads();
+    }
+    const int bb = tid >> 4, jj = tid & 15;
+    const int b = b0 + bb, j = j0 + jj;
+    if (b >= B) return;
+    float dh = dh_out[((long long)b * T + t) * HH + (long long)d * H + j];
+    if (has_next) dh += red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    const float* gp = gates + (((long long)b * T + t) * ndir + d) * G4;
+    const float gi = gp[j], gf = gp[H + j], gc = gp[2 * H + j], go = gp[3 * H + j];
+    const long long so = ((long long)b * T + t) * HH + (long long)d * H + j;
+    const float c = c_out[so];
+    const float cp = s > 0 ? c_out[((long long)b * T + tp) * HH + (long long)d * H + j] : 0.f;
+    const float tc = tanhf(c);
+    const long long si = ((long long)d * B + b) * H + j;
+    float dc = dh * go * (1.f - tc * tc);
+    if (has_next) dc += dc_state[si];
+    float* dg = dgates + (((long long)b * T + t) * ndir + d) * G4;
+    dg[j] = dc * gc * gi * (1.f - gi);
+    dg[H + j] = dc * cp * gf * (1.f - gf);
+    dg[2 * H + j] = dc * gi * (1.f - gc * gc);
+    dg[3 * H + j] = dh * tc * go * (1.f - go);
+    dc_state[si] = dc * gf;
+}
+
 }  // namespace ptts
 
 using namespace ptts;
@@ -141,6 +282,13 @@ extern "C" int ptts_lstm_fwd(const float* xproj, const float* U, float* h_out, f
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((H + LX - 1) / LX, (B + LY - 1) / LY, ndir), block(LX, LY);
     const size_t lds = (size_t)LY * H * sizeof(float);
+    if (H % 16 == 0) {
+        dim3 mgrid(H / 8, (B + 15) / 16, ndir);
+        for (int s = 0; s < T; ++s)
+            hipLaunchKernelGGL(lstm_fwd_step_mfma_kernel, mgrid, dim3(256), 0, st, xproj, U, h_out, gates, c_out, B, T,
+                               H, ndir, reverse, s);
+        return check_launch("lstm_fwd_mfma");
+    }
     for (int s = 0; s < T; ++s) {
         hipLaunchKernelGGL(lstm_fwd_step_kernel, grid, block, lds, st, xproj, U, h_out, gates, c_out, B, T, H, ndir,
                            reverse, s);
@@ -173,6 +321,13 @@ extern "C" int ptts_lstm_bwd(const float* dh_out, const float* U, const float* g
     hipLaunchKernelGGL(lstm_transpose_kernel, dim3(tb), dim3(256), 0, st, U, UT, H, ndir);
     dim3 grid((H + LX - 1) / LX, (B + LY - 1) / LY, ndir), block(LX, LY);
     const size_t lds = (size_t)LY * 4 * H * sizeof(float);
+    if (H % 16 == 0) {
+        dim3 mgrid(H / 16, (B + 15) / 16, ndir);
+        for (int s = T - 1; s >= 0; --s)
+            hipLaunchKernelGGL(lstm_bwd_step_mfma_kernel, mgrid, dim3(256), 0, st, dh_out, (const float*)UT, gates,
+                               c_out, dgates, dc_state, B, T, H, ndir, reverse, s);
+        return check_launch("lstm_bwd_mfma");
+    }
     for (int s = T - 1; s >= 0; --s) {
         hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, block, lds, st, dh_out, (const float*)UT, gates, c_out,
                            dgates, dc_state, B, T, H, ndir, reverse, s);

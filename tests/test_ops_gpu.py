@@ -315,7 +315,7 @@ def test_affine_act(ops, act):
     close(ops.affine_act(dev(x2), None, None, act), f(x2), what='y-noaffine')
 
 
-@pytest.mark.parametrize('case', [(3, 7, 5, 4), (16, 20, 24, 64), (5, 33, 10, 70)])
+@pytest.mark.parametrize('case', [(3, 7, 5, 4), (16, 20, 24, 64), (5, 33, 10, 70), (20, 9, 12, 32), (64, 6, 40, 256)])
 def test_blstm(ops, case):
     B, T, In, H = case
     g = gen(10)
