@@ -62,88 +62,53 @@ __device__ __forceinline__ long long rowbase(const GemmArgs& g, int r) {
 
 struct Frag { float a[NLD][4]; float b[NLD][4]; };
 
-// Edge tiles / K tail: every element guarded.
-template <int TRANSA, int TRANSB>
-__device__ __forceinline__ void load_tiles(const GemmArgs& g, int m0, int n0, int k0, Frag& fr) {
-    const int tid = threadIdx.x;
-    const int kend = g.K;
+// 4 consecutive floats along the contiguous index c of a row; CHECK guards row validity and the end of the row.
+template <bool CHECK>
+__device__ __forceinline__ f32x4u load4(const float* __restrict__ p, bool row_ok, int c, int limit) {
+    f32x4u v = {0.f, 0.f, 0.f, 0.f};
+    if (!CHECK || (row_ok && c + 3 < limit)) {
+        v = *reinterpret_cast<const f32x4u*>(p);
+    } else if (row_ok && c < limit) {          // the vector straddles the end of the row: rare, scalar
 #pragma unroll
-    for (int j = 0; j < NLD; ++j) {
-        const int q = tid + j * GEMM_THREADS;
-        if (TRANSA == 0) {
-            const int m = m0 + q / KQ, k = k0 + (q % KQ) * 4;
-            if (m < g.M) {
-                const long long base = rowbase(g, m);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    fr.a[j][e] = (k + e < kend) ? a_transform(g.A[base + k + e], g, base + k + e, k + e) : 0.f;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) fr.a[j][e] = 0.f;
-            }
-        } else {
-            const int k = k0 + q / (BM / 4), m = m0 + (q % (BM / 4)) * 4;
-            if (k < kend) {
-                const long long base = rowbase(g, k);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    fr.a[j][e] = (m + e < g.M) ? a_transform(g.A[base + m + e], g, base + m + e, m + e) : 0.f;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) fr.a[j][e] = 0.f;
-            }
-        }
-        if (TRANSB == 0) {
-            const int k = k0 + q / (BN / 4), n = n0 + (q % (BN / 4)) * 4;
-            if (k < kend) {
-                const long long base = (long long)k * g.ldb;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) fr.b[j][e] = (n + e < g.N) ? g.B[base + n + e] : 0.f;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) fr.b[j][e] = 0.f;
-            }
-        } else {
-            const int n = n0 + q / KQ, k = k0 + (q % KQ) * 4;
-            if (n < g.N) {
-                const long long base = (long long)n * g.ldb;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) fr.b[j][e] = (k + e < kend) ? g.B[base + k + e] : 0.f;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) fr.b[j][e] = 0.f;
-            }
-        }
+        for (int e = 0; e < 4; ++e)
+            if (c + e < limit) v[e] = p[e];
     }
+    return v;
 }
 
-// Interior tiles: no bounds checks, transform selected at compile time, all 16-byte loads in flight together.
-template <int TRANSA, int TRANSB, int MODE>
-__device__ __forceinline__ void load_tiles_fast(const GemmArgs& g, int m0, int n0, int k0, Frag& fr) {
+// Stage one 128xBK tile of A and one BKx128 tile of B into registers.  All loads are issued before any is used;
+// the transform of the previous layer is applied afterwards.  CHECK=false for interior tiles and full k-steps.
+template <int TRANSA, int TRANSB, int MODE, bool CHECK>
+__device__ __forceinline__ void load_tiles(const GemmArgs& g, int m0, int n0, int k0, Frag& fr) {
     const int tid = threadIdx.x;
     f32x4u va[NLD], vb[NLD], vm[NLD];
     int cha[NLD];
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
         const int q = tid + j * GEMM_THREADS;
-        long long offa;
         if (TRANSA == 0) {
             const int m = m0 + q / KQ, k = k0 + (q % KQ) * 4;
-            offa = rowbase(g, m) + k;
+            const bool ok = !CHECK || m < g.M;
+            const long long offa = rowbase(g, ok ? m : 0) + k;
             cha[j] = k;
+            va[j] = load4<CHECK>(g.A + offa, ok, k, g.K);
+            if (MODE == PTTS_IN_MASKMUL) vm[j] = load4<CHECK>(g.mask_src + offa, ok, k, g.K);
         } else {
             const int k = k0 + q / (BM / 4), m = m0 + (q % (BM / 4)) * 4;
-            offa = rowbase(g, k) + m;
+            const bool ok = !CHECK || k < g.K;
+            const long long offa = rowbase(g, ok ? k : 0) + m;
             cha[j] = m;
+            va[j] = load4<CHECK>(g.A + offa, ok, m, g.M);
+            if (MODE == PTTS_IN_MASKMUL) vm[j] = load4<CHECK>(g.mask_src + offa, ok, m, g.M);
         }
-        va[j] = *reinterpret_cast<const f32x4u*>(g.A + offa);
-        if (MODE == PTTS_IN_MASKMUL) vm[j] = *reinterpret_cast<const f32x4u*>(g.mask_src + offa);
         if (TRANSB == 0) {
             const int k = k0 + q / (BN / 4), n = n0 + (q % (BN / 4)) * 4;
-            vb[j] = *reinterpret_cast<const f32x4u*>(g.B + (long long)k * g.ldb + n);
+            const bool ok = !CHECK || k < g.K;
+            vb[j] = load4<CHECK>(g.B + (long long)(ok ? k : 0) * g.ldb + n, ok, n, g.N);
         } else {
             const int n = n0 + q / KQ, k = k0 + (q % KQ) * 4;
-            vb[j] = *reinterpret_cast<const f32x4u*>(g.B + (long long)n * g.ldb + k);
+            const bool ok = !CHECK || n < g.N;
+            vb[j] = load4<CHECK>(g.B + (long long)(ok ? n : 0) * g.ldb + k, ok, k, g.K);
         }
     }
 #pragma unroll
@@ -152,7 +117,10 @@ __device__ __forceinline__ void load_tiles_fast(const GemmArgs& g, int m0, int n
         for (int e = 0; e < 4; ++e) {
             float v = va[j][e];
             if (MODE == PTTS_IN_LRELU) {
-                if (g.in_scale) v = v * g.in_scale[cha[j] + e] + g.in_shift[cha[j] + e];
+                // out-of-range elements were loaded as 0 and must stay 0 after the affine: mask them
+                const int ch = cha[j] + e;
+                const bool inr = !CHECK || ch < (TRANSA == 0 ? g.K : g.M);
+                if (g.in_scale) v = inr ? v * g.in_scale[inr ? ch : 0] + g.in_shift[inr ? ch : 0] : 0.f;
                 v = lrelu(v, g.alpha);
             } else if (MODE == PTTS_IN_MASKMUL) {
                 v *= lrelu_d(vm[j][e], g.alpha);
@@ -222,8 +190,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_mfma_kernel(GemmArgs g)
 
         Frag fr;
         auto load = [&](int k0) {
-            if (interior && k0 + BK <= g.K) load_tiles_fast<TRANSA, TRANSB, MODE>(g, m0, n0, k0, fr);
-            else load_tiles<TRANSA, TRANSB>(g, m0, n0, k0, fr);
+            if (interior && k0 + BK <= g.K) load_tiles<TRANSA, TRANSB, MODE, false>(g, m0, n0, k0, fr);
+            else load_tiles<TRANSA, TRANSB, MODE, true>(g, m0, n0, k0, fr);
         };
         load(kbeg);
         store_tiles<TRANSA, TRANSB>(As[0], Bs[0], fr);
