@@ -13,6 +13,7 @@
 // dw / dbias / dscale / dshift that a second tiny kernel reduces in a fixed order
 // (deterministic, no float atomics).
 #include "common.h"
+#include <cstdlib>
 
 namespace ptts {
 
@@ -36,6 +37,12 @@ template <> struct VecIO<4> {
 
 constexpr int CONV_THREADS = 256;
 
+// v_pk_fma_f32: two fp32 FMAs per lane per issue slot -- the only way to the fp32 vector peak on gfx950.  The
+// accumulators are kept as float2 over adjacent OUTPUT channels, the activation is a broadcast (op_sel) and the
+// weight pair comes straight from an SGPR pair, so the inner loops compile to bare v_pk_fma_f32 streams.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 pkfma(float a, f2 w, f2 c) { return __builtin_elementwise_fma((f2){a, a}, w, c); }
+
 // a = transform(x) for one pixel (CIN channels)
 template <int CIN>
 __device__ __forceinline__ void in_transform(float* a, const float* __restrict__ in_scale,
@@ -57,77 +64,246 @@ __device__ __forceinline__ void in_transform(float* a, const float* __restrict__
     }
 }
 
+
+// Stage a [rows x cols] window of an NHWC tensor into LDS (zero outside the image), NB loads in flight per lane
+// before the first one is consumed (a load-wait-store loop would expose the HBM latency once per element).
+// dst[idx*C..] = transform(src[pixel]);  raw (optional) receives the untransformed values.
+template <int C, int NB>
+__device__ __forceinline__ void stage_window(const float* __restrict__ src, const float* __restrict__ mask_src,
+                                             float* __restrict__ dst, float* __restrict__ raw, long long img,
+                                             int T, int F, int rows, int cols, int t_org, int f_org,
+                                             const float* __restrict__ in_scale,
+                                             const float* __restrict__ in_shift, int in_mode, float alpha) {
+    const int total = rows * cols;
+    for (int base = threadIdx.x; base < total; base += CONV_THREADS * NB) {
+        float v[NB][C], m[NB][C];
+        bool ok[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int idx = base + u * CONV_THREADS;
+            const int r = idx / cols, c = idx - r * cols;
+            const int t = t_org + r, f = f_org + c;
+            ok[u] = idx < total && t >= 0 && t < T && f >= 0 && f < F;
+#pragma unroll
+            for (int c2 = 0; c2 < C; ++c2) { v[u][c2] = 0.f; m[u][c2] = 0.f; }
+            if (ok[u]) {
+                const long long off = (img + (long long)t * F + f) * C;
+                VecIO<C>::ld(src + off, v[u]);
+                if (in_mode == PTTS_IN_MASKMUL) VecIO<C>::ld(mask_src + off, m[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int idx = base + u * CONV_THREADS;
+            if (idx >= total) continue;
+            if (raw) VecIO<C>::st(raw + (size_t)idx * C, v[u]);
+            if (ok[u]) {
+                if (in_mode == PTTS_IN_LRELU) {
+#pragma unroll
+                    for (int c2 = 0; c2 < C; ++c2) {
+                        float p = v[u][c2];
+                        if (in_scale) p = p * in_scale[c2] + in_shift[c2];
+                        v[u][c2] = lrelu(p, alpha);
+                    }
+                } else if (in_mode == PTTS_IN_MASKMUL) {
+#pragma unroll
+                    for (int c2 = 0; c2 < C; ++c2) v[u][c2] *= lrelu_d(m[u][c2], alpha);
+                }
+            }
+            VecIO<C>::st(dst + (size_t)idx * C, v[u]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // forward
 // grid (ceil(T/TT), B), 256 threads.  LDS: [TT + (KT-1)*dil_t][Fp + KF-1][CIN] floats, Fp = ceil(F/KF)*KF
 // ------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int KT, int KF>
+// Persistent, software-pipelined: a workgroup walks tiles blockIdx.x, +gridDim.x, ...; the global loads of tile i+1
+// are issued (into registers) before the FMA phase of tile i and land in LDS after it, and the coalesced stores of
+// tile i drain while tile i+1 is computed -- without this every workgroup of the (single) wave of workgroups loads,
+// computes and stores in lock-step and HBM idles during the FMA phase.
+constexpr int NPF = 8;   // prefetch registers: up to 8 pixels per lane per tile (tile rows*cols <= 2048)
+
+template <int CIN>
+struct Prefetch {
+    float v[NPF][CIN];
+    float m[NPF][CIN];
+    unsigned okmask;
+};
+
+template <int CIN, bool MASK>
+__device__ __forceinline__ void prefetch_tile(Prefetch<CIN>& pf, const float* __restrict__ x,
+                                              const float* __restrict__ mask_src, long long img, int T, int F,
+                                              int rows, int cols, int t_org, int f_org) {
+    const int total = rows * cols;
+    pf.okmask = 0u;
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+        const int idx = threadIdx.x + u * CONV_THREADS;
+        const int r = idx / cols, c = idx - r * cols;
+        const int t = t_org + r, f = f_org + c;
+        const bool ok = idx < total && t >= 0 && t < T && f >= 0 && f < F;
+#pragma unroll
+        for (int c2 = 0; c2 < CIN; ++c2) { pf.v[u][c2] = 0.f; if (MASK) pf.m[u][c2] = 0.f; }
+        if (ok) {
+            const long long off = (img + (long long)t * F + f) * CIN;
+            VecIO<CIN>::ld(x + off, pf.v[u]);
+            if (MASK) VecIO<CIN>::ld(mask_src + off, pf.m[u]);
+            pf.okmask |= 1u << u;
+        }
+    }
+}
+
+template <int CIN, bool MASK>
+__device__ __forceinline__ void commit_tile(const Prefetch<CIN>& pf, float* __restrict__ dst, int total,
+                                            const float* __restrict__ in_scale,
+                                            const float* __restrict__ in_shift, int in_mode, float alpha) {
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+        const int idx = threadIdx.x + u * CONV_THREADS;
+        if (idx >= total) continue;
+        float a[CIN];
+#pragma unroll
+        for (int c2 = 0; c2 < CIN; ++c2) a[c2] = pf.v[u][c2];
+        if ((pf.okmask >> u) & 1u) {
+            if (MASK) {
+#pragma unroll
+                for (int c2 = 0; c2 < CIN; ++c2) a[c2] *= lrelu_d(pf.m[u][c2], alpha);
+            } else if (in_mode == PTTS_IN_LRELU) {
+#pragma unroll
+                for (int c2 = 0; c2 < CIN; ++c2) {
+                    float p = a[c2];
+                    if (in_scale) p = p * in_scale[c2] + in_shift[c2];
+                    a[c2] = lrelu(p, alpha);
+                }
+            }
+        }
+        VecIO<CIN>::st(dst + (size_t)idx * CIN, a);
+    }
+}
+
+// LDS: in-tile [TT + (KT-1)*dil_t][cols][CIN] | out-tile [TT][F][COUT]   (separate regions: the stores of tile i
+// read the out region while the in region already receives tile i+1)
+template <int CIN, int COUT, int KT, int KF, int NR, bool MASK>
 __global__ __launch_bounds__(CONV_THREADS) void conv2d_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift,
     const float* __restrict__ mask_src, float* __restrict__ y,
-    int T, int F, int TT, int dil_t, int pad_t, int in_mode, float alpha) {
+    int T, int F, int TT, int ntiles_t, int ntiles, int dil_t, int pad_t, int in_mode, float alpha) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int P = KF;                 // outputs per lane along frequency
     constexpr int PF = (KF - 1) / 2;      // 'same' padding, low side (TF: total//2)
     const int nspr = (F + P - 1) / P;     // strips per row
     const int cols = nspr * P + KF - 1;
     const int rows = TT + (KT - 1) * dil_t;
-    const int b = blockIdx.y;
-    const int t0 = blockIdx.x * TT;
-    const long long img = (long long)b * T * F;
-
-    for (int idx = threadIdx.x; idx < rows * cols; idx += CONV_THREADS) {
-        const int r = idx / cols, c = idx - r * cols;
-        const int t = t0 + r - pad_t, f = c - PF;
-        float a[CIN];
-        if (t >= 0 && t < T && f >= 0 && f < F) {
-            const long long off = (img + (long long)t * F + f) * CIN;
-            VecIO<CIN>::ld(x + off, a);
-            in_transform<CIN>(a, in_scale, in_shift, mask_src, off, in_mode, alpha);
-        } else {
-#pragma unroll
-            for (int c2 = 0; c2 < CIN; ++c2) a[c2] = 0.f;
-        }
-        VecIO<CIN>::st(smem + (size_t)idx * CIN, a);
-    }
-    __syncthreads();
-
+    float* smem_out = smem + (((size_t)rows * cols * CIN + 3) & ~(size_t)3);
     const int nstrips = TT * nspr;
-    for (int s = threadIdx.x; s < nstrips; s += CONV_THREADS) {
-        const int r = s / nspr;
-        const int fs = (s - r * nspr) * P;
-        const int t = t0 + r;
-        if (t >= T) continue;
-        float acc[P][COUT];
+    constexpr bool PK = (COUT % 2 == 0);
+    constexpr int HC = PK ? COUT / 2 : 1;
+
+    int tile = blockIdx.x;
+    Prefetch<CIN> pf;
+    if (tile < ntiles) {
+        const int b = tile / ntiles_t, t0 = (tile - b * ntiles_t) * TT;
+        prefetch_tile<CIN, MASK>(pf, x, mask_src, (long long)b * T * F, T, F, rows, cols, t0 - pad_t, -PF);
+    }
+    while (tile < ntiles) {
+        const int b = tile / ntiles_t, t0 = (tile - b * ntiles_t) * TT;
+        const long long img = (long long)b * T * F;
+        commit_tile<CIN, MASK>(pf, smem, rows * cols, in_scale, in_shift, in_mode, alpha);
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < ntiles) {
+            const int nb = next / ntiles_t, nt0 = (next - nb * ntiles_t) * TT;
+            prefetch_tile<CIN, MASK>(pf, x, mask_src, (long long)nb * T * F, T, F, rows, cols, nt0 - pad_t, -PF);
+        }
+
+        // ---- compute: NR strips per lane, advanced together so that a kernel row's weights (SGPRs) are fetched once
+        float acc[NR][P][COUT];
+        f2 acc2[NR][P][HC];
+        int sr[NR], sf[NR];
+        bool act[NR];
 #pragma unroll
-        for (int p = 0; p < P; ++p)
+        for (int q = 0; q < NR; ++q) {
+            const int s = threadIdx.x + q * CONV_THREADS;
+            const int r = s / nspr;
+            act[q] = s < nstrips && t0 + r < T;
+            sr[q] = act[q] ? r : 0;
+            sf[q] = act[q] ? (s - r * nspr) * P : 0;
 #pragma unroll
-            for (int co = 0; co < COUT; ++co) acc[p][co] = bias ? bias[co] : 0.f;
-#pragma unroll 1   // keep one kernel row (KF*CIN*COUT weights) in SGPRs at a time; full unroll spills SGPRs
-        for (int kt = 0; kt < KT; ++kt) {
-            const float* row = smem + ((size_t)(r + kt * dil_t) * cols + fs) * CIN;
+            for (int p = 0; p < P; ++p) {
 #pragma unroll
-            for (int j = 0; j < P + KF - 1; ++j) {
-                float a[CIN];
-                VecIO<CIN>::ld(row + j * CIN, a);
+                for (int co = 0; co < COUT; ++co) acc[q][p][co] = bias ? bias[co] : 0.f;
+                if (PK) {
 #pragma unroll
-                for (int kf = 0; kf < KF; ++kf) {
-                    const int p = j - kf;
-                    if (p < 0 || p >= P) continue;
-                    const float* wk = w + ((kt * KF + kf) * CIN) * COUT;
-#pragma unroll
-                    for (int ci = 0; ci < CIN; ++ci)
-#pragma unroll
-                        for (int co = 0; co < COUT; ++co)
-                            acc[p][co] = fmaf(a[ci], wk[ci * COUT + co], acc[p][co]);
+                    for (int h = 0; h < HC; ++h) acc2[q][p][h] = (f2){acc[q][p][2 * h], acc[q][p][2 * h + (PK ? 1 : 0)]};
                 }
             }
         }
-        float* yo = y + (img + (long long)t * F + fs) * COUT;
+#pragma unroll 1   // keep one kernel row (KF*CIN*COUT weights) in SGPRs at a time; full unroll spills SGPRs
+        for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
-        for (int p = 0; p < P; ++p)
-            if (fs + p < F) VecIO<COUT>::st(yo + p * COUT, acc[p]);
+            for (int q = 0; q < NR; ++q) {
+                const float* row = smem + ((size_t)(sr[q] + kt * dil_t) * cols + sf[q]) * CIN;
+#pragma unroll
+                for (int j = 0; j < P + KF - 1; ++j) {
+                    float a[CIN];
+                    VecIO<CIN>::ld(row + j * CIN, a);
+#pragma unroll
+                    for (int kf = 0; kf < KF; ++kf) {
+                        const int p = j - kf;
+                        if (p < 0 || p >= P) continue;
+                        const float* wk = w + ((kt * KF + kf) * CIN) * COUT;
+                        if (PK) {
+                            const f2* wk2 = reinterpret_cast<const f2*>(wk);
+#pragma unroll
+                            for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                                for (int h = 0; h < HC; ++h)
+                                    acc2[q][p][h] = pkfma(a[ci], wk2[ci * HC + h], acc2[q][p][h]);
+                        } else {
+#pragma unroll
+                            for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                                for (int co = 0; co < COUT; ++co)
+                                    acc[q][p][co] = fmaf(a[ci], wk[ci * COUT + co], acc[q][p][co]);
+                        }
+                    }
+                }
+            }
+        }
+        // ---- outputs go through LDS so that the global stores are whole contiguous lines (the tile's rows are one
+        //      contiguous range of y); a lane's own strip is 5 x 16 B at an 80-B stride otherwise.
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            if (!act[q]) continue;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                if (sf[q] + p >= F) continue;
+                float o[COUT];
+                if (PK) {
+#pragma unroll
+                    for (int h = 0; h < HC; ++h) { o[2 * h] = acc2[q][p][h].x; o[2 * h + (PK ? 1 : 0)] = acc2[q][p][h].y; }
+                } else {
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) o[co] = acc[q][p][co];
+                }
+                VecIO<COUT>::st(smem_out + ((size_t)sr[q] * F + sf[q] + p) * COUT, o);
+            }
+        }
+        __syncthreads();   // in-tile reads done (next commit may overwrite it); out-tile complete
+        const int nrows = min(TT, T - t0);
+        const int nout = nrows * F * COUT;
+        float* yo = y + (img + (long long)t0 * F) * COUT;
+        if ((F * COUT) % 4 == 0) {
+            for (int i = threadIdx.x * 4; i < nout; i += CONV_THREADS * 4)
+                *reinterpret_cast<float4*>(yo + i) = *reinterpret_cast<const float4*>(smem_out + i);
+        } else {
+            for (int i = threadIdx.x; i < nout; i += CONV_THREADS) yo[i] = smem_out[i];
+        }
+        tile = next;
+        // the next iteration's barrier (after commit) orders these out-tile reads before the next out-tile writes
     }
 }
 
@@ -141,6 +317,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv2d_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ w,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift,
     const float* __restrict__ mask_src, float* __restrict__ dx, float* __restrict__ partials,
+    const float* __restrict__ wt /*[KT][KF][COUT][CIN]: w transposed, for pairs over ci*/,
     int want_dx, int want_dw, int want_affine,
     int T, int F, int TT, int dil_t, int pad_t, int in_mode, float alpha) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -164,35 +341,8 @@ __global__ __launch_bounds__(CONV_THREADS) void conv2d_bwd_kernel(
     float* xt = at + (size_t)TT * Fp * CIN;
     const int tid = threadIdx.x;
 
-    for (int idx = tid; idx < rows * cols; idx += CONV_THREADS) {
-        const int r = idx / cols, c = idx - r * cols;
-        const int t = t0 + r - lo_t, f = c - LO_F;
-        float v[COUT];
-        if (t >= 0 && t < T && f >= 0 && f < F) {
-            VecIO<COUT>::ld(dy + (img + (long long)t * F + f) * COUT, v);
-        } else {
-#pragma unroll
-            for (int c2 = 0; c2 < COUT; ++c2) v[c2] = 0.f;
-        }
-        VecIO<COUT>::st(dyt + (size_t)idx * COUT, v);
-    }
-    for (int idx = tid; idx < TT * Fp; idx += CONV_THREADS) {
-        const int r = idx / Fp, f = idx - r * Fp;
-        const int t = t0 + r;
-        float a[CIN], xr[CIN];
-        if (t < T && f < F) {
-            const long long off = (img + (long long)t * F + f) * CIN;
-            VecIO<CIN>::ld(x + off, a);
-#pragma unroll
-            for (int c2 = 0; c2 < CIN; ++c2) xr[c2] = a[c2];
-            in_transform<CIN>(a, in_scale, in_shift, mask_src, off, in_mode, alpha);
-        } else {
-#pragma unroll
-            for (int c2 = 0; c2 < CIN; ++c2) { a[c2] = 0.f; xr[c2] = 0.f; }
-        }
-        VecIO<CIN>::st(at + (size_t)idx * CIN, a);
-        if (want_affine) VecIO<CIN>::st(xt + (size_t)idx * CIN, xr);
-    }
+    stage_window<COUT, 6>(dy, nullptr, dyt, nullptr, img, T, F, rows, cols, t0 - lo_t, -LO_F, nullptr, nullptr, PTTS_IN_NONE, alpha);
+    stage_window<CIN, 4>(x, mask_src, at, want_affine ? xt : nullptr, img, T, F, TT, Fp, t0, 0, in_scale, in_shift, in_mode, alpha);
     __syncthreads();
 
     // ---- phase 1: dx = conv^T(dy, w) * d(a)/d(x), plus dscale/dshift sums --------------------
@@ -206,11 +356,17 @@ __global__ __launch_bounds__(CONV_THREADS) void conv2d_bwd_kernel(
             const int fs = (s - r * nspr) * P;
             const int t = t0 + r;
             if (t >= T) continue;
+            constexpr bool PKI = (CIN % 2 == 0);
+            constexpr int HI = PKI ? CIN / 2 : 1;
             float da[P][CIN];
+            f2 da2[P][HI];
 #pragma unroll
-            for (int p = 0; p < P; ++p)
+            for (int p = 0; p < P; ++p) {
 #pragma unroll
                 for (int ci = 0; ci < CIN; ++ci) da[p][ci] = 0.f;
+#pragma unroll
+                for (int h = 0; h < HI; ++h) da2[p][h] = (f2){0.f, 0.f};
+            }
 #pragma unroll 1
             for (int kt = 0; kt < KT; ++kt) {
                 const float* row = dyt + ((size_t)(r + (KT - 1 - kt) * dil_t) * cols + fs) * COUT;
@@ -222,14 +378,31 @@ __global__ __launch_bounds__(CONV_THREADS) void conv2d_bwd_kernel(
                     for (int kf = 0; kf < KF; ++kf) {
                         const int p = j - (KF - 1 - kf);
                         if (p < 0 || p >= P) continue;
-                        const float* wk = w + ((kt * KF + kf) * CIN) * COUT;
-#pragma unroll
-                        for (int ci = 0; ci < CIN; ++ci)
+                        if (PKI) {
+                            const f2* wt2 = reinterpret_cast<const f2*>(wt + ((kt * KF + kf) * COUT) * CIN);
 #pragma unroll
                             for (int co = 0; co < COUT; ++co)
-                                da[p][ci] = fmaf(g[co], wk[ci * COUT + co], da[p][ci]);
+#pragma unroll
+                                for (int h = 0; h < HI; ++h) da2[p][h] = pkfma(g[co], wt2[co * HI + h], da2[p][h]);
+                        } else {
+                            const float* wk = w + ((kt * KF + kf) * CIN) * COUT;
+#pragma unroll
+                            for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                                for (int co = 0; co < COUT; ++co)
+                                    da[p][ci] = fmaf(g[co], wk[ci * COUT + co], da[p][ci]);
+                        }
                     }
                 }
+            }
+            if (PKI) {
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+#pragma unroll
+                    for (int h = 0; h < HI; ++h) {
+                        da[p][2 * h] = da2[p][h].x;
+                        da[p][2 * h + (PKI ? 1 : 0)] = da2[p][h].y;
+                    }
             }
             const float* arow = at + ((size_t)r * Fp + fs) * CIN;
             const float* xrow = xt + ((size_t)r * Fp + fs) * CIN;
@@ -268,11 +441,17 @@ __global__ __launch_bounds__(CONV_THREADS) void conv2d_bwd_kernel(
     // ---- phase 2: dw partials.  lane role = (kt, ci); it owns acc[kf][co] and marches along f ----
     constexpr int NROLE = KT * CIN;
     constexpr int NGRP = CONV_THREADS / NROLE;
+    constexpr bool PKO = (COUT % 2 == 0);
+    constexpr int HO = PKO ? COUT / 2 : 1;
     float accw[KF][COUT];
+    f2 accw2[KF][HO];
 #pragma unroll
-    for (int kf = 0; kf < KF; ++kf)
+    for (int kf = 0; kf < KF; ++kf) {
 #pragma unroll
         for (int co = 0; co < COUT; ++co) accw[kf][co] = 0.f;
+#pragma unroll
+        for (int h = 0; h < HO; ++h) accw2[kf][h] = (f2){0.f, 0.f};
+    }
     const int grp = tid / NROLE;
     const int role = tid - grp * NROLE;
     const int rkt = role / CIN, rci = role - rkt * CIN;
@@ -295,13 +474,28 @@ __global__ __launch_bounds__(CONV_THREADS) void conv2d_bwd_kernel(
                     for (int kf = 0; kf < KF; ++kf) {
                         // dy column fq + (KF-1-kf) lives in slot (u + KF-1-kf) % KF
                         const int slot = (u + KF - 1 - kf) % KF;
+                        if (PKO) {
 #pragma unroll
-                        for (int co = 0; co < COUT; ++co)
-                            accw[kf][co] = fmaf(av, win[slot][co], accw[kf][co]);
+                            for (int h = 0; h < HO; ++h)
+                                accw2[kf][h] = pkfma(av, (f2){win[slot][2 * h], win[slot][2 * h + (PKO ? 1 : 0)]}, accw2[kf][h]);
+                        } else {
+#pragma unroll
+                            for (int co = 0; co < COUT; ++co)
+                                accw[kf][co] = fmaf(av, win[slot][co], accw[kf][co]);
+                        }
                     }
                 }
             }
         }
+    }
+    if (PKO) {
+#pragma unroll
+        for (int kf = 0; kf < KF; ++kf)
+#pragma unroll
+            for (int h = 0; h < HO; ++h) {
+                accw[kf][2 * h] = accw2[kf][h].x;
+                accw[kf][2 * h + (PKO ? 1 : 0)] = accw2[kf][h].y;
+            }
     }
     // ---- phase 3: dbias partial (sum of dy over the pixels this block owns) -------------------
     float s_b[COUT];
@@ -360,6 +554,15 @@ __global__ __launch_bounds__(CONV_THREADS) void conv2d_bwd_kernel(
 #pragma unroll
         for (int wv = 0; wv < CONV_THREADS / 64; ++wv) s += red2[wv * (COUT + 2 * CIN) + tid];
         out[NW + tid] = s;
+    }
+}
+
+// wt[tap][co][ci] = w[tap][ci][co]
+__global__ void transpose_w_kernel(const float* __restrict__ w, float* __restrict__ wt, int ntaps, int cin, int cout) {
+    const int n = ntaps * cin * cout;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int ci = i % cin, co = (i / cin) % cout, tap = i / (cin * cout);
+        wt[i] = w[(tap * cin + ci) * cout + co];
     }
 }
 
@@ -537,7 +740,17 @@ __global__ __launch_bounds__(256) void conv2d_bwd_w_generic(
 // ------------------------------------------------------------------------------------------
 // host side: tile choice + dispatch
 // ------------------------------------------------------------------------------------------
-constexpr size_t LDS_BUDGET = 64 * 1024;   // keep >= 2 workgroups per CU (160 KiB LDS)
+// LDS per workgroup bounds the tile height; PTTS_CONV_LDS_KB overrides it (tuning knob).
+static size_t lds_budget() {
+    static size_t v = 0;
+    if (!v) {
+        const char* e = getenv("PTTS_CONV_LDS_KB");
+        v = (size_t)(e ? atoi(e) : 48) * 1024;
+        if (v < 8 * 1024) v = 8 * 1024;
+        if (v > 150 * 1024) v = 150 * 1024;
+    }
+    return v;
+}
 
 struct Tile { int TT; int ntiles; };
 
@@ -551,7 +764,7 @@ static Tile pick_tile(int T, int F, int KT, int KF, int dil_t, size_t bytes_per_
     double best_score = -1.0;
     for (int TT = 4; TT <= 128; ++TT) {
         const size_t lds = (size_t)TT * bytes_per_row_fixed + (size_t)(TT + halo) * bytes_per_halo_row;
-        if (lds > LDS_BUDGET && best.TT > 0) break;
+        if (lds > lds_budget() && best.TT > 0) break;
         const int ntiles = (T + TT - 1) / TT;
         const int strips = TT * nspr;
         const int rounds = (strips + CONV_THREADS - 1) / CONV_THREADS;
@@ -559,6 +772,27 @@ static Tile pick_tile(int T, int F, int KT, int KF, int dil_t, size_t bytes_per_
         const double row_eff = (double)T / ((double)ntiles * TT);
         const double halo_eff = (double)TT / (TT + halo);
         const double score = lane_eff * row_eff * (0.75 + 0.25 * halo_eff);
+        if (score > best_score + 1e-9) { best_score = score; best = Tile{TT, ntiles}; }
+    }
+    return best;
+}
+
+// Forward tile: rows*cols must fit the prefetch registers (NPF pixels per lane); maximise lane use x row use.
+static Tile pick_tile_fwd(int T, int F, int KT, int KF, int dil_t, int cols) {
+    const int nspr = (F + KF - 1) / KF;
+    const int halo = (KT - 1) * dil_t;
+    Tile best{0, 0};
+    double best_score = -1.0;
+    for (int TT = 1; TT <= 128; ++TT) {
+        if ((TT + halo) * cols > NPF * CONV_THREADS) break;
+        const int strips = TT * nspr;
+        const int rounds = (strips + CONV_THREADS - 1) / CONV_THREADS;
+        if (rounds > 2) break;
+        const int ntiles = (T + TT - 1) / TT;
+        const double lane_eff = (double)strips / (rounds * CONV_THREADS);
+        const double row_eff = (double)T / ((double)ntiles * TT);
+        const double halo_eff = (double)TT / (TT + halo);
+        const double score = lane_eff * row_eff * (0.6 + 0.4 * halo_eff);
         if (score > best_score + 1e-9) { best_score = score; best = Tile{TT, ntiles}; }
     }
     return best;
@@ -599,21 +833,33 @@ extern "C" int ptts_conv2d_fwd(const float* x, const float* w, const float* bias
     PTTS_REQUIRE(B <= 65535, "conv2d_fwd: B too large");
     hipStream_t st = (hipStream_t)stream;
     const ConvGeom g = geom(KT, dil_t, pad_mode);
+#define FWD_LAUNCH(CI, CO, KTT, KFF, NRR, MK)                                                           \
+    hipLaunchKernelGGL((conv2d_fwd_kernel<CI, CO, KTT, KFF, NRR, MK>), dim3(grid), dim3(CONV_THREADS), lds, \
+                       st, x, w, bias, in_scale, in_shift, mask_src, y, T, F, tl.TT, tl.ntiles,             \
+                       tl.ntiles * B, dil_t, g.pad_t, in_mode, alpha)
 #define FWD_CASE(CI, CO, KTT, KFF)                                                                       \
     if (Cin == CI && Cout == CO && KT == KTT && KF == KFF) {                                             \
         const int nspr = (F + KFF - 1) / KFF;                                                            \
-        const size_t rowb = (size_t)(nspr * KFF + KFF - 1) * CI * sizeof(float);                         \
-        const Tile tl = pick_tile(T, F, KTT, KFF, dil_t, 0, rowb);                                       \
-        const size_t lds = (size_t)(tl.TT + (KTT - 1) * dil_t) * rowb;                                   \
-        if (lds <= 160 * 1024 - 256) {                                                                   \
-            hipLaunchKernelGGL((conv2d_fwd_kernel<CI, CO, KTT, KFF>), dim3(tl.ntiles, B), dim3(CONV_THREADS), \
-                               lds, st, x, w, bias, in_scale, in_shift, mask_src, y, T, F, tl.TT, dil_t, \
-                               g.pad_t, in_mode, alpha);                                                 \
+        const int cols = nspr * KFF + KFF - 1;                                                           \
+        const Tile tl = pick_tile_fwd(T, F, KTT, KFF, dil_t, cols);                                      \
+        const int rows = tl.TT + (KTT - 1) * dil_t;                                                      \
+        const size_t in_fl = ((size_t)rows * cols * CI + 3) & ~(size_t)3;                                \
+        const size_t lds = (in_fl + (size_t)tl.TT * F * CO) * sizeof(float);                             \
+        const int nr = (tl.TT * nspr + CONV_THREADS - 1) / CONV_THREADS;                                 \
+        if (tl.TT > 0 && lds <= 150 * 1024 && nr <= 2 && rows * cols <= NPF * CONV_THREADS) {            \
+            int per_cu = (int)((150 * 1024) / lds);                                                      \
+            if (per_cu > 4) per_cu = 4;                                                                  \
+            long long grid = (long long)tl.ntiles * B;                                                   \
+            if (grid > 256LL * per_cu) grid = 256LL * per_cu;                                            \
+            const bool mk = in_mode == PTTS_IN_MASKMUL;                                                  \
+            if (nr == 1) { if (mk) FWD_LAUNCH(CI, CO, KTT, KFF, 1, true); else FWD_LAUNCH(CI, CO, KTT, KFF, 1, false); } \
+            else { if (mk) FWD_LAUNCH(CI, CO, KTT, KFF, 2, true); else FWD_LAUNCH(CI, CO, KTT, KFF, 2, false); }         \
             return check_launch("conv2d_fwd");                                                           \
         }                                                                                                \
     }
     PTTS_CONV_CASES(FWD_CASE)
 #undef FWD_CASE
+#undef FWD_LAUNCH
     const long long total = (long long)B * T * F * Cout;
     const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
     hipLaunchKernelGGL(conv2d_fwd_generic, dim3(blocks), dim3(256), 0, st, x, w, bias, in_scale, in_shift,
@@ -622,6 +868,7 @@ extern "C" int ptts_conv2d_fwd(const float* x, const float* w, const float* bias
 }
 
 namespace {
+constexpr size_t WT_BYTES = 4096;   // head of the workspace: transposed weights for the packed dx loop
 struct BwdPlan { bool fast; Tile tl; size_t lds; int npart; };
 template <int CI, int CO, int KTT, int KFF>
 BwdPlan plan_bwd(int T, int F, int dil_t) {
@@ -647,7 +894,7 @@ extern "C" size_t ptts_conv2d_bwd_workspace_bytes(int B, int T, int F, int Cin, 
 #define WS_CASE(CI, CO, KTT, KFF)                                                      \
     if (Cin == CI && Cout == CO && KT == KTT && KF == KFF) {                           \
         const BwdPlan p = plan_bwd<CI, CO, KTT, KFF>(T, F, dil_t);                     \
-        if (p.fast) return (size_t)B * p.tl.ntiles * p.npart * sizeof(float);          \
+        if (p.fast) return WT_BYTES + (size_t)B * p.tl.ntiles * p.npart * sizeof(float); \
     }
     PTTS_CONV_CASES(WS_CASE)
 #undef WS_CASE
@@ -668,7 +915,6 @@ extern "C" int ptts_conv2d_bwd(const float* dy, const float* x, const float* w, 
     PTTS_REQUIRE(!(in_mode == PTTS_IN_MASKMUL && dx), "conv2d_bwd: dx is not defined for MASKMUL (weight-only sweep)");
     PTTS_REQUIRE((dscale == nullptr) == (dshift == nullptr), "conv2d_bwd: dscale/dshift must come together");
     PTTS_REQUIRE(!dscale || (in_mode == PTTS_IN_LRELU && in_scale), "conv2d_bwd: dscale needs LRELU with scale/shift");
-    PTTS_REQUIRE((dw == nullptr) || true, "");
     PTTS_REQUIRE(B <= 65535, "conv2d_bwd: B too large");
     hipStream_t st = (hipStream_t)stream;
     const ConvGeom g = geom(KT, dil_t, pad_mode);
@@ -679,20 +925,24 @@ extern "C" int ptts_conv2d_bwd(const float* dy, const float* x, const float* w, 
         const BwdPlan p = plan_bwd<CI, CO, KTT, KFF>(T, F, dil_t);                                         \
         if (p.fast) {                                                                                      \
             const int nblocks = B * p.tl.ntiles;                                                           \
-            const size_t need = (size_t)nblocks * p.npart * sizeof(float);                                 \
-            if ((want_dw || want_aff) && (!workspace || workspace_bytes < need)) {                         \
+            const size_t need = WT_BYTES + (size_t)nblocks * p.npart * sizeof(float);                      \
+            if (!workspace || workspace_bytes < need) {                                                    \
                 set_error("conv2d_bwd: workspace %zu < %zu", workspace_bytes, need);                       \
                 return PTTS_EWORKSPACE;                                                                    \
             }                                                                                              \
+            float* wt = (float*)workspace;                                                                 \
+            float* parts = (float*)((char*)workspace + WT_BYTES);                                          \
+            if ((want_dx || want_aff) && (CI % 2 == 0))                                                    \
+                hipLaunchKernelGGL(transpose_w_kernel, dim3(2), dim3(256), 0, st, w, wt, KTT * KFF, CI, CO);\
             hipLaunchKernelGGL((conv2d_bwd_kernel<CI, CO, KTT, KFF>), dim3(p.tl.ntiles, B),                \
                                dim3(CONV_THREADS), p.lds, st, dy, x, w, in_scale, in_shift, mask_src, dx,  \
-                               (float*)workspace, want_dx, want_dw, want_aff, T, F, p.tl.TT, dil_t,        \
+                               parts, (const float*)wt, want_dx, want_dw, want_aff, T, F, p.tl.TT, dil_t,  \
                                g.pad_t, in_mode, alpha);                                                   \
             int rc = check_launch("conv2d_bwd");                                                           \
             if (rc) return rc;                                                                             \
             if (want_dw || want_aff) {                                                                     \
                 hipLaunchKernelGGL(reduce_partials_kernel, dim3(p.npart), dim3(256), 0, st,                \
-                                   (const float*)workspace, nblocks, p.npart, want_dw ? dw : nullptr,      \
+                                   (const float*)parts, nblocks, p.npart, want_dw ? dw : nullptr,          \
                                    KTT * KFF * CI * CO, want_dw ? dbias : nullptr, CO, dscale, dshift, CI);\
                 rc = check_launch("conv2d_bwd_reduce");                                                    \
             }                                                                                              \
