@@ -279,7 +279,8 @@ extern "C" int ptts_gemm(const float* A, const float* Bm, const float* bias, flo
     const long long slots = 512;
     const double eff_dp = (double)tiles / (double)(((tiles + slots - 1) / slots) * slots);
     long long workers;
-    if (g.ksteps >= 64 && eff_dp < 0.9) {
+    // (atomic combination makes the last bits order-dependent: it is kept for the deep products only, K >= 4096)
+    if (g.ksteps >= 256 && eff_dp < 0.9) {
         workers = slots;
         if (workers > g.iters_total / 8) workers = g.iters_total / 8;
         if (workers < 1) workers = 1;
