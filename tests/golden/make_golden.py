@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 from oracle import percival_oracle as O   # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-torch.set_default_dtype(torch.float64)
+torch.set_default_dtype(torch.float64)   # this script runs as its own process
 
 
 def r32(t):

@@ -43,7 +43,8 @@ def test_oracle_reproduces_conv2d_vectors():
             np.testing.assert_allclose(x.grad.numpy(), d[p + 'dx'], rtol=1e-10, atol=1e-12)
             np.testing.assert_allclose(w.grad.numpy(), d[p + 'dw'], rtol=1e-10, atol=1e-12)
             # independent check of the stored forward with the numpy loop restatement
-            ref = O.np_conv2d_same(np.where(d[p + 'x'] > 0, d[p + 'x'], 0.3 * d[p + 'x']).astype(np.float64),
+            x64 = d[p + 'x'].astype(np.float64)
+            ref = O.np_conv2d_same(np.where(x64 > 0, x64, 0.3 * x64),
                                    d[p + 'w'].astype(np.float64), d[p + 'b'].astype(np.float64))
             np.testing.assert_allclose(d[p + 'y'], ref, rtol=1e-10, atol=1e-12)
 

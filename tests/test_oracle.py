@@ -7,7 +7,7 @@ import torch
 
 from oracle import percival_oracle as O
 
-torch.set_default_dtype(torch.float64)
+F64 = torch.float64   # explicit everywhere: a process-wide default dtype would leak into the GPU tests
 
 
 def test_count_params_known_answers():
@@ -64,14 +64,14 @@ def test_bn_and_adam_match_numpy():
     x = rng.randn(4, 6, 3)
     g, bt = rng.rand(3) + 0.5, rng.randn(3)
     ref, mean, var = O.np_bn_train(x, g, bt)
-    mm, mv = torch.zeros(3), torch.ones(3)
+    mm, mv = torch.zeros(3, dtype=F64), torch.ones(3, dtype=F64)
     got = O.BN(torch.tensor(g), torch.tensor(bt), mm, mv)(torch.tensor(x), True, update=True).numpy()
     np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(mm.numpy(), 0.01 * mean, rtol=1e-12)
     np.testing.assert_allclose(mv.numpy(), 0.99 + 0.01 * var, rtol=1e-12)
     p, gr = rng.randn(10), rng.randn(10)
     m, v = np.zeros(10), np.zeros(10)
-    pt, mt, vt = torch.tensor(p.copy()), torch.zeros(10), torch.zeros(10)
+    pt, mt, vt = torch.tensor(p.copy()), torch.zeros(10, dtype=F64), torch.zeros(10, dtype=F64)
     for t in (1, 2, 3):
         p, m, v = O.np_adam_keras(p, gr, m, v, t, 1e-3, 0.5, 0.9, 1e-7)
         O.adam_keras([pt], [torch.tensor(gr)], [mt], [vt], t, 1e-3, 0.5, 0.9, 1e-7)
@@ -84,9 +84,9 @@ def _tiny():
     cw = O.random_weights(O.critic_weight_shapes(a), seed=1)
     gw = O.random_weights(O.generator_weight_shapes(a), seed=2)
     g = torch.Generator().manual_seed(3)
-    X = torch.rand(2, 8, 11, generator=g) * 2 - 1
-    Y = torch.randn(2, 8, a.outsize, generator=g)
-    al = torch.rand(2, generator=g)
+    X = torch.rand(2, 8, 11, generator=g, dtype=F64) * 2 - 1
+    Y = torch.randn(2, 8, a.outsize, generator=g, dtype=F64)
+    al = torch.rand(2, generator=g, dtype=F64)
     return a, cw, gw, X, Y, al
 
 
