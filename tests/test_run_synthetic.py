@@ -1,0 +1,48 @@
+"""End-to-end counterpart of the reference's tests/test_run.py:10-42 on the MI355X: the run.py-shaped script with the
+same shrunk configuration (batch 2, hidden 4, 1 conv layer, <=10 epochs) over a synthetic corpus of [T,425] -> [T,163]
+files, through OptimizerTTSWGAN.train (epoch loop, validation costs, checkpoints), then --continue and generate."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_run_training_continue_generate(tmp_path, monkeypatch):
+    monkeypatch.setenv('PERCIVAL_CORPUS', str(tmp_path / 'corpus'))
+    monkeypatch.chdir(tmp_path)
+    import importlib
+    import percivaltts_amd.run as run
+    run = importlib.reload(run)
+
+    print('Overwrite the configuration to run a smoke test')   # tests/test_run.py:24-35
+    run.cfg.id_valid_start = 8
+    run.cfg.id_valid_nb = 1
+    run.cfg.id_test_nb = 1
+    run.cfg.train_min_nbepochs = 1
+    run.cfg.train_max_nbepochs = 4
+    run.cfg.train_cancel_nodecepochs = 3
+    run.cfg.train_nbepochs_scalewdata = False
+    run.cfg.train_batch_size = 2
+    run.cfg.arch_hiddenwidth = 4
+    run.cfg.arch_gen_nbcnnlayers = 1
+    run.cfg.train_batch_lengthmax = 60
+    run.synthesize_corpus(nfiles=10, minlen=90, maxlen=140)
+
+    run.training(cont=False)
+    stem = 'model'
+    for f in ('model.h5.arch.json', 'model.h5.weights.npz', 'model.h5.cfgextras.pkl', stem + '-last.h5.weights.npz',
+              stem + '-trainingstate-last.h5.generator.optimizer.npz', stem + '-trainingstate-last.h5.critic.optimizer.npz',
+              stem + '-trainingstate-last.h5.critic.weights.npz', stem + '-trainingstate-last.h5.model.cfgextras.pkl'):
+        assert os.path.exists(f), f
+
+    run.cfg.train_max_nbepochs = 6
+    run.training(cont=True)            # resumes at epoch 5 from the saved state
+    run.generate()
+    outs = glob.glob('model-gen/*.cmp')
+    assert len(outs) == 1
+    y = np.fromfile(outs[0], dtype=np.float32).reshape(-1, 163)
+    assert y.shape[0] >= 90 and np.isfinite(y).all()
+    assert (y[:, 130:] > 0).all() and (y[:, 130:] < 1).all()     # sigmoid noise-mask head
