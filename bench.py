@@ -41,7 +41,7 @@ def parse():
     ap.add_argument('--no-prune', action='store_true', help="also run G's f0/noise branches in the critic step")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--cpu-batch', type=int, default=2)
+    ap.add_argument('--cpu-batch', type=int, default=32)
     return ap.parse_args()
 
 
@@ -75,8 +75,14 @@ def cpu_baseline(args, cfg_dims):
     """The oracle, fp32, all host cores, one cycle (5 critic steps + 1 generator step) at a reduced batch."""
     import torch
     from oracle import percival_oracle as O
-    ncores = os.cpu_count() or 1
+    # the GPU box gives one job a share of the host (16 cores per GPU): more threads than that only contend
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    ncores = max(1, min(16, avail))
     torch.set_num_threads(ncores)
+    print('[bench] cpu_baseline: oracle on {} threads ...'.format(ncores), file=sys.stderr, flush=True)
     ctx, spec, nm = cfg_dims
     a = O.Arch(ctx, spec, nm)
     B, T = args.cpu_batch, args.frames
@@ -105,6 +111,7 @@ def cpu_baseline(args, cfg_dims):
         grads = torch.autograd.grad(total, cw)
         for w in cw: w.requires_grad_(False)
         O.adam_keras(cw, grads, cm, cv, k + 1, 1e-4, 0.5, 0.9)
+        print('[bench] cpu_baseline: critic step {}/5 at {:.1f} s'.format(k + 1, time.time() - t0), file=sys.stderr, flush=True)
     for i in train_idx: gw[i].requires_grad_(True)
     lt, _ = O.generator_step_loss(cw, gw, a, X, Y, 'WLSWGAN', w_ls, ww)
     gg = torch.autograd.grad(lt, [gw[i] for i in train_idx], allow_unused=True)

@@ -1,0 +1,58 @@
+"""Summarise gpurun_out/prof_<tag>/ (made by tools/profile_round.sh) into profiles/<tag>_*: the rocprofv3
+--kernel-trace --stats table of the default bench command, and HBM traffic per launch of the dominant kernels from
+the separate FETCH_SIZE / WRITE_SIZE PMC passes (gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE counts half the
+bytes of a wide coalesced read -> x2; counters are in KiB)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+src = os.path.join('gpurun_out', 'prof_' + tag)
+os.makedirs('profiles', exist_ok=True)
+
+
+def short(name):
+    name = name.replace('void ', '').replace('ptts::', '')
+    return name.split('(')[0][:70]
+
+
+rows = list(csv.DictReader(open(glob.glob(src + '/trace/runc/*_kernel_stats.csv')[0])))
+total = sum(float(r['TotalDurationNs']) for r in rows)
+lines = ['# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline   (round %s)' % tag,
+         '# total kernel time %.1f ms' % (total / 1e6),
+         '%8s %12s %11s %11s %11s %6s  %s' % ('calls', 'total_us', 'avg_us', 'min_us', 'max_us', '%', 'kernel')]
+for r in rows[:40]:
+    lines.append('%8s %12.1f %11.1f %11.1f %11.1f %6.2f  %s' % (r['Calls'], float(r['TotalDurationNs']) / 1e3, float(r['AverageNs']) / 1e3,
+                 float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3, float(r['Percentage']), short(r['Name'])))
+open('profiles/%s_kernel_stats.txt' % tag, 'w').write('\n'.join(lines) + '\n')
+bench = open(src + '/bench.json').read().strip()
+open('profiles/%s_bench_under_rocprof.json' % tag, 'w').write(bench + '\n')
+
+
+def pmc(dirname, counter):
+    f = glob.glob(src + '/' + dirname + '/runc/*_counter_collection.csv')
+    out = {}
+    if not f:
+        return out
+    for r in csv.DictReader(open(f[0])):
+        if r['Counter_Name'] != counter:
+            continue
+        out.setdefault(short(r['Kernel_Name']), []).append(float(r['Counter_Value']))
+    return out
+
+
+traffic = {}
+for fdir, wdir in (('pmc_fetch', 'pmc_write'), ('pmc_fetch_conv', 'pmc_write_conv')):
+    fe, wr = pmc(fdir, 'FETCH_SIZE'), pmc(wdir, 'WRITE_SIZE')
+    for k in fe:
+        if not ('gemm' in k or 'conv2d' in k):
+            continue
+        f_kib = sum(fe[k]) / len(fe[k])
+        w_kib = sum(wr.get(k, [0.0])) / max(1, len(wr.get(k, [0.0])))
+        traffic[k] = {'fetch_bytes_raw': f_kib * 1024, 'fetch_bytes_corrected_x2': 2 * f_kib * 1024, 'write_bytes': w_kib * 1024,
+                      'hbm_bytes_per_launch': (2 * f_kib + w_kib) * 1024, 'launches_averaged': len(fe[k])}
+json.dump(traffic, open('profiles/%s_traffic.json' % tag, 'w'), indent=1, sort_keys=True)
+print(open('profiles/%s_kernel_stats.txt' % tag).read()[:3500])
+print(json.dumps(traffic, indent=1)[:3000])
