@@ -182,6 +182,19 @@ def roofline_leg(opt, X, Y, args):
                                   'frac': alg_bytes / t_conv2d / 1e9 / PEAK_HBM_GBPS, 'traffic': None,
                                   'algorithmic_bytes_per_critic_step': alg_bytes, 'time_ms': t_conv2d * 1e3}
     out['critic_step_kernel_ms'] = {k: round(v, 4) for k, v in sorted(classes.items(), key=lambda kv: -kv[1])}
+    # HBM(+Infinity-Cache) bytes per launch from the separate rocprofv3 PMC passes of the same kernels
+    # (tools/profile_round.sh -> tools/summarize_profiles.py -> profiles/<round>_traffic.json; FETCH_SIZE x2 + WRITE_SIZE)
+    try:
+        cands = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_traffic.json'))
+        if cands and B == 64 and T == 400 and X.shape[2] == 601:
+            tr = json.load(open(os.path.join(ROOT, 'profiles', cands[-1])))
+            if 'roofline' in out and 'gemm_f32_mfma_kernel<0, 0, 1, 0>' in tr:
+                out['roofline']['traffic'] = tr['gemm_f32_mfma_kernel<0, 0, 1, 0>']['hbm_bytes_per_launch']
+                out['roofline']['traffic_source'] = 'profiles/' + cands[-1]
+            if 'roofline_conv2d' in out and 'conv2d_fwd_kernel<4, 4, 5, 5, 1, false>' in tr:
+                out['roofline_conv2d']['traffic_fwd_4to4_per_launch'] = tr['conv2d_fwd_kernel<4, 4, 5, 5, 1, false>']['hbm_bytes_per_launch']
+    except (OSError, ValueError, KeyError):
+        pass
     return out
 
 

@@ -188,7 +188,9 @@ int ptts_adam_keras_step(float* p, const float* g, float* m, float* v, long long
  *   h_out [B,T,ndir*H] (the Bidirectional concat layout), gates (post-nonlinearity) [B,T,ndir*4H]
  *   and cell states c_out [B,T,ndir*H] are kept for the backward.
  * ------------------------------------------------------------------------------------- */
+size_t ptts_lstm_fwd_workspace_bytes(int B, int T, int H, int ndir);   /* packed recurrent kernel */
 int ptts_lstm_fwd(const float* xproj, const float* U, float* h_out, float* gates, float* c_out,
+                  void* workspace, size_t workspace_bytes,
                   int B, int T, int H, int ndir, int reverse, void* stream);
 /* dgates [B,T,ndir*4H] out: gradients w.r.t. the gate PRE-activations; dW, dU, db and dx follow from
  * them as ptts_gemm products.  workspace: ptts_lstm_bwd_workspace_bytes */

@@ -43,7 +43,8 @@ SIGNATURES = {
     'ptts_wlse_bwd': (c_i, [c_p] * 5 + [c_ll, c_i, c_p]),
     'ptts_weight_clip': (c_i, [c_p, c_ll, c_f, c_f, c_p]),
     'ptts_adam_keras_step': (c_i, [c_p] * 4 + [c_ll] + [c_f] * 5 + [c_p, c_p]),
-    'ptts_lstm_fwd': (c_i, [c_p] * 5 + [c_i] * 5 + [c_p]),
+    'ptts_lstm_fwd_workspace_bytes': (c_sz, [c_i] * 4),
+    'ptts_lstm_fwd': (c_i, [c_p] * 5 + [c_p, c_sz] + [c_i] * 5 + [c_p]),
     'ptts_lstm_bwd_workspace_bytes': (c_sz, [c_i] * 4),
     'ptts_lstm_bwd': (c_i, [c_p] * 5 + [c_p, c_sz] + [c_i] * 5 + [c_p]),
 }

@@ -270,18 +270,219 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_mfma_kernel(
     dc_state[si] = dc * gf;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Packed-operand MFMA step kernels (H % 64 == 0): the recurrent kernel is re-laid once per call so that every
+// lane's MFMA B operands of all k-steps are contiguous (16-byte loads, whole lines per wave), the k index of step
+// `st` for lane group q is  k = wave*(K/4) + q*KS + st  so the lane's A operands (h / dgates rows) are contiguous
+// too, and every global load of a step (operands AND the gate inputs of the epilogue) is issued before the first
+// wait.  The step is latency-bound: this cuts it to one exposed L2 round trip.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+
+// Upk[d][jt][w][lane][st][2] = { U[d][k][gate(i|f) col], U[d][k][gate(c|o) col] },  k = w*H/4 + q*KS + st
+__global__ void lstm_pack_u_fwd_kernel(const float* __restrict__ U, float* __restrict__ Upk, int H, int ndir) {
+    const int KS = H / 16, JT = H / 8;
+    const long long total = (long long)ndir * JT * 4 * 64 * KS * 2;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long r = i;
+        const int e = (int)(r % 2); r /= 2;
+        const int st = (int)(r % KS); r /= KS;
+        const int lane = (int)(r % 64); r /= 64;
+        const int w = (int)(r % 4); r /= 4;
+        const int jt = (int)(r % JT);
+        const int d = (int)(r / JT);
+        const int r16 = lane & 15, q = lane >> 4;
+        const int k = w * (H / 4) + q * KS + st;
+        const int col = ((e == 0 ? 0 : 2) + (r16 >> 3)) * H + jt * 8 + (r16 & 7);
+        Upk[i] = U[((long long)d * H + k) * 4 * H + col];
+    }
+}
+
+// UTpk[d][jt][w][lane][st] = U[d][jt*16 + r16][n],  n = w*H + q*(H/4) + st
+__global__ void lstm_pack_u_bwd_kernel(const float* __restrict__ U, float* __restrict__ UTpk, int H, int ndir) {
+    const int NS = H / 4, JT = H / 16;
+    const long long total = (long long)ndir * JT * 4 * 64 * NS;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long r = i;
+        const int st = (int)(r % NS); r /= NS;
+        const int lane = (int)(r % 64); r /= 64;
+        const int w = (int)(r % 4); r /= 4;
+        const int jt = (int)(r % JT);
+        const int d = (int)(r / JT);
+        const int r16 = lane & 15, q = lane >> 4;
+        const int n = w * H + q * NS + st;
+        UTpk[i] = U[((long long)d * H + jt * 16 + r16) * 4 * H + n];
+    }
+}
+
+template <int CH>   // k-steps per register chunk (4, 8 or 16)
+__global__ __launch_bounds__(256) void lstm_fwd_step_pk_kernel(
+    const float* __restrict__ xproj, const float* __restrict__ Upk, float* __restrict__ h_out,
+    float* __restrict__ gates, float* __restrict__ c_out, int B, int T, int H, int ndir, int reverse, int s) {
+    __shared__ float red[4][2][256];
+    const int d = blockIdx.z;
+    const bool rev = ndir == 2 ? d == 1 : reverse != 0;
+    const int t = rev ? T - 1 - s : s;
+    const int tp = rev ? t + 1 : t - 1;
+    const int jt = blockIdx.x, j0 = jt * 8, b0 = blockIdx.y * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const long long G4 = 4LL * H, HH = (long long)ndir * H;
+    const int KS = H / 16;
+    // epilogue inputs first: their latency overlaps everything else
+    const int bb = tid >> 3, jj = tid & 7;
+    const int eb = b0 + bb, ej = j0 + jj;
+    const bool epi = tid < 128 && eb < B;
+    float xv[4] = {0.f, 0.f, 0.f, 0.f}, cp = 0.f;
+    if (epi) {
+        const float* xp = xproj + (((long long)eb * T + t) * ndir + d) * G4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xv[g] = xp[g * H + ej];
+        if (s > 0) cp = c_out[((long long)eb * T + tp) * HH + (long long)d * H + ej];
+    }
+    if (s > 0) {
+        const int b = b0 + r16;
+        const float* hp = h_out + ((long long)(b < B ? b : 0) * T + tp) * HH + (long long)d * H + wave * (H / 4) + q * KS;
+        const float* up = Upk + ((((long long)d * (H / 8) + jt) * 4 + wave) * 64 + lane) * KS * 2;
+        f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 0; s0 < KS; s0 += CH) {
+            f32x4a hv[CH / 4], uv[CH / 2];
+#pragma unroll
+            for (int i = 0; i < CH / 4; ++i) hv[i] = *reinterpret_cast<const f32x4a*>(hp + s0 + 4 * i);
+#pragma unroll
+            for (int i = 0; i < CH / 2; ++i) uv[i] = *reinterpret_cast<const f32x4a*>(up + 2 * s0 + 4 * i);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const float a = b < B ? hv[i / 4][i % 4] : 0.f;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, uv[i / 2][(i % 2) * 2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, uv[i / 2][(i % 2) * 2 + 1], acc1, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            red[wave][0][(q * 4 + r) * 16 + r16] = acc0[r];
+            red[wave][1][(q * 4 + r) * 16 + r16] = acc1[r];
+        }
+        __syncthreads();
+    }
+    if (!epi) return;
+    float a4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float v = xv[g];
+        if (s > 0) {
+            const int idx = bb * 16 + (g & 1) * 8 + jj;
+            v += red[0][g >> 1][idx] + red[1][g >> 1][idx] + red[2][g >> 1][idx] + red[3][g >> 1][idx];
+        }
+        a4[g] = v;
+    }
+    const float gi = sigmoidf_(a4[0]), gf = sigmoidf_(a4[1]), gc = tanhf(a4[2]), go = sigmoidf_(a4[3]);
+    const long long so = ((long long)eb * T + t) * HH + (long long)d * H + ej;
+    const float c = gf * cp + gi * gc;
+    c_out[so] = c;
+    h_out[so] = go * tanhf(c);
+    float* gp = gates + (((long long)eb * T + t) * ndir + d) * G4;
+    gp[ej] = gi; gp[H + ej] = gf; gp[2 * H + ej] = gc; gp[3 * H + ej] = go;
+}
+
+__global__ __launch_bounds__(256) void lstm_bwd_step_pk_kernel(
+    const float* __restrict__ dh_out, const float* __restrict__ UTpk, const float* __restrict__ gates,
+    const float* __restrict__ c_out, float* __restrict__ dgates, float* __restrict__ dc_state, int B, int T,
+    int H, int ndir, int reverse, int s) {
+    __shared__ float red[4][256];
+    const int d = blockIdx.z;
+    const bool rev = ndir == 2 ? d == 1 : reverse != 0;
+    const int t = rev ? T - 1 - s : s;
+    const int tp = rev ? t + 1 : t - 1;
+    const int tn = rev ? t - 1 : t + 1;
+    const int jt = blockIdx.x, j0 = jt * 16, b0 = blockIdx.y * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const long long G4 = 4LL * H, HH = (long long)ndir * H;
+    const bool has_next = s < T - 1;
+    const int NS = H / 4;
+    // epilogue inputs first
+    const int bb = tid >> 4, jj = tid & 15;
+    const int eb = b0 + bb, ej = j0 + jj;
+    const bool epi = eb < B;
+    float dh = 0.f, gi = 0.f, gf = 0.f, gc = 0.f, go = 0.f, c = 0.f, cp = 0.f, dcs = 0.f;
+    const long long si = ((long long)d * B + eb) * H + ej;
+    if (epi) {
+        dh = dh_out[((long long)eb * T + t) * HH + (long long)d * H + ej];
+        const float* gp = gates + (((long long)eb * T + t) * ndir + d) * G4;
+        gi = gp[ej]; gf = gp[H + ej]; gc = gp[2 * H + ej]; go = gp[3 * H + ej];
+        c = c_out[((long long)eb * T + t) * HH + (long long)d * H + ej];
+        if (s > 0) cp = c_out[((long long)eb * T + tp) * HH + (long long)d * H + ej];
+        if (has_next) dcs = dc_state[si];
+    }
+    if (has_next) {
+        const int b = b0 + r16;
+        const float* ap = dgates + (((long long)(b < B ? b : 0) * T + tn) * ndir + d) * G4 + wave * H + q * NS;
+        const float* bp = UTpk + ((((long long)d * (H / 16) + jt) * 4 + wave) * 64 + lane) * NS;
+        f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 0; s0 < NS; s0 += 16) {
+            f32x4a av[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                av[i] = *reinterpret_cast<const f32x4a*>(ap + s0 + 4 * i);
+                bv[i] = *reinterpret_cast<const f32x4a*>(bp + s0 + 4 * i);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b < B ? av[i / 4][i % 4] : 0.f, bv[i / 4][i % 4], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][(q * 4 + r) * 16 + r16] = acc[r];
+        __syncthreads();
+    }
+    if (!epi) return;
+    if (has_next) dh += red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    const float tc = tanhf(c);
+    float dc = dh * go * (1.f - tc * tc);
+    if (has_next) dc += dcs;
+    float* dg = dgates + (((long long)eb * T + t) * ndir + d) * G4;
+    dg[ej] = dc * gc * gi * (1.f - gi);
+    dg[H + ej] = dc * cp * gf * (1.f - gf);
+    dg[2 * H + ej] = dc * gi * (1.f - gc * gc);
+    dg[3 * H + ej] = dh * tc * go * (1.f - go);
+    dc_state[si] = dc * gf;
+}
+
+static inline bool lstm_pk_ok(int H) { return H % 64 == 0 && ((H / 16) <= 16 ? true : (H / 16) % 16 == 0); }
+
 }  // namespace ptts
 
 using namespace ptts;
 
-extern "C" int ptts_lstm_fwd(const float* xproj, const float* U, float* h_out, float* gates, float* c_out, int B,
-                             int T, int H, int ndir, int reverse, void* stream) {
+extern "C" size_t ptts_lstm_fwd_workspace_bytes(int B, int T, int H, int ndir) {
+    (void)B; (void)T;
+    return lstm_pk_ok(H) ? (size_t)ndir * 4 * H * H * sizeof(float) : 16;
+}
+
+extern "C" int ptts_lstm_fwd(const float* xproj, const float* U, float* h_out, float* gates, float* c_out,
+                             void* workspace, size_t workspace_bytes, int B, int T, int H, int ndir, int reverse,
+                             void* stream) {
     PTTS_REQUIRE(xproj && U && h_out && gates && c_out, "lstm_fwd: null tensor");
     PTTS_REQUIRE(B > 0 && T > 0 && H > 0 && (ndir == 1 || ndir == 2), "lstm_fwd: bad dims");
     PTTS_REQUIRE((size_t)LY * H * sizeof(float) <= 64 * 1024, "lstm_fwd: H=%d too large", H);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((H + LX - 1) / LX, (B + LY - 1) / LY, ndir), block(LX, LY);
     const size_t lds = (size_t)LY * H * sizeof(float);
+    if (lstm_pk_ok(H) && workspace && workspace_bytes >= ptts_lstm_fwd_workspace_bytes(B, T, H, ndir)) {
+        float* Upk = (float*)workspace;
+        hipLaunchKernelGGL(lstm_pack_u_fwd_kernel, dim3(1024), dim3(256), 0, st, U, Upk, H, ndir);
+        dim3 mgrid(H / 8, (B + 15) / 16, ndir);
+        const int KS = H / 16;
+        for (int s = 0; s < T; ++s) {
+            if (KS == 4) hipLaunchKernelGGL(lstm_fwd_step_pk_kernel<4>, mgrid, dim3(256), 0, st, xproj, (const float*)Upk, h_out, gates, c_out, B, T, H, ndir, reverse, s);
+            else if (KS == 8) hipLaunchKernelGGL(lstm_fwd_step_pk_kernel<8>, mgrid, dim3(256), 0, st, xproj, (const float*)Upk, h_out, gates, c_out, B, T, H, ndir, reverse, s);
+            else hipLaunchKernelGGL(lstm_fwd_step_pk_kernel<16>, mgrid, dim3(256), 0, st, xproj, (const float*)Upk, h_out, gates, c_out, B, T, H, ndir, reverse, s);
+        }
+        return check_launch("lstm_fwd_pk");
+    }
     if (H % 16 == 0) {
         dim3 mgrid(H / 8, (B + 15) / 16, ndir);
         for (int s = 0; s < T; ++s)
@@ -298,7 +499,7 @@ extern "C" int ptts_lstm_fwd(const float* xproj, const float* U, float* h_out, f
 
 extern "C" size_t ptts_lstm_bwd_workspace_bytes(int B, int T, int H, int ndir) {
     (void)T;
-    return ((size_t)ndir * 4 * H * H + (size_t)ndir * B * H) * sizeof(float);
+    return ((size_t)2 * ndir * 4 * H * H + (size_t)ndir * B * H) * sizeof(float);
 }
 
 extern "C" int ptts_lstm_bwd(const float* dh_out, const float* U, const float* gates, const float* c_out,
@@ -314,7 +515,16 @@ extern "C" int ptts_lstm_bwd(const float* dh_out, const float* U, const float* g
     }
     hipStream_t st = (hipStream_t)stream;
     float* UT = (float*)workspace;
-    float* dc_state = UT + (size_t)ndir * 4 * H * H;
+    float* UTpk = UT + (size_t)ndir * 4 * H * H;
+    float* dc_state = UTpk + (size_t)ndir * 4 * H * H;
+    if (lstm_pk_ok(H)) {
+        hipLaunchKernelGGL(lstm_pack_u_bwd_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, U, UTpk, H, ndir);
+        dim3 pgrid(H / 16, (B + 15) / 16, ndir);
+        for (int s = T - 1; s >= 0; --s)
+            hipLaunchKernelGGL(lstm_bwd_step_pk_kernel, pgrid, dim3(256), 0, (hipStream_t)stream, dh_out,
+                               (const float*)UTpk, gates, c_out, dgates, dc_state, B, T, H, ndir, reverse, s);
+        return check_launch("lstm_bwd_pk");
+    }
     const long long tot = (long long)ndir * 4 * H * H;
     int tb = (int)((tot + 255) / 256);
     if (tb > 2048) tb = 2048;

@@ -520,7 +520,8 @@ class LSTMFn(torch.autograd.Function):
         h = torch.empty((B, T, ndir * H), dtype=torch.float32, device=dev)
         c = torch.empty((B, T, ndir * H), dtype=torch.float32, device=dev)
         gates = torch.empty((B, T, ndir * G4), dtype=torch.float32, device=dev)
-        call('ptts_lstm_fwd', ptr(xproj), ptr(U), ptr(h), ptr(gates), ptr(c), B, T, H, ndir, int(reverse), stream())
+        wsf = _workspace(_hip.lib().ptts_lstm_fwd_workspace_bytes(B, T, H, ndir), dev)
+        call('ptts_lstm_fwd', ptr(xproj), ptr(U), ptr(h), ptr(gates), ptr(c), ptr(wsf), wsf.numel(), B, T, H, ndir, int(reverse), stream())
         ctx.save_for_backward(x, W, U, h, c, gates)
         ctx.reverse = int(reverse)
         return h
