@@ -99,13 +99,15 @@ int ptts_conv2d_bwd(const float* dy, const float* x, const float* w,
  *    a plain matrix has rows_per_seg = its row count, seg_stride = 0.)
  * B element (k,n):   transB==0: B[k*ldb + n] ;  transB==1: B[n*ldb + k]
  * The input transform acts on the stored A element; its channel index is the stored column.
- * accumulate != 0 adds to C (beta = 1). */
+ * accumulate != 0 adds to C (beta = 1).
+ * out_mask (NULL or laid out like C with ldc): the product is multiplied by (out_mask>0 ? 1 : alpha) before it is
+ * stored -- the LeakyReLU mask of a dense layer's backward-data pass, fused into the epilogue. */
 int ptts_gemm(const float* A, const float* Bm, const float* bias, float* C,
               int M, int N, int K,
               int transA, long long lda, long long rows_per_seg, long long seg_stride,
               int transB, long long ldb, long long ldc,
               int in_mode, const float* in_scale, const float* in_shift, const float* mask_src,
-              float alpha, int accumulate, void* stream);
+              float alpha, int accumulate, const float* out_mask, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * channel-last reductions and elementwise passes

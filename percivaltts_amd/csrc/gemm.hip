@@ -38,6 +38,7 @@ struct GemmArgs {
     int transB; long long ldb, ldc;
     int in_mode; const float* in_scale; const float* in_shift; const float* mask_src; float alpha;
     int accumulate;
+    const float* out_mask; float out_alpha;   // C *= (out_mask > 0 ? 1 : out_alpha), out_mask laid out like C
     int tiles_n, ksteps;          // tiles along N; k-steps per tile
     long long iters_total;        // tiles * ksteps
     int workers;
@@ -236,7 +237,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_mfma_kernel(GemmArgs g)
                     const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     if (m >= g.M) continue;
                     float* cp = g.C + (long long)m * g.ldc + n;
-                    const float v = acc[i][j][r] + bv;
+                    float v = acc[i][j][r] + bv;
+                    if (g.out_mask) v *= lrelu_d(g.out_mask[(long long)m * g.ldc + n], g.out_alpha);
                     if (!whole) atomicAdd(cp, v);
                     else if (g.accumulate) *cp += v;
                     else *cp = v;
@@ -253,13 +255,14 @@ extern "C" int ptts_gemm(const float* A, const float* Bm, const float* bias, flo
                          int transA, long long lda, long long rows_per_seg, long long seg_stride, int transB,
                          long long ldb, long long ldc, int in_mode, const float* in_scale,
                          const float* in_shift, const float* mask_src, float alpha, int accumulate,
-                         void* stream) {
+                         const float* out_mask, void* stream) {
     PTTS_REQUIRE(A && Bm && C, "gemm: null matrix");
     PTTS_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad dims M=%d N=%d K=%d", M, N, K);
     PTTS_REQUIRE(rows_per_seg > 0 && rows_per_seg < (1LL << 31) && lda > 0 && ldb > 0 && ldc >= N, "gemm: bad leading dims");
     PTTS_REQUIRE(in_mode >= 0 && in_mode <= 2, "gemm: bad in_mode %d", in_mode);
     PTTS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "gemm: scale/shift must come together");
     PTTS_REQUIRE(in_mode != PTTS_IN_MASKMUL || mask_src, "gemm: MASKMUL needs mask_src");
+    PTTS_REQUIRE(!(out_mask && bias), "gemm: out_mask with bias is not defined");
     hipStream_t st = (hipStream_t)stream;
     GemmArgs g;
     g.A = A; g.B = Bm; g.bias = bias; g.C = C; g.M = M; g.N = N; g.K = K;
@@ -267,6 +270,7 @@ extern "C" int ptts_gemm(const float* A, const float* Bm, const float* bias, flo
     g.transB = transB; g.ldb = ldb; g.ldc = ldc;
     g.in_mode = in_mode; g.in_scale = in_scale; g.in_shift = in_shift; g.mask_src = mask_src; g.alpha = alpha;
     g.accumulate = accumulate;
+    g.out_mask = out_mask; g.out_alpha = alpha;
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     const long long tiles = (long long)tm * tn;
     g.tiles_n = tn;

@@ -143,7 +143,7 @@ def _conv2d_bwd_raw(dy, x, w, scale, shift, mask_src, mode, alpha, dil_t, pad_mo
 
 
 def gemm_raw(A, Bm, C, M, N, K, transA=0, lda=None, rows_per_seg=None, seg_stride=0, transB=0, ldb=None, ldc=None,
-             bias=None, mode=IN_NONE, scale=None, shift=None, mask_src=None, alpha=0.3, accumulate=0):
+             bias=None, mode=IN_NONE, scale=None, shift=None, mask_src=None, alpha=0.3, accumulate=0, out_mask=None):
     """C[M,N] (+)= opA(A).opB(B) (+bias).  Pointers may be views with offsets; dims are the caller's contract."""
     for t in (A, Bm, C, bias, scale, shift, mask_src):
         if t is not None:
@@ -157,7 +157,7 @@ def gemm_raw(A, Bm, C, M, N, K, transA=0, lda=None, rows_per_seg=None, seg_strid
     if ldc is None:
         ldc = N
     call('ptts_gemm', ptr(A), ptr(Bm), ptr(bias), ptr(C), M, N, K, transA, lda, rows_per_seg, seg_stride,
-         transB, ldb, ldc, mode, ptr(scale), ptr(shift), ptr(mask_src), alpha, accumulate, stream(),
+         transB, ldb, ldc, mode, ptr(scale), ptr(shift), ptr(mask_src), alpha, accumulate, ptr(out_mask), stream(),
          tag=(M, N, K, transA, transB, int(seg_stride != 0)))
     return C
 
@@ -267,6 +267,10 @@ def _dense_bwd_data(dy2, x2, w, mode, scale, shift, alpha, want_affine):
     M, N = dy2.shape
     K = w.shape[0]
     da = torch.empty((M, K), dtype=torch.float32, device=dy2.device)
+    if mode == IN_LRELU and scale is None:
+        # no BatchNorm in front: the LeakyReLU mask of the layer input goes into the GEMM epilogue
+        gemm_raw(dy2, w, da, M, K, N, transB=1, ldb=N, alpha=alpha, out_mask=x2)
+        return da, None, None
     gemm_raw(dy2, w, da, M, K, N, transB=1, ldb=N)
     if mode == IN_NONE:
         return da, None, None
