@@ -70,6 +70,47 @@ __global__ __launch_bounds__(EW_THREADS) void colreduce2_kernel(Op op, long long
     }
 }
 
+// Plain column sums / sums of squares of a [rows, C] fp32 matrix with C % 4 == 0 and C <= 1024: every lane owns four
+// adjacent channels and streams float4 (16-byte loads), fp32 partials per 16 rows folded into fp64.
+__global__ __launch_bounds__(EW_THREADS) void colstats_vec4_kernel(const float* __restrict__ x, long long rows, int C,
+                                                                   double* __restrict__ partials) {
+    __shared__ double sh[8][EW_THREADS];
+    const int tid = threadIdx.x;
+    const int C4 = C / 4;
+    const int R = EW_THREADS / C4;              // rows per sweep
+    const int r = tid / C4, c4 = tid - r * C4;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (r < R) {
+        float fs[4] = {0, 0, 0, 0}, fq[4] = {0, 0, 0, 0};
+        int n = 0;
+        for (long long row = (long long)blockIdx.x * R + r; row < rows; row += (long long)gridDim.x * R) {
+            const float4 v = *reinterpret_cast<const float4*>(x + row * C + c4 * 4);
+            fs[0] += v.x; fs[1] += v.y; fs[2] += v.z; fs[3] += v.w;
+            fq[0] += v.x * v.x; fq[1] += v.y * v.y; fq[2] += v.z * v.z; fq[3] += v.w * v.w;
+            if (++n == 16) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s[e] += fs[e]; q[e] += fq[e]; fs[e] = 0.f; fq[e] = 0.f; }
+                n = 0;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[e] += fs[e]; q[e] += fq[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sh[e][tid] = s[e]; sh[4 + e][tid] = q[e]; }
+    __syncthreads();
+    double* out = partials + (size_t)blockIdx.x * 2 * C;
+    if (tid < C4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            double a = 0.0, b = 0.0;
+            for (int rr = 0; rr < R; ++rr) { a += sh[e][rr * C4 + tid]; b += sh[4 + e][rr * C4 + tid]; }
+            out[tid * 4 + e] = a;
+            out[C + tid * 4 + e] = b;
+        }
+    }
+}
+
 // out[j] = sum_b partials[b][j] in a fixed order.  grid = ceil(n2c/32), 256 lanes = 32 columns x 8 row groups.
 __global__ __launch_bounds__(256) void colreduce_final_kernel(const double* __restrict__ partials, int nblocks,
                                                               int n2c, double* __restrict__ out) {
@@ -394,6 +435,22 @@ extern "C" int ptts_colstats(const float* x, long long rows, int C, int in_mode,
                              void* workspace, size_t workspace_bytes, void* stream) {
     PTTS_REQUIRE(x && sums, "colstats: null tensor");
     PTTS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "colstats: scale/shift must come together");
+    if (in_mode == PTTS_IN_NONE && C % 4 == 0 && C <= 4 * EW_THREADS && ((uintptr_t)x % 16 == 0)) {
+        PTTS_REQUIRE(rows > 0, "colstats: rows=%lld", rows);
+        hipStream_t st = (hipStream_t)stream;
+        const int R = EW_THREADS / (C / 4);
+        long long nbl = (rows + (long long)R * 8 - 1) / ((long long)R * 8);
+        if (nbl < 1) nbl = 1;
+        if (nbl > 256) nbl = 256;
+        const int nb = (int)nbl;
+        const size_t need = (size_t)nb * 2 * C * sizeof(double);
+        if (!workspace || workspace_bytes < need) { set_error("colstats: workspace %zu < %zu", workspace_bytes, need); return PTTS_EWORKSPACE; }
+        hipLaunchKernelGGL(colstats_vec4_kernel, dim3(nb), dim3(EW_THREADS), 0, st, x, rows, C, (double*)workspace);
+        int rc = check_launch("colstats_vec4");
+        if (rc) return rc;
+        hipLaunchKernelGGL(colreduce_final_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, (const double*)workspace, nb, 2 * C, sums);
+        return check_launch("colstats_vec4_final");
+    }
     StatsOp op{x, in_mode, in_scale, in_shift, mask_src, alpha};
     return run_colreduce(op, rows, C, sums, workspace, workspace_bytes, (hipStream_t)stream, "colstats");
 }

@@ -247,6 +247,176 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_mfma_kernel(GemmArgs g)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// "Tall" GEMM: M >> N, 128 < N <= 256 (every hidden-width product of the networks: the context Conv1D, the Dense
+// layers forward and backward-data).  One workgroup owns TBM x 256 outputs -- ALL columns -- so A is streamed from
+// HBM/L2 exactly once and TBM is chosen so that ceil(M/TBM) fills the 256 CUs in one round (M = 25 600 -> TBM = 112 ->
+// 229 workgroups).  No split, no atomics: bitwise reproducible.  v_mfma_f32_16x16x4_f32 (same rate as 32x32x2);
+// 8 waves, wave w owns columns [32w, 32w+32) x all TBM/16 row tiles (14 accumulator tiles at TBM = 112).
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4c __attribute__((ext_vector_type(4)));
+constexpr int TBN = 256, TBK = 16;
+constexpr int TALL_THREADS = 512;            // 8 waves: two per SIMD hide each other's LDS latency and barriers
+constexpr int NTW = TBN / 16 / (TALL_THREADS / 64);   // column tiles of 16 per wave (2)
+constexpr int TLDB = TBN + 4;
+
+template <int TRANSB, int MODE, int MT /* row tiles of 16: TBM = 16*MT */>
+__global__ __launch_bounds__(TALL_THREADS) void gemm_tall_kernel(GemmArgs g) {
+    constexpr int TBM = 16 * MT;
+    constexpr int TLDA = TBM + 4;
+    __shared__ __attribute__((aligned(16))) float As[2][TBK * TLDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][TBK * TLDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.x * TBM;
+    const bool interior = (m0 + TBM <= g.M) && (g.N == TBN);
+    constexpr int NA = (TBM * TBK / 4 + TALL_THREADS - 1) / TALL_THREADS;   // float4 per lane for A (rows x 4 quads)
+    constexpr int NB = TBN * TBK / 4 / TALL_THREADS;
+
+    f32x4c acc[MT][NTW];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4c){0.f, 0.f, 0.f, 0.f};
+
+    float fa[NA][4], fb[NB][4];
+    auto load = [&](int k0, bool check) {
+        f32x4u va[NA], vm[NA], vb[NB];
+        int cha[NA];
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int qq = tid + j * TALL_THREADS;               // (row, k-quad)
+            const int row = qq >> 2, k = k0 + (qq & 3) * 4;
+            const int m = m0 + row;
+            const bool ok = row < TBM && (!check || m < g.M);
+            const long long offa = rowbase(g, ok ? m : 0) + k;
+            cha[j] = k;
+            if (check) {
+                va[j] = load4<true>(g.A + offa, ok, k, g.K);
+                if (MODE == PTTS_IN_MASKMUL) vm[j] = load4<true>(g.mask_src + offa, ok, k, g.K);
+            } else {
+                va[j] = ok ? *reinterpret_cast<const f32x4u*>(g.A + offa) : (f32x4u){0.f, 0.f, 0.f, 0.f};
+                if (MODE == PTTS_IN_MASKMUL) vm[j] = ok ? *reinterpret_cast<const f32x4u*>(g.mask_src + offa) : (f32x4u){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int qq = tid + j * TALL_THREADS;
+            if (TRANSB == 0) {                          // stored [k][n]
+                const int k = k0 + (qq >> 6), n = (qq & 63) * 4;
+                const bool ok = !check || k < g.K;
+                vb[j] = check ? load4<true>(g.B + (long long)(ok ? k : 0) * g.ldb + n, ok, n, g.N)
+                              : *reinterpret_cast<const f32x4u*>(g.B + (long long)k * g.ldb + n);
+            } else {                                    // stored [n][k]
+                const int n = qq >> 2, k = k0 + (qq & 3) * 4;
+                const bool ok = !check || n < g.N;
+                vb[j] = check ? load4<true>(g.B + (long long)(ok ? n : 0) * g.ldb + k, ok, k, g.K)
+                              : *reinterpret_cast<const f32x4u*>(g.B + (long long)n * g.ldb + k);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = va[j][e];
+                if (MODE == PTTS_IN_LRELU) {
+                    const int ch = cha[j] + e;
+                    const bool inr = !check || ch < g.K;
+                    if (g.in_scale) v = inr ? v * g.in_scale[inr ? ch : 0] + g.in_shift[inr ? ch : 0] : 0.f;
+                    v = lrelu(v, g.alpha);
+                } else if (MODE == PTTS_IN_MASKMUL) {
+                    v *= lrelu_d(vm[j][e], g.alpha);
+                }
+                fa[j][e] = v;
+            }
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fb[j][e] = vb[j][e];
+    };
+    auto store = [&](float* as, float* bs) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int qq = tid + j * TALL_THREADS;
+            const int row = qq >> 2, k = (qq & 3) * 4;
+            if (row < TBM) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) as[(k + e) * TLDA + row] = fa[j][e];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int qq = tid + j * TALL_THREADS;
+            if (TRANSB == 0) {
+                const int k = qq >> 6, n = (qq & 63) * 4;
+                *reinterpret_cast<float4*>(bs + k * TLDB + n) = make_float4(fb[j][0], fb[j][1], fb[j][2], fb[j][3]);
+            } else {
+                const int n = qq >> 2, k = (qq & 3) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bs[(k + e) * TLDB + n] = fb[j][e];
+            }
+        }
+    };
+
+    const int K = g.K;
+    load(0, !(interior && TBK <= K));
+    store(As[0], Bs[0]);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += TBK, buf ^= 1) {
+        const bool more = k0 + TBK < K;
+        if (more) load(k0 + TBK, !(interior && k0 + 2 * TBK <= K));
+        const float* as = As[buf] + q * TLDA + r16;
+        const float* bs = Bs[buf] + q * TLDB + wave * (16 * NTW) + r16;
+#pragma unroll
+        for (int kk = 0; kk < TBK; kk += 4) {
+            float ra[MT], rb[NTW];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) ra[i] = as[kk * TLDA + i * 16];
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) rb[j] = bs[kk * TLDB + j * 16];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[i], rb[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store(As[buf ^ 1], Bs[buf ^ 1]);
+        __syncthreads();
+    }
+    // epilogue: 16x16 C/D layout: col = lane&15, row = 4*(lane>>4) + r
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int n = wave * (16 * NTW) + j * 16 + r16;
+        if (n >= g.N) continue;
+        const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + i * 16 + q * 4 + r;
+                if (m >= g.M) continue;
+                const long long off = (long long)m * g.ldc + n;
+                float v = acc[i][j][r] + bv;
+                if (g.out_mask) v *= lrelu_d(g.out_mask[off], g.out_alpha);
+                if (g.accumulate) g.C[off] += v; else g.C[off] = v;
+            }
+    }
+}
+
+// rows per workgroup (multiple of 16, <= 128) that best fills 256 CUs in whole rounds
+static int pick_tall_mt(int M) {
+    int best = 8; double best_eff = -1.0;
+    for (int mt = 4; mt <= 8; ++mt) {
+        const long long blocks = (M + 16 * mt - 1) / (16 * mt);
+        const long long rounds = (blocks + 255) / 256;
+        const double eff = (double)M / (double)(rounds * 256 * 16 * mt);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = mt; }
+    }
+    return best;
+}
+
 }  // namespace ptts
 
 using namespace ptts;
@@ -271,6 +441,44 @@ extern "C" int ptts_gemm(const float* A, const float* Bm, const float* bias, flo
     g.in_mode = in_mode; g.in_scale = in_scale; g.in_shift = in_shift; g.mask_src = mask_src; g.alpha = alpha;
     g.accumulate = accumulate;
     g.out_mask = out_mask; g.out_alpha = alpha;
+    // N slightly above one full-width tile (the critic's 260-wide spectral part): full-width tile + remainder
+    if (transA == 0 && N > TBN && N <= 2 * TBN && M >= 2048 && K <= 2048) {
+        const int n1 = TBN, n2 = N - TBN;
+        const float* B2 = transB == 0 ? Bm + n1 : Bm + (long long)n1 * ldb;
+        int rc = ptts_gemm(A, Bm, bias, C, M, n1, K, transA, lda, rows_per_seg, seg_stride, transB, ldb, ldc, in_mode,
+                           in_scale, in_shift, mask_src, alpha, accumulate, out_mask, stream);
+        if (rc) return rc;
+        return ptts_gemm(A, B2, bias ? bias + n1 : nullptr, C + n1, M, n2, K, transA, lda, rows_per_seg, seg_stride,
+                         transB, ldb, ldc, in_mode, in_scale, in_shift, mask_src, alpha, accumulate,
+                         out_mask ? out_mask + n1 : nullptr, stream);
+    }
+    // tall products (M >> N, N in (128, 256]) take the full-width tile kernel: A read once, one round, no atomics
+    // (for deep K the stream-K 128x128 kernel below is faster: its two co-resident workgroups per CU overlap better)
+    if (transA == 0 && N > 128 && N <= TBN && M >= 2048 && K <= 2048) {
+        const int mt = pick_tall_mt(M);
+        dim3 tgrid((M + 16 * mt - 1) / (16 * mt)), tblock(TALL_THREADS);
+#define PTTS_TALL(TB, MD, MTT) hipLaunchKernelGGL((gemm_tall_kernel<TB, MD, MTT>), tgrid, tblock, 0, st, g)
+#define PTTS_TALL_MT(TB, MD)                                          \
+        switch (mt) {                                                 \
+            case 4: PTTS_TALL(TB, MD, 4); break;                      \
+            case 5: PTTS_TALL(TB, MD, 5); break;                      \
+            case 6: PTTS_TALL(TB, MD, 6); break;                      \
+            case 7: PTTS_TALL(TB, MD, 7); break;                      \
+            default: PTTS_TALL(TB, MD, 8); break;                     \
+        }
+        if (transB == 0) {
+            if (in_mode == PTTS_IN_LRELU) { PTTS_TALL_MT(0, PTTS_IN_LRELU) }
+            else if (in_mode == PTTS_IN_MASKMUL) { PTTS_TALL_MT(0, PTTS_IN_MASKMUL) }
+            else { PTTS_TALL_MT(0, PTTS_IN_NONE) }
+        } else {
+            if (in_mode == PTTS_IN_LRELU) { PTTS_TALL_MT(1, PTTS_IN_LRELU) }
+            else if (in_mode == PTTS_IN_MASKMUL) { PTTS_TALL_MT(1, PTTS_IN_MASKMUL) }
+            else { PTTS_TALL_MT(1, PTTS_IN_NONE) }
+        }
+#undef PTTS_TALL_MT
+#undef PTTS_TALL
+        return check_launch("gemm_tall");
+    }
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     const long long tiles = (long long)tm * tn;
     g.tiles_n = tn;
