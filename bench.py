@@ -39,6 +39,7 @@ def parse():
     ap.add_argument('--errtype', default='WLSWGAN')
     ap.add_argument('--eager', action='store_true', help='no hipGraph replay of the step')
     ap.add_argument('--no-prune', action='store_true', help="also run G's f0/noise branches in the critic step")
+    ap.add_argument('--streams', action='store_true', help='the three critic evaluations on three HIP streams')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=32)
@@ -215,6 +216,7 @@ def main():
     cfg = make_cfg(args)
     cfg.train_wgan_hipgraph = (not args.eager) and world == 1
     cfg.train_wgan_prune_dead_branches = not args.no_prune
+    cfg.train_wgan_parallel_streams = bool(args.streams)
     spec, nm = 65, 20
     voc = vocoders.VocoderPML(16000, 0.005, spec, nm)
     import io, contextlib

@@ -307,6 +307,113 @@ __global__ __launch_bounds__(CONV_THREADS) void conv2d_fwd_kernel(
     }
 }
 
+// Same persistent pipeline, FMAs on the matrix pipe: v_mfma_f32_4x4x1_16B_f32 computes, for 16 blocks at once,
+// D[4 pixels x 4 out-channels] += A[4 pixels x 1] . B[1 x 4 out-channels] -- one (tap, in-channel) pair per
+// instruction, 64 pixels per wave.  The weights sit in VGPRs for the whole launch (lane j%4 holds w[tap][ci][j]),
+// the activation vector of a pixel's tap comes from LDS with one ds_read_b128 per 4 MFMAs, the VALU only computes
+// addresses.  Full fp32 rate (64 flop/clk/SIMD) without the SGPR-operand issue limits of the v_pk_fma_f32 form.
+// Layout checked on hardware (tools/mfma4_test.hip): lane 4b+j, register r  <-  sum_k A(lane 4b+r) * B(lane 4b+j).
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+
+template <int CIN, int COUT, int KT, int KF, bool MASK, int NGI>
+__global__ __launch_bounds__(CONV_THREADS) void conv2d_fwd_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+    const float* __restrict__ mask_src, float* __restrict__ y,
+    int T, int F, int TT, int ntiles_t, int ntiles, int dil_t, int pad_t, int in_mode, float alpha) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int P = KF;
+    constexpr int PF = (KF - 1) / 2;
+    const int nspr = (F + P - 1) / P;
+    const int cols = nspr * P + KF - 1;
+    const int rows = TT + (KT - 1) * dil_t;
+    float* smem_out = smem + (((size_t)rows * cols * CIN + 3) & ~(size_t)3);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j4 = lane & 3;
+
+    // weights: one VGPR per (tap, ci), lane j holds output channel j (0 beyond COUT)
+    float wreg[KT * KF][CIN];
+#pragma unroll
+    for (int tap = 0; tap < KT * KF; ++tap)
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) wreg[tap][ci] = j4 < COUT ? w[(tap * CIN + ci) * COUT + j4] : 0.f;
+    const float bj = (bias && j4 < COUT) ? bias[j4] : 0.f;
+
+    int tile = blockIdx.x;
+    Prefetch<CIN> pf;
+    if (tile < ntiles) {
+        const int b = tile / ntiles_t, t0 = (tile - b * ntiles_t) * TT;
+        prefetch_tile<CIN, MASK>(pf, x, mask_src, (long long)b * T * F, T, F, rows, cols, t0 - pad_t, -PF);
+    }
+    while (tile < ntiles) {
+        const int b = tile / ntiles_t, t0 = (tile - b * ntiles_t) * TT;
+        const long long img = (long long)b * T * F;
+        commit_tile<CIN, MASK>(pf, smem, rows * cols, in_scale, in_shift, in_mode, alpha);
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < ntiles) {
+            const int nb = next / ntiles_t, nt0 = (next - nb * ntiles_t) * TT;
+            prefetch_tile<CIN, MASK>(pf, x, mask_src, (long long)nb * T * F, T, F, rows, cols, nt0 - pad_t, -PF);
+        }
+        const int nrows = min(TT, T - t0);
+        const int npix = nrows * F;
+        const int ngroups = (npix + 63) >> 6;
+        // NGI pixel groups of 64 advance together: independent accumulators between dependent MFMAs
+        for (int g0 = wave * NGI; g0 < ngroups; g0 += 4 * NGI) {
+            f32x4m acc[NGI][CIN];    // one chain per (group, in-channel): consecutive MFMAs never share an accumulator
+            const float* base[NGI];
+            int pixn[NGI];
+#pragma unroll
+            for (int u = 0; u < NGI; ++u) {
+                const int n = (g0 + u) * 64 + lane;
+                pixn[u] = n;
+                const int nn = n < npix ? n : 0;
+                const int r = nn / F, f = nn - r * F;
+                base[u] = smem + ((size_t)r * cols + f) * CIN;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) acc[u][ci] = ci == 0 ? (f32x4m){bj, bj, bj, bj} : (f32x4m){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+                for (int kf = 0; kf < KF; ++kf) {
+                    float a[NGI][CIN];
+#pragma unroll
+                    for (int u = 0; u < NGI; ++u) VecIO<CIN>::ld(base[u] + ((size_t)kt * dil_t * cols + kf) * CIN, a[u]);
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                        for (int u = 0; u < NGI; ++u)
+                            acc[u][ci] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u][ci], wreg[kt * KF + kf][ci], acc[u][ci], 0, 0, 0);
+                }
+            }
+            // lane 4b+j, register r = pixel 4b+r of the group, channel j
+#pragma unroll
+            for (int u = 0; u < NGI; ++u) {
+                if ((g0 + u) >= ngroups || j4 >= COUT) continue;
+                const int pb = (g0 + u) * 64 + (lane & ~3);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[u][0][r];
+#pragma unroll
+                    for (int ci = 1; ci < CIN; ++ci) v += acc[u][ci][r];
+                    if (pb + r < npix) smem_out[(size_t)(pb + r) * COUT + j4] = v;
+                }
+            }
+        }
+        __syncthreads();
+        const int nout = npix * COUT;
+        float* yo = y + (img + (long long)t0 * F) * COUT;
+        if ((F * COUT) % 4 == 0) {
+            for (int i = threadIdx.x * 4; i < nout; i += CONV_THREADS * 4)
+                *reinterpret_cast<float4*>(yo + i) = *reinterpret_cast<const float4*>(smem_out + i);
+        } else {
+            for (int i = threadIdx.x; i < nout; i += CONV_THREADS) yo[i] = smem_out[i];
+        }
+        tile = next;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // fused backward
 // LDS: dyt [TT + (KT-1)*dil_t][Fp + KF-1][COUT] | at [TT][Fp][CIN] | xt [TT][Fp][CIN] (affine only)
@@ -740,6 +847,12 @@ __global__ __launch_bounds__(256) void conv2d_bwd_w_generic(
 // ------------------------------------------------------------------------------------------
 // host side: tile choice + dispatch
 // ------------------------------------------------------------------------------------------
+static bool conv_use_mfma() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PTTS_CONV_MFMA"); v = e ? atoi(e) : 0; }
+    return v != 0;
+}
+
 // LDS per workgroup bounds the tile height; PTTS_CONV_LDS_KB overrides it (tuning knob).
 static size_t lds_budget() {
     static size_t v = 0;
@@ -781,6 +894,10 @@ static Tile pick_tile(int T, int F, int KT, int KF, int dil_t, size_t bytes_per_
 static Tile pick_tile_fwd(int T, int F, int KT, int KF, int dil_t, int cols) {
     const int nspr = (F + KF - 1) / KF;
     const int halo = (KT - 1) * dil_t;
+    if (const char* e = getenv("PTTS_CONV_TT")) {     // tuning knob
+        const int TT = atoi(e);
+        if (TT > 0 && (TT + halo) * cols <= NPF * CONV_THREADS) return Tile{TT, (T + TT - 1) / TT};
+    }
     Tile best{0, 0};
     double best_score = -1.0;
     for (int TT = 1; TT <= 128; ++TT) {
@@ -852,6 +969,11 @@ extern "C" int ptts_conv2d_fwd(const float* x, const float* w, const float* bias
             long long grid = (long long)tl.ntiles * B;                                                   \
             if (grid > 256LL * per_cu) grid = 256LL * per_cu;                                            \
             const bool mk = in_mode == PTTS_IN_MASKMUL;                                                  \
+            if (conv_use_mfma() && dil_t >= 1) {                                                         \
+                if (mk) hipLaunchKernelGGL((conv2d_fwd_mfma_kernel<CI, CO, KTT, KFF, true, 2>), dim3(grid), dim3(CONV_THREADS), lds, st, x, w, bias, in_scale, in_shift, mask_src, y, T, F, tl.TT, tl.ntiles, tl.ntiles * B, dil_t, g.pad_t, in_mode, alpha); \
+                else hipLaunchKernelGGL((conv2d_fwd_mfma_kernel<CI, CO, KTT, KFF, false, 2>), dim3(grid), dim3(CONV_THREADS), lds, st, x, w, bias, in_scale, in_shift, mask_src, y, T, F, tl.TT, tl.ntiles, tl.ntiles * B, dil_t, g.pad_t, in_mode, alpha); \
+                return check_launch("conv2d_fwd_mfma");                                                  \
+            }                                                                                            \
             if (nr == 1) { if (mk) FWD_LAUNCH(CI, CO, KTT, KFF, 1, true); else FWD_LAUNCH(CI, CO, KTT, KFF, 1, false); } \
             else { if (mk) FWD_LAUNCH(CI, CO, KTT, KFF, 2, true); else FWD_LAUNCH(CI, CO, KTT, KFF, 2, false); }         \
             return check_launch("conv2d_fwd");                                                           \

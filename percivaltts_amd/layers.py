@@ -143,6 +143,14 @@ class Dense(Layer):
     def out_shape(self, in_shapes):
         return tuple(in_shapes[0][:-1]) + (self.units,)
 
+    def prime_part(self, i, widths, part, memo):
+        """Product of concat part i with its rows of the kernel, stored in `memo` for every evaluation that shares it."""
+        off = sum(widths[:i])
+        part = ops.as_lazy(part)
+        key = ('dense_part', id(self), i, id(part.z))
+        if key not in memo:
+            memo[key] = ops.dense(part, self.kernel[off:off + widths[i]], None)
+
     def compute(self, vals, training, memo):
         v = vals[0]
         if isinstance(v, LazyConcat):
@@ -453,17 +461,44 @@ class Model(nn.Module):
             assert id(i) in self.deps or True
 
     def _run(self, feed, training, memo, values=None, only_dep=None):
+        """Evaluate the nodes not yet in `values`.  Nodes tagged `stream = 1` (an independent branch such as the
+        generator's latency-bound BLSTM) are enqueued on a side HIP stream when `self.parallel_branches` is set, so
+        that they overlap with the rest of the graph; autograd replays the same streams in the backward pass (and,
+        processing nodes in reverse creation order, enqueues the main-stream backward first)."""
         values = {} if values is None else values
+        use_side = bool(getattr(self, 'parallel_branches', False)) and torch.cuda.is_available()
+        side, cur, pending = None, None, False
+        on_side = set()
         for n in self.order:
             if id(n) in values:
                 continue
             if not n.parents:
                 values[id(n)] = feed[id(n)]
                 continue
-            if only_dep is not None and only_dep not in self.deps[id(n)] and False:
-                continue
             vals = [values[id(p)] for p in n.parents]
+            if use_side and getattr(n, 'stream', 0):
+                if side is None:
+                    side = self._variant_streams(2)[0]
+                    cur = torch.cuda.current_stream()
+                if not any(id(p) in on_side for p in n.parents):
+                    side.wait_stream(cur)          # inputs were produced on the main stream
+                with torch.cuda.stream(side):
+                    values[id(n)] = n.layer.compute(vals, training, memo)
+                on_side.add(id(n))
+                pending = True
+                continue
+            if pending and any(id(p) in on_side for p in n.parents):
+                cur.wait_stream(side)
+                pending = False
+                for p in n.parents:
+                    if id(p) in on_side:
+                        t = values[id(p)]
+                        t = t.z if isinstance(t, Lazy) else t
+                        if torch.is_tensor(t):
+                            t.record_stream(cur)
             values[id(n)] = n.layer.compute(vals, training, memo)
+        if pending:
+            cur.wait_stream(side)
         return values
 
     def forward(self, *xs, **kw):
@@ -477,7 +512,7 @@ class Model(nn.Module):
         outs = [to_tensor(values[id(o)]) for o in self.outputs]
         return outs[0] if self.single_output else outs
 
-    def forward_multi(self, varying_index, variants, fixed, training=False, memo=None):
+    def forward_multi(self, varying_index, variants, fixed, training=False, memo=None, parallel_streams=False):
         """Evaluate the model for several values of input `varying_index` while every node that does not
         depend on it (the critic's context branch) is computed once and shared."""
         memo = {} if memo is None else memo
@@ -496,14 +531,41 @@ class Model(nn.Module):
                 shared[id(n)] = feed[id(n)]
             else:
                 shared[id(n)] = n.layer.compute([shared[id(p)] for p in n.parents], training, memo)
+        # products of shared concat parts with their kernel rows (Dense over a LazyConcat) are computed once, up front
+        for n in self.order:
+            if isinstance(n.layer, Dense) and id(vin) in self.deps[id(n)] and isinstance(n.parents[0].layer, Concatenate):
+                for i, pn in enumerate(n.parents[0].parents):
+                    if i > 0 and id(pn) in shared:
+                        n.layer.prime_part(i, [pp.shape[-1] for pp in n.parents[0].parents], shared[id(pn)], memo)
         results = []
-        for x in variants:
+        streams = self._variant_streams(len(variants)) if parallel_streams else None
+        cur = torch.cuda.current_stream() if parallel_streams else None
+        for vi, x in enumerate(variants):
             values = dict(shared)
             values[id(vin)] = x
-            values = self._run({}, training, memo, values)
-            outs = [to_tensor(values[id(o)]) for o in self.outputs]
+            if streams is not None and vi > 0:
+                st = streams[vi - 1]
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    values = self._run({}, training, memo, values)
+                    outs = [to_tensor(values[id(o)]) for o in self.outputs]
+            else:
+                values = self._run({}, training, memo, values)
+                outs = [to_tensor(values[id(o)]) for o in self.outputs]
             results.append(outs[0] if self.single_output else outs)
+        if streams is not None:
+            for vi in range(1, len(variants)):
+                cur.wait_stream(streams[vi - 1])
+                for o in (results[vi] if isinstance(results[vi], list) else [results[vi]]):
+                    o.record_stream(cur)
         return results
+
+    def _variant_streams(self, n):
+        ss = getattr(self, '_vstreams', None)
+        if ss is None or len(ss) < n - 1:
+            ss = [torch.cuda.Stream() for _ in range(n - 1)]
+            self._vstreams = ss
+        return ss
 
     # ---- Keras-like accessors ----------------------------------------------------------------
     def weights(self):

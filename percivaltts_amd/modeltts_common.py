@@ -37,7 +37,9 @@ class DCNNF0SpecNoiseFeatures(modeltts.ModelTTS):
 
         # F0
         l_f0 = networktts.pBLSTM(l_ctx, width=cfgarch.arch_hiddenwidth)
+        l_f0.stream = 1           # independent, latency-bound branch: may run on a side HIP stream (layers.Model._run)
         l_f0 = kl.Dense(1, activation=None, use_bias=True)(l_f0)
+        l_f0.stream = 1
 
         # Spec
         l_spec = kl.Dense(vocoder.specsize(), use_bias=True)(l_ctx)   # projection

@@ -105,6 +105,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         cfg.train_wgan_weight_clip = None             # c > 0: clamp critic weights to [-c, c] after each critic update
         cfg.train_wgan_prune_dead_branches = True
         cfg.train_wgan_hipgraph = False
+        cfg.train_wgan_parallel_streams = False      # the three critic evaluations on three HIP streams
         return cfg
 
     # ---------------------------------------------------------------------------------------------------------
@@ -176,6 +177,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             raise ValueError('unknown error type ' + str(self._errtype))
 
         # these two names are what the reference exposes after prepare()
+        generator.parallel_branches = bool(cfg.train_wgan_parallel_streams)
         self.critic_model = self.critic_net
         self.generator_model = generator
         self._graphs = {}
@@ -199,7 +201,8 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         if fake is None:
             fake = self._fake_sample(X, training)
         x_hat = RandomWeightedAverage(X.shape[0])([Y, fake], alpha).requires_grad_(True)
-        valid, fake_v, v_hat = self.critic_net.forward_multi(0, [Y, fake, x_hat], [X], training=training)
+        valid, fake_v, v_hat = self.critic_net.forward_multi(0, [Y, fake, x_hat], [X], training=training,
+                                                               parallel_streams=bool(getattr(self.cfg, 'train_wgan_parallel_streams', False)))
         l_valid = wasserstein_loss(-1.0, valid)
         l_fake = wasserstein_loss(+1.0, fake_v)
         gp = gradient_penalty_loss(None, v_hat, x_hat)

@@ -75,7 +75,7 @@ def close(got, want, rtol=5e-4, atol=1e-5, what='', kinks=False):
     assert got.shape == want.shape, what
     err = np.abs(got - want)
     tol = atol + rtol * np.abs(want)
-    if kinks and (err > tol).sum() <= max(1, int(1e-3 * err.size)) and err.max() <= 0.05 * np.abs(want).max():
+    if kinks and np.linalg.norm(err) <= 2e-3 * np.linalg.norm(want) and err.max() <= 0.05 * np.abs(want).max():
         return
     assert (err <= tol).all(), '{}: {} of {} off, worst {:.3e} (max|want| {:.3e})'.format(what, int((err > tol).sum()), err.size, float(err.max()), float(np.abs(want).max()))
 

@@ -13,16 +13,15 @@ pytestmark = pytest.mark.gpu
 def close(got, want, rtol, atol, what='', kinks=False):
     """kinks=True (gradient comparisons): LeakyReLU makes the gradient discontinuous in the pre-activations, so a
     pre-activation that is ~0 can take a different side in fp32 (HIP) and fp64 (oracle); the handful of gradient entries
-    fed by that one mask then differ by a few percent.  Up to 0.1 % of the entries may therefore miss the tolerance, by
-    at most 5 % of the largest gradient."""
+    fed by that one mask then differ by a few percent.  When the elementwise check fails, the tensor still passes if its
+    relative L2 error is <= 2e-3 and no entry is off by more than 5 % of the largest gradient."""
     got = torch.as_tensor(np.asarray(got.detach().cpu() if torch.is_tensor(got) else got), dtype=torch.float64)
     want = torch.as_tensor(np.asarray(want.detach().cpu() if torch.is_tensor(want) else want), dtype=torch.float64)
     assert got.shape == want.shape, '{}: {} vs {}'.format(what, tuple(got.shape), tuple(want.shape))
     err = (got - want).abs()
     tol = atol + rtol * want.abs()
     if kinks and (err > tol).any():
-        bad = err > tol
-        if int(bad.sum()) <= max(1, int(1e-3 * err.numel())) and float(err.max()) <= 0.05 * float(want.abs().max()):
+        if float(err.norm()) <= 2e-3 * float(want.norm()) and float(err.max()) <= 0.05 * float(want.abs().max()):
             return
     if (err > tol).any():
         i = int(torch.argmax(err - tol))
@@ -216,3 +215,23 @@ def test_hipgraph_replay_matches_eager():
         outs.append((losses, opt.critic_opti.flat.flat.detach().cpu().clone()))
     np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-4, atol=1e-6)
     close(outs[1][1], outs[0][1], 1e-3, 1e-5, 'critic weights after 3 steps, graph vs eager')
+
+
+def test_parallel_streams_match_single_stream():
+    """cfg.train_wgan_parallel_streams runs the three critic evaluations on three HIP streams: same loss and gradients."""
+    from percivaltts_amd import optimizertts_wgan
+    res = []
+    for par in (False, True):
+        cfg, voc, mod, crit, a, gw, cw, X, Y, al = build('default')
+        cfg.train_wgan_parallel_streams = par
+        opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype='WLSWGAN', critic=crit)
+        opt.prepare()
+        Xd, Yd, ald = f32(X), f32(Y), f32(al)
+        losses = []
+        for _ in range(3):
+            losses.append(float(opt.critic_step(Xd, Yd, ald).item()))
+        torch.cuda.synchronize()
+        res.append((losses, opt.critic_opti.flat.flat.detach().cpu().clone(), opt.critic_opti.flat.grad.detach().cpu().clone()))
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-5, atol=1e-6)
+    close(res[1][2], res[0][2], 1e-4, 1e-6, 'last critic gradient, 3 streams vs 1', kinks=True)
+    close(res[1][1], res[0][1], 1e-4, 1e-6, 'critic weights after 3 steps, 3 streams vs 1', kinks=True)

@@ -9,6 +9,6 @@ def timed(fn, n=20):
         for _ in range(n): fn()
     d = [t for (_, _, t) in kt.durations_ms()]
     d.sort(); return d[len(d)//2] * 1e3
-for name, bits in (('full', 0), ('1of5 kt', 1), ('no prefetch-next', 2), ('no store', 4), ('1kt+nostore', 5), ('1kt+nopf+nostore', 7)):
+for name, bits in (('full', 0), ('no compute', 1), ('no compute, no store', 5), ('no compute/store/prefetch-next', 7), ('nothing but first prefetch+barriers', 15), ('no prefetch-next', 2), ('no store', 4)):
     mode = 1 | (bits << 8)
-    print('{:<22} {:7.1f} us'.format(name, timed(lambda: ops._conv2d_fwd_raw(x, w, b, None, None, None, mode, 0.3, 1, 0))))
+    print('{:<38} {:7.1f} us'.format(name, timed(lambda: ops._conv2d_fwd_raw(x, w, b, None, None, None, mode, 0.3, 1, 0))))
