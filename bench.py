@@ -37,9 +37,10 @@ def parse():
     ap.add_argument('--frames', type=int, default=400)
     ap.add_argument('--ctx', type=int, default=601)
     ap.add_argument('--errtype', default='WLSWGAN')
-    ap.add_argument('--eager', action='store_true', help='no hipGraph replay of the step')
+    ap.add_argument('--graph', action='store_true', help='capture each step once and replay it as a hipGraph (single stream)')
+    ap.add_argument('--eager', action='store_true', help='(default) eager launches; kept for compatibility')
     ap.add_argument('--no-prune', action='store_true', help="also run G's f0/noise branches in the critic step")
-    ap.add_argument('--streams', action='store_true', help='the three critic evaluations on three HIP streams')
+    ap.add_argument('--no-streams', action='store_true', help='single HIP stream (default: the three critic evaluations and the BLSTM branch on side streams)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=32)
@@ -131,6 +132,9 @@ def roofline_leg(opt, X, Y, args):
     B, T = X.shape[0], X.shape[1]
     voc = opt._model.vocoder
     F, C, L = voc.specsize(), opt.cfg.arch_gen_nbfilters, opt.cfg.arch_gen_nbcnnlayers
+    # per-kernel HIP events need every launch on the one stream the events are recorded on
+    opt.cfg.train_wgan_parallel_streams = False
+    opt._model.kerasmodel.parallel_branches = False
     for _ in range(2):
         opt.critic_step(X, Y)
     torch.cuda.synchronize()
@@ -214,9 +218,9 @@ def main():
     world, rank = parallel.init()
     dev = backend_hip.device()
     cfg = make_cfg(args)
-    cfg.train_wgan_hipgraph = (not args.eager) and world == 1
+    cfg.train_wgan_hipgraph = bool(args.graph) and world == 1
     cfg.train_wgan_prune_dead_branches = not args.no_prune
-    cfg.train_wgan_parallel_streams = bool(args.streams)
+    cfg.train_wgan_parallel_streams = (not args.no_streams) and not cfg.train_wgan_hipgraph
     spec, nm = 65, 20
     voc = vocoders.VocoderPML(16000, 0.005, spec, nm)
     import io, contextlib
@@ -226,6 +230,7 @@ def main():
         crit = networks_critic.Critic(voc, args.ctx, cfg)
         opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype=args.errtype, critic=crit)
         opt.prepare()
+    par_streams = bool(cfg.train_wgan_parallel_streams)
     opt.generator_updates = 26           # steady state: critic_runs = 5 (optimizertts_wgan.py:225-228)
 
     B, T = args.batch, args.frames
@@ -273,6 +278,7 @@ def main():
                                    'step = one train_on_batch'.format(b=B, t=T, c=args.ctx, o=voc.featuressize(), e=args.errtype),
                        'per_gpu_batch': B, 'global_batch': B * world, 'frames_per_step_per_gpu': B * T,
                        'parallelism': 'dp{}'.format(world), 'hipgraph': bool(cfg.train_wgan_hipgraph),
+                       'hip_streams': 3 if par_streams else 1,
                        'prune_dead_generator_branches_in_critic_step': bool(cfg.train_wgan_prune_dead_branches),
                        'generator_params': mod.count_params(), 'critic_params': crit.model.count_params()},
         }
