@@ -1,0 +1,92 @@
+"""Data-parallel WGAN-GP step on real kernels: two ranks (gloo, both on the one GPU of the test box) must end with the
+same critic / generator weights as one process that averages the two shard gradients by hand."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _setup():
+    import io, contextlib
+    import test_model_gpu as tm
+    with contextlib.redirect_stdout(io.StringIO()):
+        cfg, voc, mod, crit, a, gw, cw, X, Y, al = tm.build('test')
+    return tm, cfg, mod, crit, X, Y, al
+
+
+def _worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'RANK': str(rank), 'WORLD_SIZE': str(world),
+                       'LOCAL_RANK': '0', 'PTTS_DIST_BACKEND': 'gloo'})
+    import io, contextlib
+    from percivaltts_amd import optimizertts_wgan, parallel
+    tm, cfg, mod, crit, X, Y, al = _setup()
+    with contextlib.redirect_stdout(io.StringIO()):
+        opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype='WLSWGAN', critic=crit)
+        opt.prepare()
+    assert opt.world == world
+    lo, hi = parallel.shard_batch(X.shape[0], world, rank)
+    Xd, Yd, ald = tm.f32(X[lo:hi]), tm.f32(Y[lo:hi]), tm.f32(al[lo:hi])
+    for _ in range(2):
+        opt.critic_step(Xd, Yd, ald)
+    opt.generator_step(Xd, Yd)
+    torch.cuda.synchronize()
+    q.put((rank, opt.critic_opti.flat.flat.cpu().numpy(), opt.gen_opti.flat.flat.cpu().numpy()))
+    parallel.barrier()
+
+
+def test_two_ranks_equal_manual_gradient_averaging():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=0, atol=0)      # replicas stay identical
+    np.testing.assert_allclose(res[0][2], res[1][2], rtol=0, atol=0)
+
+    # single process: same two shards, gradients averaged by hand
+    import io, contextlib
+    from percivaltts_amd import optimizertts_wgan
+    tm, cfg, mod, crit, X, Y, al = _setup()
+    with contextlib.redirect_stdout(io.StringIO()):
+        opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype='WLSWGAN', critic=crit)
+        opt.prepare()
+    shards = [(tm.f32(X[i:i + 1]), tm.f32(Y[i:i + 1]), tm.f32(al[i:i + 1])) for i in range(2)]
+    for _ in range(2):
+        acc = torch.zeros_like(opt.critic_opti.flat.grad)
+        for (xs, ys, as_) in shards:
+            opt.critic_opti.zero_grad()
+            total, _ = opt.critic_loss(xs, ys, as_, training=True)
+            total.backward()
+            acc += opt.critic_opti.flat.grad
+        opt.critic_opti.flat.grad.copy_(acc)
+        opt.critic_opti.step(0.5)
+    acc = torch.zeros_like(opt.gen_opti.flat.grad)
+    snap = [b.clone() for b in opt._model.kerasmodel.buffers()]
+    for (xs, ys, _) in shards:
+        opt.gen_opti.zero_grad()
+        for p in opt.critic_opti.flat.params: p.requires_grad_(False)
+        total, _ = opt.generator_loss(xs, ys, training=True)
+        total.backward()
+        for p in opt.critic_opti.flat.params: p.requires_grad_(True)
+        acc += opt.gen_opti.flat.grad
+    opt.gen_opti.flat.grad.copy_(acc)
+    opt.gen_opti.step(0.5)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(res[0][1], opt.critic_opti.flat.flat.cpu().numpy(), rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(res[0][2], opt.gen_opti.flat.flat.cpu().numpy(), rtol=2e-4, atol=2e-6)
