@@ -237,10 +237,7 @@ class Conv1D(Layer):
         return (self.filters,)
 
     def compute(self, vals, training, memo):
-        v = vals[0]
-        a = to_tensor(v)
-        key = None
-        return ops.conv1d(a, self.kernel, self.bias)
+        return ops.conv1d(to_tensor(vals[0]), self.kernel, self.bias)
 
 
 class Conv2D(Layer):
@@ -457,8 +454,6 @@ class Model(nn.Module):
                 for p in n.parents:
                     s |= self.deps[id(p)]
                 self.deps[id(n)] = s
-        for i in self.inputs:
-            assert id(i) in self.deps or True
 
     def _run(self, feed, training, memo, values=None, only_dep=None):
         """Evaluate the nodes not yet in `values`.  Nodes tagged `stream = 1` (an independent branch such as the
@@ -633,5 +628,3 @@ class FlatParams(object):
 
     def zero_grad(self):
         self.grad.zero_()
-        for p, in zip(self.params):
-            pass
