@@ -28,6 +28,12 @@ inline int check_launch(const char* what) {
 
 constexpr int WAVE = 64;
 
+// thin.hip: returns 1 when it handled the product, 0 to fall through to the MFMA kernels, <0 on error
+int thin_gemm_dispatch(const float* A, const float* Bm, const float* bias, float* C, int M, int N, int K, int transA,
+                       long long lda, long long rows_per_seg, long long seg_stride, int transB, long long ldb,
+                       long long ldc, int in_mode, const float* in_scale, const float* in_shift,
+                       const float* mask_src, float alpha, int accumulate, const float* out_mask, hipStream_t st);
+
 __device__ __forceinline__ float lrelu(float p, float alpha) { return p > 0.f ? p : alpha * p; }
 __device__ __forceinline__ float lrelu_d(float p, float alpha) { return p > 0.f ? 1.f : alpha; }
 

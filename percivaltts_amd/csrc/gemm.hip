@@ -421,6 +421,12 @@ static int pick_tall_mt(int M) {
 
 using namespace ptts;
 
+static bool thin_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PTTS_GEMM_THIN"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
+
 extern "C" int ptts_gemm(const float* A, const float* Bm, const float* bias, float* C, int M, int N, int K,
                          int transA, long long lda, long long rows_per_seg, long long seg_stride, int transB,
                          long long ldb, long long ldc, int in_mode, const float* in_scale,
@@ -441,6 +447,13 @@ extern "C" int ptts_gemm(const float* A, const float* Bm, const float* bias, flo
     g.in_mode = in_mode; g.in_scale = in_scale; g.in_shift = in_shift; g.mask_src = mask_src; g.alpha = alpha;
     g.accumulate = accumulate;
     g.out_mask = out_mask; g.out_alpha = alpha;
+    // thin products (N <= 4 heads, K <= 4 outer products, 1-2 weighted column sums) never reach the MFMA tiles
+    if (thin_enabled()) {
+        const int thin = thin_gemm_dispatch(A, Bm, bias, C, M, N, K, transA, lda, rows_per_seg, seg_stride, transB, ldb, ldc,
+                                            in_mode, in_scale, in_shift, mask_src, alpha, accumulate, out_mask, st);
+        if (thin < 0) return thin;
+        if (thin == 1) return PTTS_OK;
+    }
     // N slightly above one full-width tile (the critic's 260-wide spectral part): full-width tile + remainder
     if (transA == 0 && N > TBN && N <= 2 * TBN && M >= 2048 && K <= 2048) {
         const int n1 = TBN, n2 = N - TBN;

@@ -1,0 +1,158 @@
+// Thin products that a 128-wide MFMA tile would waste: the critic's Dense(1) head, the generator's f0 head and the
+// 4-column remainder of the 260-wide spectral part (reference networks_critic.py:89-96, modeltts_common.py:84).
+//   gemv  : C[M, N<=4]  = T(A)[M,K] . B          (one wave per row, lanes along K, butterfly reduce)
+//   thin-K: C[M, N]     = A[M, K<=4] . B  (* mask)   (outer-product-like, streaming write of C)
+//   wcol  : C[Mo, N<=2] = T(A)[Kr, Mo]^T . B[Kr, N]   (column sums of A weighted by 1-2 columns of B; fp32 atomics)
+// All are HBM-bound single passes over the big operand.
+#include "common.h"
+
+namespace ptts {
+
+struct ThinArgs {
+    const float* A; const float* B; const float* bias; float* C;
+    int M, N, K;
+    long long lda, ldb, ldc;
+    int transB;
+    int in_mode; const float* in_scale; const float* in_shift; const float* mask_src; float alpha;
+    int accumulate; const float* out_mask;
+};
+
+__device__ __forceinline__ float thin_xform(float v, const ThinArgs& g, long long off, int ch) {
+    if (g.in_mode == PTTS_IN_LRELU) {
+        if (g.in_scale) v = v * g.in_scale[ch] + g.in_shift[ch];
+        return lrelu(v, g.alpha);
+    } else if (g.in_mode == PTTS_IN_MASKMUL) {
+        return v * lrelu_d(g.mask_src[off], g.alpha);
+    }
+    return v;
+}
+
+// one wave per row; A row-major with leading dim lda (transA = 0)
+template <int NT>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(ThinArgs g) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int nwaves = gridDim.x * 4;
+    for (int m = wave; m < g.M; m += nwaves) {
+        float acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = 0.f;
+        const long long row = (long long)m * g.lda;
+        for (int k = lane; k < g.K; k += 64) {
+            const float a = thin_xform(g.A[row + k], g, row + k, k);
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                if (n < g.N) acc[n] = fmaf(a, g.transB ? g.B[(long long)n * g.ldb + k] : g.B[(long long)k * g.ldb + n], acc[n]);
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = wave_sum(acc[n]);
+        if (lane == 0) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                if (n >= g.N) continue;
+                const long long off = (long long)m * g.ldc + n;
+                float v = acc[n] + (g.bias ? g.bias[n] : 0.f);
+                if (g.out_mask) v *= lrelu_d(g.out_mask[off], g.alpha);
+                if (g.accumulate) g.C[off] += v; else g.C[off] = v;
+            }
+        }
+    }
+}
+
+// K <= 4: each lane produces consecutive columns of one row
+template <int KT>
+__global__ __launch_bounds__(256) void thin_k_kernel(ThinArgs g) {
+    const long long total = (long long)g.M * g.N;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int n = (int)(i % g.N);
+        const long long m = i / g.N;
+        float v = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            if (k >= g.K) continue;
+            const long long offa = m * g.lda + k;
+            const float a = thin_xform(g.A[offa], g, offa, k);
+            v = fmaf(a, g.transB ? g.B[(long long)n * g.ldb + k] : g.B[(long long)k * g.ldb + n], v);
+        }
+        const long long off = m * g.ldc + n;
+        if (g.out_mask) v *= lrelu_d(g.out_mask[off], g.alpha);
+        if (g.accumulate) g.C[off] += v; else g.C[off] = v;
+    }
+}
+
+// C[i, n] = sum_r T(A[r, i]) * B[r, n],  n < N <= 2,  A stored [Kr rows][Mo cols] (the transA = 1 operand).
+// Lanes along the columns i (coalesced rows), 4 row groups per workgroup, LDS combine, one fp32 atomic per (i, n).
+template <int NT>
+__global__ __launch_bounds__(256) void wcol_kernel(ThinArgs g, int rows) {
+    __shared__ float sh[NT][4][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    float acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = 0.f;
+    if (i < g.M) {
+        for (long long r = (long long)blockIdx.y * 4 + rg; r < rows; r += (long long)gridDim.y * 4) {
+            const long long offa = r * g.lda + i;
+            const float a = thin_xform(g.A[offa], g, offa, i);
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                if (n < g.N) acc[n] = fmaf(a, g.B[r * g.ldb + n], acc[n]);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) sh[n][rg][lane] = acc[n];
+    __syncthreads();
+    if (rg == 0 && i < g.M) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            if (n >= g.N) continue;
+            atomicAdd(g.C + (long long)i * g.ldc + n, sh[n][0][lane] + sh[n][1][lane] + sh[n][2][lane] + sh[n][3][lane]);
+        }
+    }
+}
+
+// returns 1 if the product was handled here, 0 if the caller should use the MFMA kernels, <0 on error
+int thin_gemm_dispatch(const float* A, const float* Bm, const float* bias, float* C, int M, int N, int K, int transA,
+                       long long lda, long long rows_per_seg, long long seg_stride, int transB, long long ldb,
+                       long long ldc, int in_mode, const float* in_scale, const float* in_shift,
+                       const float* mask_src, float alpha, int accumulate, const float* out_mask, hipStream_t st) {
+    if (seg_stride != 0) return 0;
+    ThinArgs g{A, Bm, bias, C, M, N, K, lda, ldb, ldc, transB, in_mode, in_scale, in_shift, mask_src, alpha, accumulate, out_mask};
+    if (transA == 0 && N <= 4 && K >= 16 && M >= 256) {
+        int blocks = (M + 3) / 4;
+        if (blocks > 2048) blocks = 2048;
+        if (N == 1) hipLaunchKernelGGL(gemv_rows_kernel<1>, dim3(blocks), dim3(256), 0, st, g);
+        else if (N == 2) hipLaunchKernelGGL(gemv_rows_kernel<2>, dim3(blocks), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL(gemv_rows_kernel<4>, dim3(blocks), dim3(256), 0, st, g);
+        int rc = check_launch("gemv_rows");
+        return rc ? rc : 1;
+    }
+    if (transA == 0 && K <= 4 && (long long)M * N >= 65536) {
+        long long b = ((long long)M * N + 1023) / 1024;
+        if (b > 2048) b = 2048;
+        if (K == 1) hipLaunchKernelGGL(thin_k_kernel<1>, dim3((int)b), dim3(256), 0, st, g);
+        else if (K == 2) hipLaunchKernelGGL(thin_k_kernel<2>, dim3((int)b), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL(thin_k_kernel<4>, dim3((int)b), dim3(256), 0, st, g);
+        int rc = check_launch("thin_k");
+        return rc ? rc : 1;
+    }
+    if (transA == 1 && transB == 0 && N <= 2 && K >= 1024 && !bias && !out_mask && rows_per_seg >= K) {
+        if (!accumulate) {
+            hipError_t e;
+            if (ldc == N) e = hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), st);
+            else e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, st);
+            if (e != hipSuccess) { set_error("wcol: memset failed"); return PTTS_ELAUNCH; }
+        }
+        const int cb = (M + 63) / 64;
+        int rb = 1024 / cb;
+        if (rb < 1) rb = 1;
+        if (rb > 256) rb = 256;
+        if (N == 1) hipLaunchKernelGGL(wcol_kernel<1>, dim3(cb, rb), dim3(256), 0, st, g, K);
+        else hipLaunchKernelGGL(wcol_kernel<2>, dim3(cb, rb), dim3(256), 0, st, g, K);
+        int rc = check_launch("wcol");
+        return rc ? rc : 1;
+    }
+    return 0;
+}
+
+}  // namespace ptts

@@ -188,6 +188,54 @@ def test_gemm_transforms(ops):
     close(W, O.lrelu(A * sc + sh).t() @ D, rtol=2e-4, atol=1e-3, what='transA-lrelu')
 
 
+def test_gemm_thin_shapes(ops):
+    """The thin-product kernels (thin.hip): N<=4 heads, K<=4 outer products with the output mask, and 1-2 weighted
+    column sums, each with the fused transforms and strided C/mask views the Dense layers use."""
+    g = gen(14)
+    M, K = 3000, 256
+    A = torch.randn(M, K, generator=g, dtype=torch.float64)
+    msk = torch.randn(M, K, generator=g, dtype=torch.float64)
+    sc = torch.rand(K, generator=g, dtype=torch.float64) + 0.5
+    sh = torch.randn(K, generator=g, dtype=torch.float64) * 0.3
+    for N in (1, 2, 3, 4):
+        Bm = torch.randn(K, N, generator=g, dtype=torch.float64)
+        bias = torch.randn(N, generator=g, dtype=torch.float64)
+        for tb in (0, 1):
+            C = torch.empty(M, N, dtype=torch.float32, device='cuda')
+            ops.gemm_raw(dev(A), dev(Bm.t() if tb else Bm), C, M, N, K, transB=tb, bias=dev(bias), mode=ops.IN_LRELU,
+                         scale=dev(sc), shift=dev(sh))
+            close(C, O.lrelu(A * sc + sh) @ Bm + bias, rtol=2e-4, atol=2e-3, what='gemv N=%d tb=%d' % (N, tb))
+        C = torch.empty(M, N, dtype=torch.float32, device='cuda')
+        ops.gemm_raw(dev(A), dev(Bm), C, M, N, K, mode=ops.IN_MASKMUL, mask_src=dev(msk))
+        close(C, (A * torch.where(msk > 0, 1.0, 0.3)) @ Bm, rtol=2e-4, atol=2e-3, what='gemv maskmul N=%d' % N)
+    # N=4 remainder written into columns 256.. of a 260-wide C with the output mask laid out alike
+    Bm = torch.randn(K, 4, generator=g, dtype=torch.float64)
+    om = torch.randn(M, 260, generator=g, dtype=torch.float64)
+    Cw = torch.zeros(M, 260, dtype=torch.float32, device='cuda')
+    omd = dev(om)
+    ops.gemm_raw(dev(A), dev(Bm), Cw[:, 256:], M, 4, K, ldc=260, out_mask=omd[:, 256:])
+    close(Cw[:, 256:], (A @ Bm) * torch.where(om[:, 256:] > 0, 1.0, 0.3), rtol=2e-4, atol=2e-3, what='gemv strided mask')
+    assert float(Cw[:, :256].abs().max()) == 0.0
+    # K<=4 outer products
+    for Kt in (1, 2, 3, 4):
+        At = torch.randn(M, Kt, generator=g, dtype=torch.float64)
+        W = torch.randn(K, Kt, generator=g, dtype=torch.float64)     # used transposed: C = At @ W^T
+        C = torch.empty(M, K, dtype=torch.float32, device='cuda')
+        ops.gemm_raw(dev(At), dev(W), C, M, K, Kt, transB=1, out_mask=dev(msk))
+        close(C, (At @ W.t()) * torch.where(msk > 0, 1.0, 0.3), rtol=2e-4, atol=1e-4, what='thinK %d' % Kt)
+        ops.gemm_raw(dev(At), dev(W.t()), C, M, K, Kt, accumulate=1)
+        close(C, (At @ W.t()) * torch.where(msk > 0, 1.0, 0.3) + At @ W.t(), rtol=2e-4, atol=2e-4, what='thinK acc %d' % Kt)
+    # weighted column sums (weight gradient of a 1-2 wide head)
+    for N in (1, 2):
+        D = torch.randn(M, N, generator=g, dtype=torch.float64)
+        W = torch.empty(K, N, dtype=torch.float32, device='cuda')
+        ops.gemm_raw(dev(A), dev(D), W, K, N, M, transA=1, lda=K, rows_per_seg=M, mode=ops.IN_LRELU, scale=dev(sc), shift=dev(sh))
+        close(W, O.lrelu(A * sc + sh).t() @ D, rtol=2e-4, atol=5e-3, what='wcol lrelu N=%d' % N)
+        ops.gemm_raw(dev(A), dev(D), W, K, N, M, transA=1, lda=K, rows_per_seg=M, mode=ops.IN_MASKMUL, mask_src=dev(msk), accumulate=1)
+        close(W, O.lrelu(A * sc + sh).t() @ D + (A * torch.where(msk > 0, 1.0, 0.3)).t() @ D, rtol=2e-4, atol=1e-2,
+              what='wcol maskmul acc N=%d' % N)
+
+
 @pytest.mark.parametrize('mode', ['none', 'lrelu', 'affine'])
 @pytest.mark.parametrize('shape', [(2, 8, 11, 5), (3, 50, 300, 130)])
 def test_dense_forward_backward(ops, mode, shape):
