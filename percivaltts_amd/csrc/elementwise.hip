@@ -70,10 +70,15 @@ __global__ __launch_bounds__(EW_THREADS) void colreduce2_kernel(Op op, long long
     }
 }
 
-// Plain column sums / sums of squares of a [rows, C] fp32 matrix with C % 4 == 0 and C <= 1024: every lane owns four
-// adjacent channels and streams float4 (16-byte loads), fp32 partials per 16 rows folded into fp64.
-__global__ __launch_bounds__(EW_THREADS) void colstats_vec4_kernel(const float* __restrict__ x, long long rows, int C,
-                                                                   double* __restrict__ partials) {
+// Vectorised form of the two-quantity column reduction for C % 4 == 0, C <= 1024 and 16-byte aligned operands: every
+// lane owns four adjacent channels and streams float4.  The loads of VU row sweeps are issued before any of them is
+// consumed (a lone 16-byte load per lane per iteration leaves the kernel latency-bound at ~1 TB/s); fp32 partials over
+// 16 rows are folded into fp64.  Op4 provides  load(off, regs)  and  apply(off, c, regs, a[4], b[4]).
+constexpr int VU = 4;
+
+template <class Op4>
+__global__ __launch_bounds__(EW_THREADS) void colreduce2_vec4_kernel(Op4 op, long long rows, int C,
+                                                                     double* __restrict__ partials) {
     __shared__ double sh[8][EW_THREADS];
     const int tid = threadIdx.x;
     const int C4 = C / 4;
@@ -83,11 +88,25 @@ __global__ __launch_bounds__(EW_THREADS) void colstats_vec4_kernel(const float* 
     if (r < R) {
         float fs[4] = {0, 0, 0, 0}, fq[4] = {0, 0, 0, 0};
         int n = 0;
-        for (long long row = (long long)blockIdx.x * R + r; row < rows; row += (long long)gridDim.x * R) {
-            const float4 v = *reinterpret_cast<const float4*>(x + row * C + c4 * 4);
-            fs[0] += v.x; fs[1] += v.y; fs[2] += v.z; fs[3] += v.w;
-            fq[0] += v.x * v.x; fq[1] += v.y * v.y; fq[2] += v.z * v.z; fq[3] += v.w * v.w;
-            if (++n == 16) {
+        const long long step = (long long)gridDim.x * R * VU;
+        for (long long base = (long long)blockIdx.x * R * VU + r; base < rows; base += step) {
+            typename Op4::Regs regs[VU];
+#pragma unroll
+            for (int u = 0; u < VU; ++u) {
+                const long long row = base + (long long)u * R;
+                if (row < rows) op.load(row * C + c4 * 4, regs[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < VU; ++u) {
+                const long long row = base + (long long)u * R;
+                if (row < rows) {
+                    float a[4], b[4];
+                    op.apply(row * C + c4 * 4, c4 * 4, regs[u], a, b);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { fs[e] += a[e]; fq[e] += b[e]; }
+                }
+            }
+            if (++n == 16 / VU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { s[e] += fs[e]; q[e] += fq[e]; fs[e] = 0.f; fq[e] = 0.f; }
                 n = 0;
@@ -111,21 +130,24 @@ __global__ __launch_bounds__(EW_THREADS) void colstats_vec4_kernel(const float* 
     }
 }
 
-// out[j] = sum_b partials[b][j] in a fixed order.  grid = ceil(n2c/32), 256 lanes = 32 columns x 8 row groups.
+// out[j] = sum_b partials[b][j] in a fixed order.  grid = ceil(n2c/8), 256 lanes = 8 columns x 32 row groups, so
+// the serial chain per lane is nblocks/32 L2-resident loads.
 __global__ __launch_bounds__(256) void colreduce_final_kernel(const double* __restrict__ partials, int nblocks,
                                                               int n2c, double* __restrict__ out) {
-    __shared__ double sh[8][32];
-    const int jj = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int j = blockIdx.x * 32 + jj;
+    __shared__ double sh[32][8];
+    const int jj = threadIdx.x & 7, g = threadIdx.x >> 3;
+    const int j = blockIdx.x * 8 + jj;
     double s = 0.0;
-    if (j < n2c)
-        for (int b = g; b < nblocks; b += 8) s += partials[(size_t)b * n2c + j];
+    if (j < n2c) {
+#pragma unroll 4
+        for (int b = g; b < nblocks; b += 32) s += partials[(size_t)b * n2c + j];
+    }
     sh[g][jj] = s;
     __syncthreads();
     if (g == 0 && j < n2c) {
         double t = 0.0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += sh[k][jj];
+        for (int k = 0; k < 32; ++k) t += sh[k][jj];
         out[j] = t;
     }
 }
@@ -187,6 +209,74 @@ struct ActBwdOp {
         b = gd;        // dshift
     }
 };
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+struct StatsOp4 {
+    const float* x; int in_mode; const float* in_scale; const float* in_shift; const float* mask_src; float alpha;
+    struct Regs { float4 v, m; };
+    __device__ __forceinline__ void load(long long off, Regs& r) const {
+        r.v = ld4(x + off);
+        if (in_mode == PTTS_IN_MASKMUL) r.m = ld4(mask_src + off);
+    }
+    __device__ __forceinline__ void apply(long long off, int c, const Regs& r, float* a, float* b) const {
+        float v[4] = {r.v.x, r.v.y, r.v.z, r.v.w};
+        const float m[4] = {r.m.x, r.m.y, r.m.z, r.m.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (in_mode == PTTS_IN_LRELU) {
+                if (in_scale) v[e] = v[e] * in_scale[c + e] + in_shift[c + e];
+                v[e] = lrelu(v[e], alpha);
+            } else if (in_mode == PTTS_IN_MASKMUL) {
+                v[e] *= lrelu_d(m[e], alpha);
+            }
+            a[e] = v[e];
+            b[e] = v[e] * v[e];
+        }
+    }
+};
+
+struct ActBwdOp4 {
+    const float* dy; const float* x; const float* y; const float* scale; const float* shift; float* dx;
+    int act; float alpha;
+    struct Regs { float4 d, x, y; };
+    __device__ __forceinline__ void load(long long off, Regs& r) const {
+        r.d = ld4(dy + off);
+        r.x = ld4(x + off);
+        if (act == PTTS_ACT_SIGMOID || act == PTTS_ACT_TANH) r.y = ld4(y + off);
+    }
+    __device__ __forceinline__ void apply(long long off, int c, const Regs& r, float* a, float* b) const {
+        const float dv[4] = {r.d.x, r.d.y, r.d.z, r.d.w}, xv[4] = {r.x.x, r.x.y, r.x.z, r.x.w};
+        const float yv[4] = {r.y.x, r.y.y, r.y.z, r.y.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float sc = scale ? scale[c + e] : 1.f;
+            float d;
+            if (act == PTTS_ACT_LRELU) d = lrelu_d(scale ? xv[e] * sc + shift[c + e] : xv[e], alpha);
+            else if (act == PTTS_ACT_SIGMOID) d = yv[e] * (1.f - yv[e]);
+            else if (act == PTTS_ACT_TANH) d = 1.f - yv[e] * yv[e];
+            else d = 1.f;
+            const float gd = dv[e] * d;
+            o[e] = gd * sc;
+            a[e] = gd * xv[e];   // dscale
+            b[e] = gd;           // dshift
+        }
+        if (dx) *reinterpret_cast<float4*>(dx + off) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+};
+
+static inline bool al16(const void* p) { return p == nullptr || ((uintptr_t)p % 16) == 0; }
+
+// workgroups of the vectorised reduction: whole passes of R*VU rows each, at most 1024
+static int colreduce_vec4_blocks(long long rows, int C) {
+    const int R = EW_THREADS / (C / 4);
+    const long long chunks = (rows + (long long)R * VU - 1) / ((long long)R * VU);
+    const long long passes = (chunks + 1023) / 1024;
+    long long b = (chunks + passes - 1) / passes;
+    if (b < 1) b = 1;
+    return (int)b;
+}
 
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, long long count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -408,7 +498,9 @@ __global__ void adam_keras_kernel(float* __restrict__ p, const float* __restrict
 using namespace ptts;
 
 extern "C" size_t ptts_colstats_workspace_bytes(long long rows, int C) {
-    return (size_t)colreduce_blocks(rows, C) * 2 * (size_t)C * sizeof(double);
+    int nb = colreduce_blocks(rows, C);
+    if (C % 4 == 0 && C <= 4 * EW_THREADS) { const int v = colreduce_vec4_blocks(rows, C); if (v > nb) nb = v; }
+    return (size_t)nb * 2 * (size_t)C * sizeof(double);
 }
 
 template <class Op>
@@ -425,7 +517,25 @@ static int run_colreduce(const Op& op, long long rows, int C, double* out, void*
     hipLaunchKernelGGL((colreduce2_kernel<Op>), dim3(nb), dim3(EW_THREADS), 0, st, op, rows, C, (double*)workspace);
     int rc = check_launch(what);
     if (rc) return rc;
-    hipLaunchKernelGGL(colreduce_final_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st,
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((2 * C + 7) / 8), dim3(256), 0, st,
+                       (const double*)workspace, nb, 2 * C, out);
+    return check_launch(what);
+}
+
+template <class Op4>
+static int run_colreduce_vec4(const Op4& op, long long rows, int C, double* out, void* workspace,
+                              size_t workspace_bytes, hipStream_t st, const char* what) {
+    PTTS_REQUIRE(rows > 0, "%s: rows=%lld", what, rows);
+    const int nb = colreduce_vec4_blocks(rows, C);
+    const size_t need = (size_t)nb * 2 * C * sizeof(double);
+    if (!workspace || workspace_bytes < need) {
+        set_error("%s: workspace %zu < %zu", what, workspace_bytes, need);
+        return PTTS_EWORKSPACE;
+    }
+    hipLaunchKernelGGL((colreduce2_vec4_kernel<Op4>), dim3(nb), dim3(EW_THREADS), 0, st, op, rows, C, (double*)workspace);
+    int rc = check_launch(what);
+    if (rc) return rc;
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((2 * C + 7) / 8), dim3(256), 0, st,
                        (const double*)workspace, nb, 2 * C, out);
     return check_launch(what);
 }
@@ -435,21 +545,9 @@ extern "C" int ptts_colstats(const float* x, long long rows, int C, int in_mode,
                              void* workspace, size_t workspace_bytes, void* stream) {
     PTTS_REQUIRE(x && sums, "colstats: null tensor");
     PTTS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "colstats: scale/shift must come together");
-    if (in_mode == PTTS_IN_NONE && C % 4 == 0 && C <= 4 * EW_THREADS && ((uintptr_t)x % 16 == 0)) {
-        PTTS_REQUIRE(rows > 0, "colstats: rows=%lld", rows);
-        hipStream_t st = (hipStream_t)stream;
-        const int R = EW_THREADS / (C / 4);
-        long long nbl = (rows + (long long)R * 8 - 1) / ((long long)R * 8);
-        if (nbl < 1) nbl = 1;
-        if (nbl > 256) nbl = 256;
-        const int nb = (int)nbl;
-        const size_t need = (size_t)nb * 2 * C * sizeof(double);
-        if (!workspace || workspace_bytes < need) { set_error("colstats: workspace %zu < %zu", workspace_bytes, need); return PTTS_EWORKSPACE; }
-        hipLaunchKernelGGL(colstats_vec4_kernel, dim3(nb), dim3(EW_THREADS), 0, st, x, rows, C, (double*)workspace);
-        int rc = check_launch("colstats_vec4");
-        if (rc) return rc;
-        hipLaunchKernelGGL(colreduce_final_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, (const double*)workspace, nb, 2 * C, sums);
-        return check_launch("colstats_vec4_final");
+    if (C % 4 == 0 && C <= 4 * EW_THREADS && al16(x) && al16(mask_src)) {
+        StatsOp4 op4{x, in_mode, in_scale, in_shift, mask_src, alpha};
+        return run_colreduce_vec4(op4, rows, C, sums, workspace, workspace_bytes, (hipStream_t)stream, "colstats");
     }
     StatsOp op{x, in_mode, in_scale, in_shift, mask_src, alpha};
     return run_colreduce(op, rows, C, sums, workspace, workspace_bytes, (hipStream_t)stream, "colstats");
@@ -502,6 +600,10 @@ extern "C" int ptts_affine_act_bwd(const float* dy, const float* x, const float*
     PTTS_REQUIRE((scale == nullptr) == (shift == nullptr), "affine_act_bwd: scale/shift must come together");
     PTTS_REQUIRE((act != PTTS_ACT_SIGMOID && act != PTTS_ACT_TANH) || y, "affine_act_bwd: sigmoid/tanh need y");
     PTTS_REQUIRE(dsums, "affine_act_bwd: dsums required (the reduction is fused with the dx pass)");
+    if (C % 4 == 0 && C <= 4 * EW_THREADS && al16(dy) && al16(x) && al16(y) && al16(dx)) {
+        ActBwdOp4 op4{dy, x, y, scale, shift, dx, act, alpha};
+        return run_colreduce_vec4(op4, rows, C, dsums, workspace, workspace_bytes, (hipStream_t)stream, "affine_act_bwd");
+    }
     ActBwdOp op{dy, x, y, scale, shift, dx, act, alpha};
     return run_colreduce(op, rows, C, dsums, workspace, workspace_bytes, (hipStream_t)stream, "affine_act_bwd");
 }

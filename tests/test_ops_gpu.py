@@ -363,6 +363,47 @@ def test_affine_act(ops, act):
     close(ops.affine_act(dev(x2), None, None, act), f(x2), what='y-noaffine')
 
 
+@pytest.mark.parametrize('C', [256, 260, 1024, 86, 2044])
+def test_colsums_modes_wide(ops, C):
+    """Column sums / sums of squares at the layer widths of the networks, vectorised and scalar paths, all transforms."""
+    g = gen(15)
+    rows = 5003
+    x = torch.randn(rows, C, generator=g, dtype=torch.float64)
+    m = torch.randn(rows, C, generator=g, dtype=torch.float64)
+    sc = torch.rand(C, generator=g, dtype=torch.float64) + 0.5
+    sh = torch.randn(C, generator=g, dtype=torch.float64) * 0.3
+    for mode, want in ((ops.IN_NONE, x), (ops.IN_LRELU, O.lrelu(x * sc + sh)), (ops.IN_MASKMUL, x * torch.where(m > 0, 1.0, 0.3))):
+        kw = {}
+        if mode == ops.IN_LRELU:
+            kw = dict(scale=dev(sc), shift=dev(sh))
+        elif mode == ops.IN_MASKMUL:
+            kw = dict(mask_src=dev(m))
+        got = ops.colsums(dev(x), mode=mode, **kw)
+        close(got[:C], want.sum(0), rtol=1e-5, atol=2e-3, what='sum mode %d' % mode)
+        close(got[C:], (want * want).sum(0), rtol=1e-5, atol=2e-3, what='sumsq mode %d' % mode)
+
+
+@pytest.mark.parametrize('act', [None, 'lrelu', 'sigmoid', 'tanh'])
+def test_affine_act_bwd_wide(ops, act):
+    g = gen(16)
+    rows, C = 3001, 256
+    x = torch.randn(rows, C, generator=g, dtype=torch.float64)
+    sc = torch.rand(C, generator=g, dtype=torch.float64) + 0.5
+    sh = torch.randn(C, generator=g, dtype=torch.float64)
+    dy = torch.randn(rows, C, generator=g, dtype=torch.float64)
+    f = {None: lambda t: t, 'lrelu': O.lrelu, 'sigmoid': torch.sigmoid, 'tanh': torch.tanh}[act]
+    xr, scr, shr = ref(x, True), ref(sc, True), ref(sh, True)
+    yr = f(xr * scr + shr)
+    yr.backward(dy)
+    xd, scd, shd = dev(x, True), dev(sc, True), dev(sh, True)
+    yd = ops.affine_act(xd, scd, shd, act)
+    close(yd, yr, what='y')
+    yd.backward(dev(dy))
+    close(xd.grad, xr.grad, what='dx')
+    close(scd.grad, scr.grad, rtol=2e-4, atol=2e-3, what='dscale')
+    close(shd.grad, shr.grad, rtol=2e-4, atol=2e-3, what='dshift')
+
+
 @pytest.mark.parametrize('case', [(3, 7, 5, 4), (16, 20, 24, 64), (5, 33, 10, 70), (20, 9, 12, 32), (64, 6, 40, 256)])
 def test_blstm(ops, case):
     B, T, In, H = case
