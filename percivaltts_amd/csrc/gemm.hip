@@ -61,7 +61,10 @@ __device__ __forceinline__ long long rowbase(const GemmArgs& g, int r) {
     return (long long)seg * g.seg_stride + (long long)(r - seg * rps) * g.lda;
 }
 
-struct Frag { float a[NLD][4]; float b[NLD][4]; };
+// One k-step of operands in flight: raw A and B quads, the GP mask quads (MASKMUL) and the BN affine of this lane's
+// four channels (LRELU).  The transform is applied when the registers are written to LDS -- after the MFMAs of the
+// current k-step -- so that nothing waits on the loads before the matrix pipe has its work.
+struct Frag { f32x4u a[NLD], b[NLD], m[NLD], sc, sh; };
 
 // 4 consecutive floats along the contiguous index c of a row; CHECK guards row validity and the end of the row.
 template <bool CHECK>
@@ -77,13 +80,12 @@ __device__ __forceinline__ f32x4u load4(const float* __restrict__ p, bool row_ok
     return v;
 }
 
-// Stage one 128xBK tile of A and one BKx128 tile of B into registers.  All loads are issued before any is used;
-// the transform of the previous layer is applied afterwards.  CHECK=false for interior tiles and full k-steps.
+// Issue the loads of one 128xBK tile of A and one BKx128 tile of B.  CHECK=false for interior tiles and full k-steps.
+// Out-of-range elements load as 0 (also scale/shift), and an out-of-range row of one operand always meets zeros of
+// the other or an output row that is never stored, so no masking is needed after the affine.
 template <int TRANSA, int TRANSB, int MODE, bool CHECK>
 __device__ __forceinline__ void load_tiles(const GemmArgs& g, int m0, int n0, int k0, Frag& fr) {
     const int tid = threadIdx.x;
-    f32x4u va[NLD], vb[NLD], vm[NLD];
-    int cha[NLD];
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
         const int q = tid + j * GEMM_THREADS;
@@ -91,60 +93,59 @@ __device__ __forceinline__ void load_tiles(const GemmArgs& g, int m0, int n0, in
             const int m = m0 + q / KQ, k = k0 + (q % KQ) * 4;
             const bool ok = !CHECK || m < g.M;
             const long long offa = rowbase(g, ok ? m : 0) + k;
-            cha[j] = k;
-            va[j] = load4<CHECK>(g.A + offa, ok, k, g.K);
-            if (MODE == PTTS_IN_MASKMUL) vm[j] = load4<CHECK>(g.mask_src + offa, ok, k, g.K);
+            fr.a[j] = load4<CHECK>(g.A + offa, ok, k, g.K);
+            if (MODE == PTTS_IN_MASKMUL) fr.m[j] = load4<CHECK>(g.mask_src + offa, ok, k, g.K);
         } else {
             const int k = k0 + q / (BM / 4), m = m0 + (q % (BM / 4)) * 4;
             const bool ok = !CHECK || k < g.K;
             const long long offa = rowbase(g, ok ? k : 0) + m;
-            cha[j] = m;
-            va[j] = load4<CHECK>(g.A + offa, ok, m, g.M);
-            if (MODE == PTTS_IN_MASKMUL) vm[j] = load4<CHECK>(g.mask_src + offa, ok, m, g.M);
+            fr.a[j] = load4<CHECK>(g.A + offa, ok, m, g.M);
+            if (MODE == PTTS_IN_MASKMUL) fr.m[j] = load4<CHECK>(g.mask_src + offa, ok, m, g.M);
         }
         if (TRANSB == 0) {
             const int k = k0 + q / (BN / 4), n = n0 + (q % (BN / 4)) * 4;
             const bool ok = !CHECK || k < g.K;
-            vb[j] = load4<CHECK>(g.B + (long long)(ok ? k : 0) * g.ldb + n, ok, n, g.N);
+            fr.b[j] = load4<CHECK>(g.B + (long long)(ok ? k : 0) * g.ldb + n, ok, n, g.N);
         } else {
             const int n = n0 + q / KQ, k = k0 + (q % KQ) * 4;
             const bool ok = !CHECK || n < g.N;
-            vb[j] = load4<CHECK>(g.B + (long long)(ok ? n : 0) * g.ldb + k, ok, k, g.K);
+            fr.b[j] = load4<CHECK>(g.B + (long long)(ok ? n : 0) * g.ldb + k, ok, k, g.K);
         }
     }
-#pragma unroll
-    for (int j = 0; j < NLD; ++j) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v = va[j][e];
-            if (MODE == PTTS_IN_LRELU) {
-                // out-of-range elements were loaded as 0 and must stay 0 after the affine: mask them
-                const int ch = cha[j] + e;
-                const bool inr = !CHECK || ch < (TRANSA == 0 ? g.K : g.M);
-                if (g.in_scale) v = inr ? v * g.in_scale[inr ? ch : 0] + g.in_shift[inr ? ch : 0] : 0.f;
-                v = lrelu(v, g.alpha);
-            } else if (MODE == PTTS_IN_MASKMUL) {
-                v *= lrelu_d(vm[j][e], g.alpha);
-            }
-            fr.a[j][e] = v;
-            fr.b[j][e] = vb[j][e];
-        }
+    if (MODE == PTTS_IN_LRELU && g.in_scale) {
+        // the channel is the stored column of A: the same four for every quad of this lane
+        const int ch = TRANSA == 0 ? k0 + (tid % KQ) * 4 : m0 + (tid % (BM / 4)) * 4;
+        const int lim = TRANSA == 0 ? g.K : g.M;
+        fr.sc = load4<true>(g.in_scale + ch, true, ch, lim);
+        fr.sh = load4<true>(g.in_shift + ch, true, ch, lim);
     }
 }
 
-template <int TRANSA, int TRANSB>
-__device__ __forceinline__ void store_tiles(float* As, float* Bs, const Frag& fr) {
+template <int TRANSA, int TRANSB, int MODE>
+__device__ __forceinline__ void store_tiles(const GemmArgs& g, float* As, float* Bs, const Frag& fr) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
         const int q = tid + j * GEMM_THREADS;
+        float a[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = fr.a[j][e];
+            if (MODE == PTTS_IN_LRELU) {
+                if (g.in_scale) v = v * fr.sc[e] + fr.sh[e];
+                v = lrelu(v, g.alpha);
+            } else if (MODE == PTTS_IN_MASKMUL) {
+                v *= lrelu_d(fr.m[j][e], g.alpha);
+            }
+            a[e] = v;
+        }
         if (TRANSA == 0) {
             const int m = q / KQ, k = (q % KQ) * 4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) As[(k + e) * LDA_S + m] = fr.a[j][e];
+            for (int e = 0; e < 4; ++e) As[(k + e) * LDA_S + m] = a[e];
         } else {
             const int k = q / (BM / 4), m = (q % (BM / 4)) * 4;
-            *reinterpret_cast<float4*>(As + k * LDA_S + m) = make_float4(fr.a[j][0], fr.a[j][1], fr.a[j][2], fr.a[j][3]);
+            *reinterpret_cast<float4*>(As + k * LDA_S + m) = make_float4(a[0], a[1], a[2], a[3]);
         }
         if (TRANSB == 0) {
             const int k = q / (BN / 4), n = (q % (BN / 4)) * 4;
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_mfma_kernel(GemmArgs g)
             else load_tiles<TRANSA, TRANSB, MODE, true>(g, m0, n0, k0, fr);
         };
         load(kbeg);
-        store_tiles<TRANSA, TRANSB>(As[0], Bs[0], fr);
+        store_tiles<TRANSA, TRANSB, MODE>(g, As[0], Bs[0], fr);
         __syncthreads();
         int buf = 0;
         for (int k0 = kbeg; k0 < kend; k0 += BK, buf ^= 1) {
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_mfma_kernel(GemmArgs g)
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[kk][1], rb[kk][0], acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[kk][1], rb[kk][1], acc[1][1], 0, 0, 0);
             }
-            if (more) store_tiles<TRANSA, TRANSB>(As[buf ^ 1], Bs[buf ^ 1], fr);
+            if (more) store_tiles<TRANSA, TRANSB, MODE>(g, As[buf ^ 1], Bs[buf ^ 1], fr);
             __syncthreads();
         }
 
@@ -246,7 +247,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_mfma_kernel(GemmArgs g)
             }
     }
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // "Tall" GEMM: M >> N, 128 < N <= 256 (every hidden-width product of the networks: the context Conv1D, the Dense
@@ -280,10 +280,9 @@ __global__ __launch_bounds__(TALL_THREADS) void gemm_tall_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4c){0.f, 0.f, 0.f, 0.f};
 
-    float fa[NA][4], fb[NB][4];
+    // raw operands of the next k-step; the transform of A is applied when they are written to LDS (after the MFMAs)
+    f32x4u va[NA], vm[NA], vb[NB], vsc, vsh;
     auto load = [&](int k0, bool check) {
-        f32x4u va[NA], vm[NA], vb[NB];
-        int cha[NA];
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int qq = tid + j * TALL_THREADS;               // (row, k-quad)
@@ -291,7 +290,6 @@ __global__ __launch_bounds__(TALL_THREADS) void gemm_tall_kernel(GemmArgs g) {
             const int m = m0 + row;
             const bool ok = row < TBM && (!check || m < g.M);
             const long long offa = rowbase(g, ok ? m : 0) + k;
-            cha[j] = k;
             if (check) {
                 va[j] = load4<true>(g.A + offa, ok, k, g.K);
                 if (MODE == PTTS_IN_MASKMUL) vm[j] = load4<true>(g.mask_src + offa, ok, k, g.K);
@@ -315,25 +313,11 @@ __global__ __launch_bounds__(TALL_THREADS) void gemm_tall_kernel(GemmArgs g) {
                               : *reinterpret_cast<const f32x4u*>(g.B + (long long)n * g.ldb + k);
             }
         }
-#pragma unroll
-        for (int j = 0; j < NA; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = va[j][e];
-                if (MODE == PTTS_IN_LRELU) {
-                    const int ch = cha[j] + e;
-                    const bool inr = !check || ch < g.K;
-                    if (g.in_scale) v = inr ? v * g.in_scale[inr ? ch : 0] + g.in_shift[inr ? ch : 0] : 0.f;
-                    v = lrelu(v, g.alpha);
-                } else if (MODE == PTTS_IN_MASKMUL) {
-                    v *= lrelu_d(vm[j][e], g.alpha);
-                }
-                fa[j][e] = v;
-            }
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) fb[j][e] = vb[j][e];
+        if (MODE == PTTS_IN_LRELU && g.in_scale) {      // this lane's four channels (k-quad) of the k-step
+            const int ch = k0 + (tid & 3) * 4;
+            vsc = load4<true>(g.in_scale + ch, true, ch, g.K);
+            vsh = load4<true>(g.in_shift + ch, true, ch, g.K);
+        }
     };
     auto store = [&](float* as, float* bs) {
 #pragma unroll
@@ -342,7 +326,16 @@ __global__ __launch_bounds__(TALL_THREADS) void gemm_tall_kernel(GemmArgs g) {
             const int row = qq >> 2, k = (qq & 3) * 4;
             if (row < TBM) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) as[(k + e) * TLDA + row] = fa[j][e];
+                for (int e = 0; e < 4; ++e) {
+                    float v = va[j][e];
+                    if (MODE == PTTS_IN_LRELU) {
+                        if (g.in_scale) v = v * vsc[e] + vsh[e];
+                        v = lrelu(v, g.alpha);
+                    } else if (MODE == PTTS_IN_MASKMUL) {
+                        v *= lrelu_d(vm[j][e], g.alpha);
+                    }
+                    as[(k + e) * TLDA + row] = v;
+                }
             }
         }
 #pragma unroll
@@ -350,11 +343,11 @@ __global__ __launch_bounds__(TALL_THREADS) void gemm_tall_kernel(GemmArgs g) {
             const int qq = tid + j * TALL_THREADS;
             if (TRANSB == 0) {
                 const int k = qq >> 6, n = (qq & 63) * 4;
-                *reinterpret_cast<float4*>(bs + k * TLDB + n) = make_float4(fb[j][0], fb[j][1], fb[j][2], fb[j][3]);
+                *reinterpret_cast<float4*>(bs + k * TLDB + n) = make_float4(vb[j][0], vb[j][1], vb[j][2], vb[j][3]);
             } else {
                 const int n = qq >> 2, k = (qq & 3) * 4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) bs[(k + e) * TLDB + n] = fb[j][e];
+                for (int e = 0; e < 4; ++e) bs[(k + e) * TLDB + n] = vb[j][e];
             }
         }
     };
@@ -385,28 +378,57 @@ __global__ __launch_bounds__(TALL_THREADS) void gemm_tall_kernel(GemmArgs g) {
         if (more) store(As[buf ^ 1], Bs[buf ^ 1]);
         __syncthreads();
     }
-    // epilogue: 16x16 C/D layout: col = lane&15, row = 4*(lane>>4) + r
+    // epilogue: the 16x16 C/D layout (col = lane&15, row = 4*(lane>>4) + r) would store 64-byte pieces; each 16-row
+    // band is instead passed through the (now free) B buffers so that C and the output mask move as whole 1 KB rows.
+    const int col4 = (tid & 63) * 4, erow = tid >> 6;        // this lane's 4 columns and row (of 8) in the band halves
+    float bv[4];
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-        const int n = wave * (16 * NTW) + j * 16 + r16;
-        if (n >= g.N) continue;
-        const float bv = g.bias ? g.bias[n] : 0.f;
+    for (int e = 0; e < 4; ++e) bv[e] = (g.bias && col4 + e < g.N) ? g.bias[col4 + e] : 0.f;
+    const bool vec = (g.N == TBN) && (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0) &&
+                     (!g.out_mask || (reinterpret_cast<uintptr_t>(g.out_mask) & 15) == 0);
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MT; ++i) {
+        float* sb = Bs[i & 1];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + i * 16 + q * 4 + r;
-                if (m >= g.M) continue;
-                const long long off = (long long)m * g.ldc + n;
-                float v = acc[i][j][r] + bv;
-                if (g.out_mask) v *= lrelu_d(g.out_mask[off], g.out_alpha);
-                if (g.accumulate) g.C[off] += v; else g.C[off] = v;
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sb[(q * 4 + r) * TLDB + wave * (16 * NTW) + j * 16 + r16] = acc[i][j][r];
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = erow + 8 * h;
+            const int m = m0 + i * 16 + row;
+            if (m >= g.M) continue;
+            const float4 t = *reinterpret_cast<const float4*>(sb + row * TLDB + col4);
+            float v[4] = {t.x + bv[0], t.y + bv[1], t.z + bv[2], t.w + bv[3]};
+            const long long off = (long long)m * g.ldc + col4;
+            if (vec) {
+                if (g.out_mask) {
+                    const float4 mk = *reinterpret_cast<const float4*>(g.out_mask + off);
+                    v[0] *= lrelu_d(mk.x, g.out_alpha); v[1] *= lrelu_d(mk.y, g.out_alpha);
+                    v[2] *= lrelu_d(mk.z, g.out_alpha); v[3] *= lrelu_d(mk.w, g.out_alpha);
+                }
+                float4* cp = reinterpret_cast<float4*>(g.C + off);
+                if (g.accumulate) { const float4 o = *cp; v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+                *cp = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (col4 + e >= g.N) continue;
+                    float w = v[e];
+                    if (g.out_mask) w *= lrelu_d(g.out_mask[off + e], g.out_alpha);
+                    if (g.accumulate) g.C[off + e] += w; else g.C[off + e] = w;
+                }
             }
+        }
     }
 }
 
 // rows per workgroup (multiple of 16, <= 128) that best fills 256 CUs in whole rounds
 static int pick_tall_mt(int M) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("PTTS_TALL_MT"); forced = e ? atoi(e) : 0; }
+    if (forced >= 2 && forced <= 8) return forced;
     int best = 8; double best_eff = -1.0;
     for (int mt = 4; mt <= 8; ++mt) {
         const long long blocks = (M + 16 * mt - 1) / (16 * mt);
@@ -425,6 +447,12 @@ static bool thin_enabled() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("PTTS_GEMM_THIN"); v = e ? atoi(e) : 1; }
     return v != 0;
+}
+
+static long long gemm_slots() {
+    static long long slots_env = -1;
+    if (slots_env < 0) { const char* e = getenv("PTTS_GEMM_SLOTS"); slots_env = e ? atoll(e) : 0; }
+    return slots_env > 0 ? slots_env : 512;
 }
 
 extern "C" int ptts_gemm(const float* A, const float* Bm, const float* bias, float* C, int M, int N, int K,
@@ -473,6 +501,8 @@ extern "C" int ptts_gemm(const float* A, const float* Bm, const float* bias, flo
 #define PTTS_TALL(TB, MD, MTT) hipLaunchKernelGGL((gemm_tall_kernel<TB, MD, MTT>), tgrid, tblock, 0, st, g)
 #define PTTS_TALL_MT(TB, MD)                                          \
         switch (mt) {                                                 \
+            case 2: PTTS_TALL(TB, MD, 2); break;                      \
+            case 3: PTTS_TALL(TB, MD, 3); break;                      \
             case 4: PTTS_TALL(TB, MD, 4); break;                      \
             case 5: PTTS_TALL(TB, MD, 5); break;                      \
             case 6: PTTS_TALL(TB, MD, 6); break;                      \
@@ -501,7 +531,7 @@ extern "C" int ptts_gemm(const float* A, const float* Bm, const float* bias, flo
     // 8 k-steps of work each
     // stream-K pays when the tile count loads the 512 workgroup slots unevenly AND K is deep enough to amortise
     // the atomic epilogue; otherwise one workgroup per tile (plain stores).
-    const long long slots = 512;
+    const long long slots = gemm_slots();
     const double eff_dp = (double)tiles / (double)(((tiles + slots - 1) / slots) * slots);
     long long workers;
     // (atomic combination makes the last bits order-dependent: it is kept for the deep products only, K >= 4096)
