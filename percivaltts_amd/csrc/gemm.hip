@@ -42,6 +42,7 @@ struct GemmArgs {
     int tiles_n, ksteps;          // tiles along N; k-steps per tile
     long long iters_total;        // tiles * ksteps
     int workers;
+    int prio;                     // raise the issue priority of the second half of the grid (see the kernel)
 };
 
 __device__ __forceinline__ float a_transform(float v, const GemmArgs& g, long long off, int ch) {
@@ -168,6 +169,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_mfma_kernel(GemmArgs g)
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int l31 = lane & 31, lh = lane >> 5;
 
+    // Two workgroups share a CU and run the same program: left alone they fall into lockstep (MFMA phases together,
+    // then load/store/barrier phases together with the matrix pipe idle).  Giving one of the pair -- the second half
+    // of the grid, dispatched onto the CUs the first half already occupies -- a higher issue priority breaks the tie.
+    if (g.prio && (int)blockIdx.x >= (int)(gridDim.x / 2)) __builtin_amdgcn_s_setprio(3);
     // this workgroup's contiguous share of the (tile, k-step) space
     long long it = g.iters_total * blockIdx.x / g.workers;
     const long long it_end = g.iters_total * (blockIdx.x + 1) / g.workers;
@@ -475,6 +480,9 @@ extern "C" int ptts_gemm(const float* A, const float* Bm, const float* bias, flo
     g.in_mode = in_mode; g.in_scale = in_scale; g.in_shift = in_shift; g.mask_src = mask_src; g.alpha = alpha;
     g.accumulate = accumulate;
     g.out_mask = out_mask; g.out_alpha = alpha;
+    static int prio = -1;
+    if (prio < 0) { const char* e = getenv("PTTS_GEMM_PRIO"); prio = e ? atoi(e) : 1; }
+    g.prio = prio;
     // thin products (N <= 4 heads, K <= 4 outer products, 1-2 weighted column sums) never reach the MFMA tiles
     if (thin_enabled()) {
         const int thin = thin_gemm_dispatch(A, Bm, bias, C, M, N, K, transA, lda, rows_per_seg, seg_stride, transB, ldb, ldc,

