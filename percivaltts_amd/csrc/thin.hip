@@ -27,12 +27,76 @@ __device__ __forceinline__ float thin_xform(float v, const ThinArgs& g, long lon
     return v;
 }
 
-// one wave per row; A row-major with leading dim lda (transA = 0)
-template <int NT>
+__device__ __forceinline__ float4 thin_xform4(float4 v, float4 m, const ThinArgs& g, int ch) {
+    float a[4] = {v.x, v.y, v.z, v.w};
+    const float mm[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (g.in_mode == PTTS_IN_LRELU) {
+            if (g.in_scale) a[e] = a[e] * g.in_scale[ch + e] + g.in_shift[ch + e];
+            a[e] = lrelu(a[e], g.alpha);
+        } else if (g.in_mode == PTTS_IN_MASKMUL) {
+            a[e] *= lrelu_d(mm[e], g.alpha);
+        }
+    }
+    return make_float4(a[0], a[1], a[2], a[3]);
+}
+
+// one wave per row; A row-major with leading dim lda (transA = 0).  VEC: K % 4 == 0, K <= 256 and 16-byte aligned
+// rows -- one float4 of A per lane and row, B held in registers (NT x 4 values per lane), two rows in flight.
+template <int NT, bool VEC>
 __global__ __launch_bounds__(256) void gemv_rows_kernel(ThinArgs g) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const int nwaves = gridDim.x * 4;
+    if (VEC) {
+        const int k = lane * 4;
+        const bool on = k < g.K;
+        float w[NT][4];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                w[n][e] = (on && n < g.N) ? (g.transB ? g.B[(long long)n * g.ldb + k + e] : g.B[(long long)(k + e) * g.ldb + n]) : 0.f;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int m = wave; m < g.M; m += 2 * nwaves) {
+            const int m2 = m + nwaves;
+            const bool two = m2 < g.M;
+            const long long r1 = (long long)m * g.lda + k, r2 = (long long)(two ? m2 : m) * g.lda + k;
+            float4 a1 = on ? *reinterpret_cast<const float4*>(g.A + r1) : z4;
+            float4 a2 = on ? *reinterpret_cast<const float4*>(g.A + r2) : z4;
+            float4 k1 = z4, k2 = z4;
+            if (g.in_mode == PTTS_IN_MASKMUL && on) {
+                k1 = *reinterpret_cast<const float4*>(g.mask_src + r1);
+                k2 = *reinterpret_cast<const float4*>(g.mask_src + r2);
+            }
+            if (on) { a1 = thin_xform4(a1, k1, g, k); a2 = thin_xform4(a2, k2, g, k); }
+            float acc1[NT], acc2[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                acc1[n] = a1.x * w[n][0] + a1.y * w[n][1] + a1.z * w[n][2] + a1.w * w[n][3];
+                acc2[n] = a2.x * w[n][0] + a2.y * w[n][1] + a2.z * w[n][2] + a2.w * w[n][3];
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) { acc1[n] = wave_sum(acc1[n]); acc2[n] = wave_sum(acc2[n]); }
+            if (lane == 0) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (h == 1 && !two) break;
+                    const int mm = h ? m2 : m;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        if (n >= g.N) continue;
+                        const long long off = (long long)mm * g.ldc + n;
+                        float v = (h ? acc2[n] : acc1[n]) + (g.bias ? g.bias[n] : 0.f);
+                        if (g.out_mask) v *= lrelu_d(g.out_mask[off], g.alpha);
+                        if (g.accumulate) g.C[off] += v; else g.C[off] = v;
+                    }
+                }
+            }
+        }
+        return;
+    }
     for (int m = wave; m < g.M; m += nwaves) {
         float acc[NT];
 #pragma unroll
@@ -59,9 +123,39 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(ThinArgs g) {
     }
 }
 
-// K <= 4: each lane produces consecutive columns of one row
-template <int KT>
+// K <= 4: C[m, :] = sum_k A[m,k] * B(k, :).  VEC: N % 4 == 0 and 16-byte aligned C / mask rows -- a float4 of C per lane.
+template <int KT, bool VEC>
 __global__ __launch_bounds__(256) void thin_k_kernel(ThinArgs g) {
+    if (VEC) {
+        const int n4 = g.N / 4;
+        const long long total = (long long)g.M * n4;
+        for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+            const int m = (int)(i / n4);
+            const int n = (int)(i - (long long)m * n4) * 4;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = g.bias ? g.bias[n + e] : 0.f;
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                if (k >= g.K) continue;
+                const long long offa = (long long)m * g.lda + k;
+                const float a = thin_xform(g.A[offa], g, offa, k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = fmaf(a, g.transB ? g.B[(long long)(n + e) * g.ldb + k] : g.B[(long long)k * g.ldb + n + e], v[e]);
+            }
+            const long long off = (long long)m * g.ldc + n;
+            if (g.out_mask) {
+                const float4 mk = *reinterpret_cast<const float4*>(g.out_mask + off);
+                v[0] *= lrelu_d(mk.x, g.alpha); v[1] *= lrelu_d(mk.y, g.alpha);
+                v[2] *= lrelu_d(mk.z, g.alpha); v[3] *= lrelu_d(mk.w, g.alpha);
+            }
+            float4* cp = reinterpret_cast<float4*>(g.C + off);
+            if (g.accumulate) { const float4 o = *cp; v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+            *cp = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        return;
+    }
     const long long total = (long long)g.M * g.N;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int n = (int)(i % g.N);
@@ -82,10 +176,12 @@ __global__ __launch_bounds__(256) void thin_k_kernel(ThinArgs g) {
 
 // C[i, n] = sum_r T(A[r, i]) * B[r, n],  n < N <= 2,  A stored [Kr rows][Mo cols] (the transA = 1 operand).
 // Lanes along the columns i (coalesced rows), 4 row groups per workgroup, LDS combine, one fp32 atomic per (i, n).
+// (A float4-per-lane variant with batched loads was slower: the contended atomics on the few output addresses, not the
+// row stream, set the time of this kernel.)
 template <int NT>
 __global__ __launch_bounds__(256) void wcol_kernel(ThinArgs g, int rows) {
-    __shared__ float sh[NT][4][64];
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    __shared__ float sh[NT][4][64];
     const int i = blockIdx.x * 64 + lane;
     float acc[NT];
 #pragma unroll
@@ -111,6 +207,8 @@ __global__ __launch_bounds__(256) void wcol_kernel(ThinArgs g, int rows) {
     }
 }
 
+static inline bool thin_al16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 // returns 1 if the product was handled here, 0 if the caller should use the MFMA kernels, <0 on error
 int thin_gemm_dispatch(const float* A, const float* Bm, const float* bias, float* C, int M, int N, int K, int transA,
                        long long lda, long long rows_per_seg, long long seg_stride, int transB, long long ldb,
@@ -121,18 +219,26 @@ int thin_gemm_dispatch(const float* A, const float* Bm, const float* bias, float
     if (transA == 0 && N <= 4 && K >= 16 && M >= 256) {
         int blocks = (M + 3) / 4;
         if (blocks > 2048) blocks = 2048;
-        if (N == 1) hipLaunchKernelGGL(gemv_rows_kernel<1>, dim3(blocks), dim3(256), 0, st, g);
-        else if (N == 2) hipLaunchKernelGGL(gemv_rows_kernel<2>, dim3(blocks), dim3(256), 0, st, g);
-        else hipLaunchKernelGGL(gemv_rows_kernel<4>, dim3(blocks), dim3(256), 0, st, g);
+        const bool vec = K % 4 == 0 && K <= 256 && lda % 4 == 0 && thin_al16(A) && thin_al16(mask_src);
+#define PTTS_GEMV(NTT) do { if (vec) hipLaunchKernelGGL((gemv_rows_kernel<NTT, true>), dim3(blocks), dim3(256), 0, st, g); \
+                            else hipLaunchKernelGGL((gemv_rows_kernel<NTT, false>), dim3(blocks), dim3(256), 0, st, g); } while (0)
+        if (N == 1) PTTS_GEMV(1);
+        else if (N == 2) PTTS_GEMV(2);
+        else PTTS_GEMV(4);
+#undef PTTS_GEMV
         int rc = check_launch("gemv_rows");
         return rc ? rc : 1;
     }
     if (transA == 0 && K <= 4 && (long long)M * N >= 65536) {
         long long b = ((long long)M * N + 1023) / 1024;
         if (b > 2048) b = 2048;
-        if (K == 1) hipLaunchKernelGGL(thin_k_kernel<1>, dim3((int)b), dim3(256), 0, st, g);
-        else if (K == 2) hipLaunchKernelGGL(thin_k_kernel<2>, dim3((int)b), dim3(256), 0, st, g);
-        else hipLaunchKernelGGL(thin_k_kernel<4>, dim3((int)b), dim3(256), 0, st, g);
+        const bool vec = N % 4 == 0 && ldc % 4 == 0 && thin_al16(C) && thin_al16(out_mask);
+#define PTTS_THINK(KTT) do { if (vec) hipLaunchKernelGGL((thin_k_kernel<KTT, true>), dim3((int)b), dim3(256), 0, st, g); \
+                             else hipLaunchKernelGGL((thin_k_kernel<KTT, false>), dim3((int)b), dim3(256), 0, st, g); } while (0)
+        if (K == 1) PTTS_THINK(1);
+        else if (K == 2) PTTS_THINK(2);
+        else PTTS_THINK(4);
+#undef PTTS_THINK
         int rc = check_launch("thin_k");
         return rc ? rc : 1;
     }
