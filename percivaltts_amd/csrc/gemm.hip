@@ -429,6 +429,221 @@ __global__ __launch_bounds__(TALL_THREADS) void gemm_tall_kernel(GemmArgs g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tall GEMM, k-contiguous A tile, BKT = 16 or 32 per k-step.  Same ownership as gemm_tall_kernel (TBM x 256 outputs per
+// workgroup, wave w owns columns [32w, 32w+32)), different data path:
+//  * the A tile keeps the global layout [row][k] in LDS (row stride BKT+8 floats: conflict-free ds_read_b128), staged
+//    with one ds_write_b128 per quad; a lane fetches four k-values of a row with ONE ds_read_b128.  MFMA number e of a
+//    16-wide k-group multiplies the k-set {e, 4+e, 8+e, 12+e} (the sum over k does not care about the order) and B is
+//    read at rows 4*q + e;
+//  * every fragment of a 16-wide k-group is requested before its 8*MT MFMAs, and with BKT = 32 the second group's
+//    fragments are requested before the first group's MFMAs issue, so one barrier is amortised over 16*MT MFMAs.
+// ------------------------------------------------------------------------------------------------
+template <int TRANSB, int MODE, int MT, int BKT>
+__global__ __launch_bounds__(TALL_THREADS) void gemm_tall_kc_kernel(GemmArgs g) {
+    constexpr int TBM = 16 * MT;
+    constexpr int SA = BKT + 8;                 // 24 / 40: both conflict-free for the b128 fragment reads
+    constexpr int QR = BKT / 4;                 // quads per A row (and per B row when B is stored [n][k])
+    constexpr int KG = BKT / 16;                // 16-wide k-groups per k-step
+    __shared__ __attribute__((aligned(16))) float As[2][TBM * SA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BKT * TLDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.x * TBM;
+    const bool interior = (m0 + TBM <= g.M) && (g.N == TBN);
+    constexpr int NA = (TBM * QR + TALL_THREADS - 1) / TALL_THREADS;
+    constexpr int NB = TBN * QR / TALL_THREADS;
+
+    f32x4c acc[MT][NTW];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4c){0.f, 0.f, 0.f, 0.f};
+
+    // Loop-invariant addresses of this lane's quads: the row base of A (one 32-bit division each, done once) and the
+    // B column / row; a k-step adds k0 (or k0*ldb).  Rows beyond M are clamped to row 0 and flagged.
+    const float* pa[NA]; const float* pm[NA]; bool oka[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int qq = tid + j * TALL_THREADS;
+        const int row = qq / QR;
+        oka[j] = row < TBM && m0 + row < g.M;
+        const long long base = rowbase(g, oka[j] ? m0 + row : 0) + (qq % QR) * 4;
+        pa[j] = g.A + base;
+        pm[j] = MODE == PTTS_IN_MASKMUL ? g.mask_src + base : nullptr;
+    }
+    const float* pb[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int qq = tid + j * TALL_THREADS;
+        if (TRANSB == 0) pb[j] = g.B + (long long)(qq >> 6) * g.ldb + (qq & 63) * 4;
+        else pb[j] = g.B + (long long)((qq / QR) < g.N ? (qq / QR) : 0) * g.ldb + (qq % QR) * 4;
+    }
+    const long long bstep = TRANSB == 0 ? g.ldb : 1;     // B pointer advance per unit of k
+
+    struct Stage { f32x4u va[NA], vm[NA], vb[NB], vsc, vsh; };
+    auto load = [&](int k0, bool check, Stage& sg) {
+        const f32x4u z4 = {0.f, 0.f, 0.f, 0.f};
+        if (!check) {
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                sg.va[j] = oka[j] ? *reinterpret_cast<const f32x4u*>(pa[j] + k0) : z4;
+                if (MODE == PTTS_IN_MASKMUL) sg.vm[j] = oka[j] ? *reinterpret_cast<const f32x4u*>(pm[j] + k0) : z4;
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) sg.vb[j] = *reinterpret_cast<const f32x4u*>(pb[j] + k0 * bstep);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const int k = k0 + ((tid + j * TALL_THREADS) % QR) * 4;
+                sg.va[j] = load4<true>(pa[j] + k0, oka[j], k, g.K);
+                if (MODE == PTTS_IN_MASKMUL) sg.vm[j] = load4<true>(pm[j] + k0, oka[j], k, g.K);
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int qq = tid + j * TALL_THREADS;
+                if (TRANSB == 0) {                          // stored [k][n]
+                    const int k = k0 + (qq >> 6), n = (qq & 63) * 4;
+                    const bool ok = k < g.K;
+                    sg.vb[j] = load4<true>(ok ? pb[j] + k0 * bstep : g.B, ok, n, g.N);
+                } else {                                    // stored [n][k]
+                    const int n = qq / QR, k = k0 + (qq % QR) * 4;
+                    sg.vb[j] = load4<true>(pb[j] + k0, n < g.N, k, g.K);
+                }
+            }
+        }
+        if (MODE == PTTS_IN_LRELU && g.in_scale) {      // this lane's four channels (k-quad) of the k-step
+            const int ch = k0 + (tid % QR) * 4;
+            sg.vsc = load4<true>(g.in_scale + ch, true, ch, g.K);
+            sg.vsh = load4<true>(g.in_shift + ch, true, ch, g.K);
+        }
+    };
+    auto store = [&](float* as, float* bs, const Stage& sg) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int qq = tid + j * TALL_THREADS;
+            const int row = qq / QR, k = (qq % QR) * 4;
+            if (row < TBM) {
+                float t[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = sg.va[j][e];
+                    if (MODE == PTTS_IN_LRELU) {
+                        if (g.in_scale) v = v * sg.vsc[e] + sg.vsh[e];
+                        v = lrelu(v, g.alpha);
+                    } else if (MODE == PTTS_IN_MASKMUL) {
+                        v *= lrelu_d(sg.vm[j][e], g.alpha);
+                    }
+                    t[e] = v;
+                }
+                *reinterpret_cast<float4*>(as + row * SA + k) = make_float4(t[0], t[1], t[2], t[3]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int qq = tid + j * TALL_THREADS;
+            if (TRANSB == 0) {
+                const int k = qq >> 6, n = (qq & 63) * 4;
+                *reinterpret_cast<float4*>(bs + k * TLDB + n) = make_float4(sg.vb[j][0], sg.vb[j][1], sg.vb[j][2], sg.vb[j][3]);
+            } else {
+                const int n = qq / QR, k = (qq % QR) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bs[(k + e) * TLDB + n] = sg.vb[j][e];
+            }
+        }
+    };
+    auto compute = [&](int buf) {
+        const float* as = As[buf] + r16 * SA + 4 * q;
+        const float* bs = Bs[buf] + (4 * q) * TLDB + wave * (16 * NTW) + r16;
+        float4 fa[KG][MT];
+        float fb[KG][4][NTW];
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[kg][i] = *reinterpret_cast<const float4*>(as + i * 16 * SA + kg * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) fb[kg][e][j] = bs[(kg * 16 + e) * TLDB + j * 16];
+        }
+        __builtin_amdgcn_sched_barrier(0);      // every fragment of the k-step is requested before the first MFMA
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const float av = e == 0 ? fa[kg][i].x : e == 1 ? fa[kg][i].y : e == 2 ? fa[kg][i].z : fa[kg][i].w;
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, fb[kg][e][j], acc[i][j], 0, 0, 0);
+                }
+    };
+
+    // Two register stages: the loads of k-step s+2 are issued before the MFMAs of step s and the loads of step s+1
+    // (issued one step earlier) are written to LDS after them, so every global load has two k-steps to arrive.
+    const int K = g.K;
+    auto chk = [&](int k0) { return !(interior && k0 + BKT <= K); };
+    Stage s0, s1;
+    load(0, chk(0), s0);
+    store(As[0], Bs[0], s0);
+    if (BKT < K) load(BKT, chk(BKT), s1);
+    __syncthreads();
+    auto step = [&](int k0, int buf, const Stage& pend, Stage& next) {
+        if (k0 + 2 * BKT < K) load(k0 + 2 * BKT, chk(k0 + 2 * BKT), next);
+        compute(buf);
+        if (k0 + BKT < K) store(As[buf ^ 1], Bs[buf ^ 1], pend);
+        __syncthreads();
+    };
+    for (int k0 = 0; k0 < K; k0 += 2 * BKT) {
+        step(k0, 0, s1, s0);
+        if (k0 + BKT < K) step(k0 + BKT, 1, s0, s1);
+    }
+    // epilogue: each 16-row band goes through the (now free) B buffers so that C and the output mask move as whole rows
+    const int col4 = (tid & 63) * 4, erow = tid >> 6;
+    float bv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = (g.bias && col4 + e < g.N) ? g.bias[col4 + e] : 0.f;
+    const bool vec = (g.N == TBN) && (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0) &&
+                     (!g.out_mask || (reinterpret_cast<uintptr_t>(g.out_mask) & 15) == 0);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        float* sb = Bs[i & 1];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sb[(q * 4 + r) * TLDB + wave * (16 * NTW) + j * 16 + r16] = acc[i][j][r];
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = erow + 8 * h;
+            const int m = m0 + i * 16 + row;
+            if (m >= g.M) continue;
+            const float4 t = *reinterpret_cast<const float4*>(sb + row * TLDB + col4);
+            float v[4] = {t.x + bv[0], t.y + bv[1], t.z + bv[2], t.w + bv[3]};
+            const long long off = (long long)m * g.ldc + col4;
+            if (vec) {
+                if (g.out_mask) {
+                    const float4 mk = *reinterpret_cast<const float4*>(g.out_mask + off);
+                    v[0] *= lrelu_d(mk.x, g.out_alpha); v[1] *= lrelu_d(mk.y, g.out_alpha);
+                    v[2] *= lrelu_d(mk.z, g.out_alpha); v[3] *= lrelu_d(mk.w, g.out_alpha);
+                }
+                float4* cp = reinterpret_cast<float4*>(g.C + off);
+                if (g.accumulate) { const float4 o = *cp; v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+                *cp = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (col4 + e >= g.N) continue;
+                    float w = v[e];
+                    if (g.out_mask) w *= lrelu_d(g.out_mask[off + e], g.out_alpha);
+                    if (g.accumulate) g.C[off + e] += w; else g.C[off + e] = w;
+                }
+            }
+        }
+    }
+}
+
 // rows per workgroup (multiple of 16, <= 128) that best fills 256 CUs in whole rounds
 static int pick_tall_mt(int M) {
     static int forced = -1;
@@ -483,6 +698,7 @@ extern "C" int ptts_gemm(const float* A, const float* Bm, const float* bias, flo
     static int prio = -1;
     if (prio < 0) { const char* e = getenv("PTTS_GEMM_PRIO"); prio = e ? atoi(e) : 1; }
     g.prio = prio;
+
     // thin products (N <= 4 heads, K <= 4 outer products, 1-2 weighted column sums) never reach the MFMA tiles
     if (thin_enabled()) {
         const int thin = thin_gemm_dispatch(A, Bm, bias, C, M, N, K, transA, lda, rows_per_seg, seg_stride, transB, ldb, ldc,
@@ -506,7 +722,11 @@ extern "C" int ptts_gemm(const float* A, const float* Bm, const float* bias, flo
     if (transA == 0 && N > 128 && N <= TBN && M >= 2048 && K <= 2048) {
         const int mt = pick_tall_mt(M);
         dim3 tgrid((M + 16 * mt - 1) / (16 * mt)), tblock(TALL_THREADS);
-#define PTTS_TALL(TB, MD, MTT) hipLaunchKernelGGL((gemm_tall_kernel<TB, MD, MTT>), tgrid, tblock, 0, st, g)
+        static int kc = -1;
+        if (kc < 0) { const char* e = getenv("PTTS_TALL_KC"); kc = e ? atoi(e) : 16; }
+#define PTTS_TALL(TB, MD, MTT) do { if (kc == 32) hipLaunchKernelGGL((gemm_tall_kc_kernel<TB, MD, MTT, 32>), tgrid, tblock, 0, st, g); \
+                                    else if (kc == 16) hipLaunchKernelGGL((gemm_tall_kc_kernel<TB, MD, MTT, 16>), tgrid, tblock, 0, st, g); \
+                                    else hipLaunchKernelGGL((gemm_tall_kernel<TB, MD, MTT>), tgrid, tblock, 0, st, g); } while (0)
 #define PTTS_TALL_MT(TB, MD)                                          \
         switch (mt) {                                                 \
             case 2: PTTS_TALL(TB, MD, 2); break;                      \
