@@ -81,11 +81,51 @@ __device__ __forceinline__ f32x4u load4(const float* __restrict__ p, bool row_ok
     return v;
 }
 
+// Row addressing of this lane's A quads, kept out of the k-loop: the 32-bit division of rowbase() costs ~40 vector
+// instructions, and four of them per k-step were a sixth of the MFMA time of a step.
+//  TRANSA == 0: the stored rows (m) are fixed for a tile: one division per quad per tile.
+//  TRANSA == 1: the stored row is k; (segment, row in segment) advance by BK per k-step without dividing.
+struct ARows {
+    long long base[NLD];     // TRANSA == 0: element offset of the row;  TRANSA == 1: unused
+    int seg[NLD], rem[NLD];  // TRANSA == 1: segment and row-in-segment of this lane's k row at the current k-step
+};
+
+template <int TRANSA>
+__device__ __forceinline__ void arows_begin(const GemmArgs& g, int m0, int k0, ARows& ar) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int q = tid + j * GEMM_THREADS;
+        if (TRANSA == 0) {
+            const int m = m0 + q / KQ;
+            ar.base[j] = rowbase(g, m < g.M ? m : 0);
+        } else {
+            const int k = k0 + q / (BM / 4);
+            const int rps = (int)g.rows_per_seg;
+            ar.seg[j] = k / rps;
+            ar.rem[j] = k - ar.seg[j] * rps;
+        }
+    }
+}
+
+template <int TRANSA>
+__device__ __forceinline__ void arows_advance(const GemmArgs& g, ARows& ar) {
+    if (TRANSA == 1) {
+        const int rps = (int)g.rows_per_seg;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            ar.rem[j] += BK;
+            while (ar.rem[j] >= rps) { ar.rem[j] -= rps; ++ar.seg[j]; }
+        }
+    }
+}
+
 // Issue the loads of one 128xBK tile of A and one BKx128 tile of B.  CHECK=false for interior tiles and full k-steps.
 // Out-of-range elements load as 0 (also scale/shift), and an out-of-range row of one operand always meets zeros of
 // the other or an output row that is never stored, so no masking is needed after the affine.
+// `ar` must describe k-step k0 (arows_begin at the first step of a tile segment, arows_advance after every load).
 template <int TRANSA, int TRANSB, int MODE, bool CHECK>
-__device__ __forceinline__ void load_tiles(const GemmArgs& g, int m0, int n0, int k0, Frag& fr) {
+__device__ __forceinline__ void load_tiles(const GemmArgs& g, int m0, int n0, int k0, const ARows& ar, Frag& fr) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
@@ -93,13 +133,13 @@ __device__ __forceinline__ void load_tiles(const GemmArgs& g, int m0, int n0, in
         if (TRANSA == 0) {
             const int m = m0 + q / KQ, k = k0 + (q % KQ) * 4;
             const bool ok = !CHECK || m < g.M;
-            const long long offa = rowbase(g, ok ? m : 0) + k;
+            const long long offa = ar.base[j] + k;
             fr.a[j] = load4<CHECK>(g.A + offa, ok, k, g.K);
             if (MODE == PTTS_IN_MASKMUL) fr.m[j] = load4<CHECK>(g.mask_src + offa, ok, k, g.K);
         } else {
             const int k = k0 + q / (BM / 4), m = m0 + (q % (BM / 4)) * 4;
             const bool ok = !CHECK || k < g.K;
-            const long long offa = rowbase(g, ok ? k : 0) + m;
+            const long long offa = (ok ? (long long)ar.seg[j] * g.seg_stride + (long long)ar.rem[j] * g.lda : 0) + m;
             fr.a[j] = load4<CHECK>(g.A + offa, ok, m, g.M);
             if (MODE == PTTS_IN_MASKMUL) fr.m[j] = load4<CHECK>(g.mask_src + offa, ok, m, g.M);
         }
@@ -196,9 +236,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_mfma_kernel(GemmArgs g)
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
         Frag fr;
-        auto load = [&](int k0) {
-            if (interior && k0 + BK <= g.K) load_tiles<TRANSA, TRANSB, MODE, false>(g, m0, n0, k0, fr);
-            else load_tiles<TRANSA, TRANSB, MODE, true>(g, m0, n0, k0, fr);
+        ARows ar;
+        arows_begin<TRANSA>(g, m0, kbeg, ar);
+        auto load = [&](int k0) {           // called for kbeg, kbeg + BK, ... in order
+            if (interior && k0 + BK <= g.K) load_tiles<TRANSA, TRANSB, MODE, false>(g, m0, n0, k0, ar, fr);
+            else load_tiles<TRANSA, TRANSB, MODE, true>(g, m0, n0, k0, ar, fr);
+            arows_advance<TRANSA>(g, ar);
         };
         load(kbeg);
         store_tiles<TRANSA, TRANSB, MODE>(g, As[0], Bs[0], fr);
@@ -719,7 +762,9 @@ extern "C" int ptts_gemm(const float* A, const float* Bm, const float* bias, flo
     }
     // tall products (M >> N, N in (128, 256]) take the full-width tile kernel: A read once, one round, no atomics
     // (for deep K the stream-K 128x128 kernel below is faster: its two co-resident workgroups per CU overlap better)
-    if (transA == 0 && N > 128 && N <= TBN && M >= 2048 && K <= 2048) {
+    static int tall_kmax = -1;
+    if (tall_kmax < 0) { const char* e = getenv("PTTS_TALL_KMAX"); tall_kmax = e ? atoi(e) : 2048; }
+    if (transA == 0 && N > 128 && N <= TBN && M >= 2048 && K <= tall_kmax) {
         const int mt = pick_tall_mt(M);
         dim3 tgrid((M + 16 * mt - 1) / (16 * mt)), tblock(TALL_THREADS);
         static int kc = -1;

@@ -4,7 +4,7 @@
 set -u
 TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
-mkdir -p $OUT
+rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err
 echo "trace done" > $OUT/progress.txt
