@@ -40,6 +40,7 @@ def parse():
     ap.add_argument('--graph', action='store_true', help='capture each step once and replay it as a hipGraph (single stream)')
     ap.add_argument('--eager', action='store_true', help='(default) eager launches; kept for compatibility')
     ap.add_argument('--no-prune', action='store_true', help="also run G's f0/noise branches in the critic step")
+    ap.add_argument('--no-stack', action='store_true', help='evaluate critic(real) and critic(fake) separately instead of as one 2B pass')
     ap.add_argument('--no-streams', action='store_true', help='single HIP stream (default: the three critic evaluations and the BLSTM branch on side streams)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -221,6 +222,7 @@ def main():
     cfg.train_wgan_hipgraph = bool(args.graph) and world == 1
     cfg.train_wgan_prune_dead_branches = not args.no_prune
     cfg.train_wgan_parallel_streams = (not args.no_streams) and not cfg.train_wgan_hipgraph
+    cfg.train_wgan_stack_real_fake = not args.no_stack
     spec, nm = 65, 20
     voc = vocoders.VocoderPML(16000, 0.005, spec, nm)
     import io, contextlib

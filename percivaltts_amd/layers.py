@@ -167,7 +167,12 @@ class Dense(Layer):
                     y = ops.dense(part, wpart, bias)
                     if memo is not None and i > 0:
                         memo[key] = y
-                z = y if z is None else z + y
+                if z is not None and y.shape[0] != z.shape[0]:
+                    # a part shared by several stacked evaluations (forward_multi with a k*B variant): broadcast it
+                    k = z.shape[0] // y.shape[0]
+                    z = (z.view((k,) + tuple(y.shape)) + y).view(z.shape)
+                else:
+                    z = y if z is None else z + y
         else:
             z = ops.dense(v, self.kernel, self.bias)
         return _apply_activation(z, self.activation)

@@ -105,7 +105,8 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         cfg.train_wgan_weight_clip = None             # c > 0: clamp critic weights to [-c, c] after each critic update
         cfg.train_wgan_prune_dead_branches = True
         cfg.train_wgan_hipgraph = False
-        cfg.train_wgan_parallel_streams = False      # the three critic evaluations on three HIP streams
+        cfg.train_wgan_parallel_streams = False      # the critic evaluations on separate HIP streams
+        cfg.train_wgan_stack_real_fake = True        # critic(real) and critic(fake) as one stacked 2B pass (exact: no BatchNorm)
         return cfg
 
     # ---------------------------------------------------------------------------------------------------------
@@ -201,13 +202,31 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         if fake is None:
             fake = self._fake_sample(X, training)
         x_hat = RandomWeightedAverage(X.shape[0])([Y, fake], alpha).requires_grad_(True)
-        valid, fake_v, v_hat = self.critic_net.forward_multi(0, [Y, fake, x_hat], [X], training=training,
-                                                               parallel_streams=bool(getattr(self.cfg, 'train_wgan_parallel_streams', False)))
+        streams = bool(getattr(self.cfg, 'train_wgan_parallel_streams', False))
+        if getattr(self.cfg, 'train_wgan_stack_real_fake', True) and self._critic_is_per_sample():
+            # the critic has no BatchNorm, so critic(real) and critic(fake) are one pass over the stacked 2B batch: half the
+            # launches and one weight-gradient product per layer instead of two (the context branch stays shared, at B)
+            B = Y.shape[0]
+            both, v_hat = self.critic_net.forward_multi(0, [torch.cat([Y, fake], 0), x_hat], [X], training=training,
+                                                        parallel_streams=streams)
+            valid, fake_v = both[:B], both[B:]
+        else:
+            valid, fake_v, v_hat = self.critic_net.forward_multi(0, [Y, fake, x_hat], [X], training=training,
+                                                                   parallel_streams=streams)
         l_valid = wasserstein_loss(-1.0, valid)
         l_fake = wasserstein_loss(+1.0, fake_v)
         gp = gradient_penalty_loss(None, v_hat, x_hat)
         total = l_valid + l_fake + float(self.cfg.train_wgan_pg_lambda) * gp
         return total, (l_valid, l_fake, gp)
+
+    def _critic_is_per_sample(self):
+        """True when no critic layer couples the samples of a batch (no BatchNormalization): stacking evaluations is exact."""
+        ok = getattr(self, '_critic_per_sample', None)
+        if ok is None:
+            from . import layers as _layers
+            ok = not any(isinstance(l, _layers.BatchNormalization) for l in self.critic_net.layers_list)
+            self._critic_per_sample = ok
+        return ok
 
     def generator_loss(self, X, Y, training=True):
         pred = self._model.kerasmodel(X, training=training)
