@@ -251,23 +251,24 @@ def main():
     torch.cuda.synchronize(); parallel.barrier()
     dt = parallel.max_over_ranks(time.time() - t0, dev)
 
-    # separate timings of the two step kinds (eager or graph as configured), rank 0 only
+    # separate timings of the two step kinds (eager or graph as configured) and the roofline leg.  Every rank runs them
+    # (the steps contain the gradient all-reduce: a collective only rank 0 entered would hang the job); rank 0 reports.
     extra = {}
-    if rank == 0:
-        X, Y = batches[0]
-        def timeit(fn, n):
-            fn(); torch.cuda.synchronize()
-            t = time.time()
-            for _ in range(n): fn()
-            torch.cuda.synchronize()
-            return (time.time() - t) / n * 1e3
-        use_graph = bool(cfg.train_wgan_hipgraph)
-        extra['critic_step_ms'] = timeit((lambda: opt._graphed('critic', X, Y)) if use_graph else (lambda: opt.critic_step(X, Y)), 10)
-        extra['generator_step_ms'] = timeit((lambda: opt._graphed('generator', X, Y)) if use_graph else (lambda: opt.generator_step(X, Y)), 5)
-        if not args.no_roofline:
-            extra.update(roofline_leg(opt, X, Y, args))
-        if not args.no_cpu_baseline and world == 1:
-            extra['cpu_baseline'] = cpu_baseline(args, (args.ctx, spec, nm))
+    X, Y = batches[0]
+    def timeit(fn, n):
+        fn(); torch.cuda.synchronize()
+        t = time.time()
+        for _ in range(n): fn()
+        torch.cuda.synchronize()
+        return (time.time() - t) / n * 1e3
+    use_graph = bool(cfg.train_wgan_hipgraph)
+    extra['critic_step_ms'] = timeit((lambda: opt._graphed('critic', X, Y)) if use_graph else (lambda: opt.critic_step(X, Y)), 10)
+    extra['generator_step_ms'] = timeit((lambda: opt._graphed('generator', X, Y)) if use_graph else (lambda: opt.generator_step(X, Y)), 5)
+    if not args.no_roofline:
+        extra.update(roofline_leg(opt, X, Y, args))
+    parallel.barrier()
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        extra['cpu_baseline'] = cpu_baseline(args, (args.ctx, spec, nm))
 
     if rank == 0:
         frames = float(args.steps) * B * T * world

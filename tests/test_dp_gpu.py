@@ -90,3 +90,21 @@ def test_two_ranks_equal_manual_gradient_averaging():
     torch.cuda.synchronize()
     np.testing.assert_allclose(res[0][1], opt.critic_opti.flat.flat.cpu().numpy(), rtol=2e-4, atol=2e-6)
     np.testing.assert_allclose(res[0][2], opt.gen_opti.flat.flat.cpu().numpy(), rtol=2e-4, atol=2e-6)
+
+
+def test_bench_two_ranks_prints_one_line():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank; here gloo and both
+    ranks on the one GPU): every collective must be entered by both ranks, rank 0 prints ONE JSON line."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PTTS_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--batch', '4', '--frames', '40', '--no-cpu-baseline']
+    out = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, lines
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['config']['global_batch'] == 8 and res['scaling'] == 'weak'
+    assert res['value'] > 0 and 'roofline' in res
