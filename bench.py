@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--no-streams', action='store_true', help='single HIP stream (default: the three critic evaluations and the BLSTM branch on side streams)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-host-leg', action='store_true', help='skip the PCIe-inclusive leg (host batches through the prefetcher)')
     ap.add_argument('--cpu-batch', type=int, default=32)
     return ap.parse_args()
 
@@ -266,6 +267,23 @@ def main():
     extra['generator_step_ms'] = timeit((lambda: opt._graphed('generator', X, Y)) if use_graph else (lambda: opt.generator_step(X, Y)), 5)
     if not args.no_roofline:
         extra.update(roofline_leg(opt, X, Y, args))
+    if not args.no_host_leg:
+        # PCIe-inclusive rate: the same steps fed from host numpy batches through the double-buffered prefetcher
+        # (data.BatchPrefetcher: loader thread + copy stream), as the training driver feeds train_on_batch.  Never `value`.
+        from percivaltts_amd import data
+        pool = [(bx.cpu().numpy(), by.cpu().numpy()) for bx, by in batches]
+        nh = max(6, min(args.steps, 30))
+        pf = data.BatchPrefetcher(lambda i: pool[i % nbuf], nh, device=dev, depth=2)
+        parallel.barrier(); torch.cuda.synchronize()
+        th = time.time()
+        for i, (hx, hy) in enumerate(pf):
+            opt.device_step(i, hx, hy)
+        torch.cuda.synchronize(); parallel.barrier()
+        dth = parallel.max_over_ranks(time.time() - th, dev)
+        pf.close()
+        extra['pcie_inclusive'] = {'value': nh * B * T * world / dth, 'unit': 'frames/s', 'steps': nh,
+                                   'ms_per_step': dth / nh * 1e3, 'host_bytes_per_step': int(sum(a.nbytes for a in pool[0])),
+                                   'how': 'host numpy batches -> loader thread -> H2D on a copy stream, 2 batches ahead (data.BatchPrefetcher)'}
     parallel.barrier()
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         extra['cpu_baseline'] = cpu_baseline(args, (args.ctx, spec, nm))

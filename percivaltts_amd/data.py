@@ -240,3 +240,126 @@ def prediction_rms(mod, Xs):
         s += np.sum(ypred[0,] ** 2)
         nbel += ypred[0,].size
     return float(np.sqrt(s / nbel))
+
+
+class BatchPrefetcher(object):
+    """Double-buffered batch pipeline in front of `train_on_batch`.
+
+    The reference loads the files of a batch, builds the numpy arrays and only then trains on them, every batch
+    (optimizertts.py:230-232), so a sub-15 ms device step would wait on numpy I/O and on a synchronous host-to-device
+    copy.  Here a worker thread calls `make_batch(i)` (any function returning a tuple of float32 numpy arrays, e.g.
+    `load_inoutset` of the i-th list of file ids) for i = 0..n-1 and issues the host-to-device copies on a dedicated
+    HIP copy stream; the consumer iterates over device tensors and its stream waits on the copy's event, not on the
+    host.  `depth` batches are in flight (2 = double buffering).  stage_pinned=True first copies each array into a
+    reusable pinned buffer (a slot is rewritten only after its DMA completed) -- useful when the loader can fill such
+    a buffer directly; for numpy arrays that already exist it measured slower than letting the runtime stage them.
+
+    device=None (or a CPU device) gives the same iterator without pinning or streams (host tests).
+    """
+
+    _END = object()
+
+    def __init__(self, make_batch, n, device=None, depth=2, stage_pinned=False):
+        import threading
+        try:
+            import queue
+        except ImportError:      # pragma: no cover
+            import Queue as queue
+        import torch
+        self._torch = torch
+        self._make, self._n, self._depth = make_batch, int(n), max(1, int(depth))
+        self._device = torch.device(device) if device is not None else torch.device('cpu')
+        self._cuda = self._device.type == 'cuda'
+        if self._cuda and self._device.index is None:
+            self._device = torch.device('cuda', torch.cuda.current_device())
+        self._stage = bool(stage_pinned)
+        self._q = queue.Queue(maxsize=self._depth)
+        self._slots = [None] * (self._depth + 1)      # pinned buffers (+1: one is being filled while `depth` are queued)
+        self._events = [None] * (self._depth + 1)
+        self._copy_stream = torch.cuda.Stream(device=self._device) if self._cuda else None
+        self._stop = False
+        self.load_seconds = 0.0
+        self._thread = threading.Thread(target=self._work, name='ptts-prefetch')
+        self._thread.daemon = True
+        self._thread.start()
+
+    def _pinned(self, slot, k, shape):
+        torch = self._torch
+        bufs = self._slots[slot]
+        if bufs is None:
+            bufs = self._slots[slot] = {}
+        need = int(np.prod(shape))
+        b = bufs.get(k)
+        if b is None or b.numel() < need:
+            b = bufs[k] = torch.empty(need, dtype=torch.float32).pin_memory()
+        return b[:need].view(*shape)
+
+    def _work(self):
+        torch = self._torch
+        try:
+            if self._cuda:
+                torch.cuda.set_device(self._device)
+            for i in range(self._n):
+                if self._stop:
+                    break
+                t0 = time.time()
+                arrays = self._make(i)
+                self.load_seconds += time.time() - t0
+                if not isinstance(arrays, (tuple, list)):
+                    arrays = (arrays,)
+                if not self._cuda:
+                    item = tuple(torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)) for a in arrays)
+                    self._q.put((item, None))
+                    continue
+                slot = i % len(self._slots)
+                outs = []
+                with torch.cuda.stream(self._copy_stream):
+                    for k, a in enumerate(arrays):
+                        a = np.ascontiguousarray(a, dtype=np.float32)
+                        d = torch.empty(a.shape, dtype=torch.float32, device=self._device)
+                        if self._stage:
+                            if self._events[slot] is not None:
+                                self._events[slot].synchronize()      # the copy that last read this pinned slot is done
+                            pin = self._pinned(slot, k, a.shape)
+                            np.copyto(pin.numpy(), a)                 # single-threaded memcpy, interpreter lock released
+                            d.copy_(pin, non_blocking=True)
+                        else:
+                            # pageable source: the HIP runtime stages it through its own pinned chunks, pipelined with the
+                            # DMA (measured 1.1 ms for 61 MB, against 10 ms for a host-side copy into a pinned buffer plus the
+                            # DMA); the call blocks this loader thread only
+                            d.copy_(torch.from_numpy(a))
+                        outs.append(d)
+                    ev = self._copy_stream.record_event()
+                self._events[slot] = ev
+                self._q.put((tuple(outs), ev))
+            self._q.put((self._END, None))
+        except BaseException as e:       # hand the failure to the consumer instead of dying silently
+            self._q.put((e, None))
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        item, ev = self._q.get()
+        if item is self._END:
+            self._q.put((self._END, None))
+            raise StopIteration
+        if isinstance(item, BaseException):
+            raise item
+        if ev is not None:
+            cur = self._torch.cuda.current_stream(self._device)
+            cur.wait_event(ev)
+            for t in item:
+                t.record_stream(cur)       # allocated on the copy stream, consumed here
+        return item
+
+    next = __next__
+
+    def close(self):
+        self._stop = True
+        try:
+            while True:
+                self._q.get_nowait()
+        except Exception:
+            pass
+        self._thread.join(timeout=10.0)

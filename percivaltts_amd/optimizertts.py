@@ -162,15 +162,20 @@ class OptimizerTTS:
             np.random.shuffle(rndidx)
             rndidxb = np.split(rndidx, nbbatches)
             costs_tra_batches, load_times, train_times = [], [], []
-            for batchid in range(nbbatches):
-                t0 = time.time()
-                print_tty('\r    Training batch {}/{}'.format(1 + batchid, nbbatches))
+            def make_batch(batchid, rndidxb=rndidxb):
                 fid_lst_trab = [fid_lst_tra[bidx] for bidx in rndidxb[batchid]]
                 X_trab, Y_trab, W_trab = data.load_inoutset(
                     indir, outdir, wdir, fid_lst_trab, length=self.cfg.train_batch_length,
                     lengthmax=self.cfg.train_batch_lengthmax, maskpadtype=self.cfg.train_batch_padtype,
                     cropmode=self.cfg.train_batch_cropmode)
-                load_times.append(time.time() - t0)
+                return self._local_shard(X_trab, Y_trab)      # only this rank's shard crosses PCIe
+
+            # batches are loaded, pinned and copied to the device two ahead of the step that consumes them
+            prefetch = data.BatchPrefetcher(make_batch, nbbatches, device=self.device, depth=2)
+            for batchid, (X_trab, Y_trab) in enumerate(self._closing(prefetch)):
+                t0 = time.time()
+                print_tty('\r    Training batch {}/{}'.format(1 + batchid, nbbatches))
+                load_times.append(prefetch.load_seconds - sum(load_times))
                 print_tty(' (iter load: {:.6f}s); training '.format(load_times[-1]))
 
                 t1 = time.time()
@@ -298,16 +303,36 @@ class OptimizerTTS:
     def prepare(self):
         print('    Prepare LSE training')
         self.device = self._model.to_device()
-        parallel.init()
+        self.world, self.rank = parallel.init()
         self.opti = KerasAdam(self._model.kerasmodel, self.device, lr=10 ** self.cfg.train_lse_learningrate_log10,
                               beta_1=self.cfg.train_lse_adam_beta1, beta_2=self.cfg.train_lse_adam_beta2,
                               epsilon=10 ** self.cfg.train_lse_adam_epsilon_log10)
         print('    optimizer: Adam')
 
+    @staticmethod
+    def _closing(prefetch):
+        """Iterate a BatchPrefetcher and stop its worker thread whatever ends the loop (NaN guard, KeyboardInterrupt)."""
+        try:
+            for item in prefetch:
+                yield item
+        finally:
+            prefetch.close()
+
+    def _local_shard(self, X, Y):
+        """Host (numpy) batches are the global batch: keep this rank's rows.  Device tensors come from
+        data.BatchPrefetcher, whose loader already cut the shard before it crossed PCIe."""
+        if getattr(self, 'world', 1) > 1 and not torch.is_tensor(X):
+            lo, hi = parallel.shard_batch(X.shape[0], self.world, self.rank)
+            return X[lo:hi], Y[lo:hi]
+        return X, Y
+
     def _to_dev(self, a):
+        if torch.is_tensor(a):            # already resident (data.BatchPrefetcher)
+            return a.to(device=self.device, dtype=torch.float32)
         return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(self.device)
 
     def train_on_batch(self, batchid, X_trab, Y_trab):
+        X_trab, Y_trab = self._local_shard(X_trab, Y_trab)
         X, Y = self._to_dev(X_trab), self._to_dev(Y_trab)
         self.opti.zero_grad()
         pred = self._model.kerasmodel(X, training=True)

@@ -300,9 +300,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
 
     # ---- the reference's hooks --------------------------------------------------------------------------------------
     def train_on_batch(self, batchid, X_trab, Y_trab):
-        if self.world > 1:
-            lo, hi = parallel.shard_batch(X_trab.shape[0], self.world, self.rank)
-            X_trab, Y_trab = X_trab[lo:hi], Y_trab[lo:hi]
+        X_trab, Y_trab = self._local_shard(X_trab, Y_trab)
         X, Y = self._to_dev(X_trab), self._to_dev(Y_trab)
         lc, lg = self.device_step(batchid, X, Y)
         self.costs_tra_critic_batches.append(float(lc.item()))

@@ -163,3 +163,30 @@ def test_data_batching(tmp_path):
             return np.zeros((1, x.shape[1], 5), dtype=np.float32)
     assert abs(data.cost_model_prediction_rmse(Stub(), [X], Y) - data.cost_0pred_rmse(Y)) < 1e-6
     assert data.prediction_rms(Stub(), [X]) == 0.0
+
+
+def test_batch_prefetcher_host_mode_order_and_errors():
+    """data.BatchPrefetcher without a GPU: same iterator (order, contents, length), loader failures reach the consumer."""
+    import numpy as np
+    import pytest
+    from percivaltts_amd import data
+
+    def make(i):
+        return np.full((2, 3), float(i), dtype=np.float32), np.arange(4, dtype=np.float64) + i
+
+    got = list(data.BatchPrefetcher(make, 5, device=None, depth=2))
+    assert len(got) == 5
+    for i, (x, y) in enumerate(got):
+        assert x.dtype.is_floating_point and tuple(x.shape) == (2, 3) and float(x[0, 0]) == float(i)
+        assert np.allclose(y.numpy(), np.arange(4) + i)
+
+    def bad(i):
+        if i == 2:
+            raise IOError('missing file')
+        return (np.zeros(3, dtype=np.float32),)
+
+    it = data.BatchPrefetcher(bad, 4, device=None)
+    next(it); next(it)
+    with pytest.raises(IOError):
+        next(it)
+    it.close()

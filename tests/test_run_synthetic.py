@@ -46,3 +46,25 @@ def test_run_training_continue_generate(tmp_path, monkeypatch):
     y = np.fromfile(outs[0], dtype=np.float32).reshape(-1, 163)
     assert y.shape[0] >= 90 and np.isfinite(y).all()
     assert (y[:, 130:] > 0).all() and (y[:, 130:] < 1).all()     # sigmoid noise-mask head
+
+
+@pytest.mark.gpu
+def test_batch_prefetcher_device_mode():
+    """data.BatchPrefetcher on the GPU: pinned slots are reused only after their copy completed (more batches than
+    slots, each with its own contents), tensors arrive on the device in order, shapes may change between batches."""
+    import numpy as np
+    import torch
+    from percivaltts_amd import data
+
+    rng = np.random.RandomState(0)
+    host = [(rng.randn(3 + (i % 2), 50, 7).astype(np.float32), rng.randn(3 + (i % 2), 50, 2).astype(np.float32)) for i in range(9)]
+    for stage in (False, True):
+        pf = data.BatchPrefetcher(lambda i: host[i], len(host), device='cuda', depth=2, stage_pinned=stage)
+        n = 0
+        for i, (x, y) in enumerate(pf):
+            assert x.is_cuda and y.is_cuda and x.dtype == torch.float32
+            # consume on the current stream (the iterator made it wait for the copy)
+            assert torch.equal(x.cpu(), torch.from_numpy(host[i][0])) and torch.equal(y.cpu(), torch.from_numpy(host[i][1]))
+            n += 1
+        assert n == len(host)
+        pf.close()
