@@ -297,184 +297,20 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_mfma_kernel(GemmArgs g)
 }
 
 // ------------------------------------------------------------------------------------------------
-// "Tall" GEMM: M >> N, 128 < N <= 256 (every hidden-width product of the networks: the context Conv1D, the Dense
-// layers forward and backward-data).  One workgroup owns TBM x 256 outputs -- ALL columns -- so A is streamed from
-// HBM/L2 exactly once and TBM is chosen so that ceil(M/TBM) fills the 256 CUs in one round (M = 25 600 -> TBM = 112 ->
-// 229 workgroups).  No split, no atomics: bitwise reproducible.  v_mfma_f32_16x16x4_f32 (same rate as 32x32x2);
-// 8 waves, wave w owns columns [32w, 32w+32) x all TBM/16 row tiles (14 accumulator tiles at TBM = 112).
+// "Tall" GEMM: M >> N, 128 < N <= 256, K <= 2048 (the Dense layers forward and backward-data).  One workgroup owns
+// TBM x 256 outputs -- ALL columns -- so A is streamed from HBM/L2 exactly once and TBM is chosen so that ceil(M/TBM)
+// fills the 256 CUs in one round (M = 25 600 -> TBM = 112 -> 229 workgroups).  No split, no atomics: bitwise
+// reproducible.  v_mfma_f32_16x16x4_f32; 8 waves, wave w owns columns [32w, 32w+32) x all TBM/16 row tiles
+// (14 accumulator tiles at TBM = 112).
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4c __attribute__((ext_vector_type(4)));
-constexpr int TBN = 256, TBK = 16;
+constexpr int TBN = 256;
 constexpr int TALL_THREADS = 512;            // 8 waves: two per SIMD hide each other's LDS latency and barriers
 constexpr int NTW = TBN / 16 / (TALL_THREADS / 64);   // column tiles of 16 per wave (2)
 constexpr int TLDB = TBN + 4;
 
-template <int TRANSB, int MODE, int MT /* row tiles of 16: TBM = 16*MT */>
-__global__ __launch_bounds__(TALL_THREADS) void gemm_tall_kernel(GemmArgs g) {
-    constexpr int TBM = 16 * MT;
-    constexpr int TLDA = TBM + 4;
-    __shared__ __attribute__((aligned(16))) float As[2][TBK * TLDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][TBK * TLDB];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r16 = lane & 15, q = lane >> 4;
-    const int m0 = blockIdx.x * TBM;
-    const bool interior = (m0 + TBM <= g.M) && (g.N == TBN);
-    constexpr int NA = (TBM * TBK / 4 + TALL_THREADS - 1) / TALL_THREADS;   // float4 per lane for A (rows x 4 quads)
-    constexpr int NB = TBN * TBK / 4 / TALL_THREADS;
-
-    f32x4c acc[MT][NTW];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4c){0.f, 0.f, 0.f, 0.f};
-
-    // raw operands of the next k-step; the transform of A is applied when they are written to LDS (after the MFMAs)
-    f32x4u va[NA], vm[NA], vb[NB], vsc, vsh;
-    auto load = [&](int k0, bool check) {
-#pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int qq = tid + j * TALL_THREADS;               // (row, k-quad)
-            const int row = qq >> 2, k = k0 + (qq & 3) * 4;
-            const int m = m0 + row;
-            const bool ok = row < TBM && (!check || m < g.M);
-            const long long offa = rowbase(g, ok ? m : 0) + k;
-            if (check) {
-                va[j] = load4<true>(g.A + offa, ok, k, g.K);
-                if (MODE == PTTS_IN_MASKMUL) vm[j] = load4<true>(g.mask_src + offa, ok, k, g.K);
-            } else {
-                va[j] = ok ? *reinterpret_cast<const f32x4u*>(g.A + offa) : (f32x4u){0.f, 0.f, 0.f, 0.f};
-                if (MODE == PTTS_IN_MASKMUL) vm[j] = ok ? *reinterpret_cast<const f32x4u*>(g.mask_src + offa) : (f32x4u){0.f, 0.f, 0.f, 0.f};
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int qq = tid + j * TALL_THREADS;
-            if (TRANSB == 0) {                          // stored [k][n]
-                const int k = k0 + (qq >> 6), n = (qq & 63) * 4;
-                const bool ok = !check || k < g.K;
-                vb[j] = check ? load4<true>(g.B + (long long)(ok ? k : 0) * g.ldb + n, ok, n, g.N)
-                              : *reinterpret_cast<const f32x4u*>(g.B + (long long)k * g.ldb + n);
-            } else {                                    // stored [n][k]
-                const int n = qq >> 2, k = k0 + (qq & 3) * 4;
-                const bool ok = !check || n < g.N;
-                vb[j] = check ? load4<true>(g.B + (long long)(ok ? n : 0) * g.ldb + k, ok, k, g.K)
-                              : *reinterpret_cast<const f32x4u*>(g.B + (long long)n * g.ldb + k);
-            }
-        }
-        if (MODE == PTTS_IN_LRELU && g.in_scale) {      // this lane's four channels (k-quad) of the k-step
-            const int ch = k0 + (tid & 3) * 4;
-            vsc = load4<true>(g.in_scale + ch, true, ch, g.K);
-            vsh = load4<true>(g.in_shift + ch, true, ch, g.K);
-        }
-    };
-    auto store = [&](float* as, float* bs) {
-#pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int qq = tid + j * TALL_THREADS;
-            const int row = qq >> 2, k = (qq & 3) * 4;
-            if (row < TBM) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = va[j][e];
-                    if (MODE == PTTS_IN_LRELU) {
-                        if (g.in_scale) v = v * vsc[e] + vsh[e];
-                        v = lrelu(v, g.alpha);
-                    } else if (MODE == PTTS_IN_MASKMUL) {
-                        v *= lrelu_d(vm[j][e], g.alpha);
-                    }
-                    as[(k + e) * TLDA + row] = v;
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int qq = tid + j * TALL_THREADS;
-            if (TRANSB == 0) {
-                const int k = qq >> 6, n = (qq & 63) * 4;
-                *reinterpret_cast<float4*>(bs + k * TLDB + n) = make_float4(vb[j][0], vb[j][1], vb[j][2], vb[j][3]);
-            } else {
-                const int n = qq >> 2, k = (qq & 3) * 4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) bs[(k + e) * TLDB + n] = vb[j][e];
-            }
-        }
-    };
-
-    const int K = g.K;
-    load(0, !(interior && TBK <= K));
-    store(As[0], Bs[0]);
-    __syncthreads();
-    int buf = 0;
-    for (int k0 = 0; k0 < K; k0 += TBK, buf ^= 1) {
-        const bool more = k0 + TBK < K;
-        if (more) load(k0 + TBK, !(interior && k0 + 2 * TBK <= K));
-        const float* as = As[buf] + q * TLDA + r16;
-        const float* bs = Bs[buf] + q * TLDB + wave * (16 * NTW) + r16;
-#pragma unroll
-        for (int kk = 0; kk < TBK; kk += 4) {
-            float ra[MT], rb[NTW];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) ra[i] = as[kk * TLDA + i * 16];
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) rb[j] = bs[kk * TLDB + j * 16];
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NTW; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[i], rb[j], acc[i][j], 0, 0, 0);
-        }
-        if (more) store(As[buf ^ 1], Bs[buf ^ 1]);
-        __syncthreads();
-    }
-    // epilogue: the 16x16 C/D layout (col = lane&15, row = 4*(lane>>4) + r) would store 64-byte pieces; each 16-row
-    // band is instead passed through the (now free) B buffers so that C and the output mask move as whole 1 KB rows.
-    const int col4 = (tid & 63) * 4, erow = tid >> 6;        // this lane's 4 columns and row (of 8) in the band halves
-    float bv[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) bv[e] = (g.bias && col4 + e < g.N) ? g.bias[col4 + e] : 0.f;
-    const bool vec = (g.N == TBN) && (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0) &&
-                     (!g.out_mask || (reinterpret_cast<uintptr_t>(g.out_mask) & 15) == 0);
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        float* sb = Bs[i & 1];
-#pragma unroll
-        for (int j = 0; j < NTW; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sb[(q * 4 + r) * TLDB + wave * (16 * NTW) + j * 16 + r16] = acc[i][j][r];
-        __syncthreads();
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int row = erow + 8 * h;
-            const int m = m0 + i * 16 + row;
-            if (m >= g.M) continue;
-            const float4 t = *reinterpret_cast<const float4*>(sb + row * TLDB + col4);
-            float v[4] = {t.x + bv[0], t.y + bv[1], t.z + bv[2], t.w + bv[3]};
-            const long long off = (long long)m * g.ldc + col4;
-            if (vec) {
-                if (g.out_mask) {
-                    const float4 mk = *reinterpret_cast<const float4*>(g.out_mask + off);
-                    v[0] *= lrelu_d(mk.x, g.out_alpha); v[1] *= lrelu_d(mk.y, g.out_alpha);
-                    v[2] *= lrelu_d(mk.z, g.out_alpha); v[3] *= lrelu_d(mk.w, g.out_alpha);
-                }
-                float4* cp = reinterpret_cast<float4*>(g.C + off);
-                if (g.accumulate) { const float4 o = *cp; v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
-                *cp = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (col4 + e >= g.N) continue;
-                    float w = v[e];
-                    if (g.out_mask) w *= lrelu_d(g.out_mask[off + e], g.out_alpha);
-                    if (g.accumulate) g.C[off + e] += w; else g.C[off + e] = w;
-                }
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// Tall GEMM, k-contiguous A tile, BKT = 16 or 32 per k-step.  Same ownership as gemm_tall_kernel (TBM x 256 outputs per
-// workgroup, wave w owns columns [32w, 32w+32)), different data path:
+// The kernel: k-contiguous A tile, BKT = 16 (or 32) per k-step:
 //  * the A tile keeps the global layout [row][k] in LDS (row stride BKT+8 floats: conflict-free ds_read_b128), staged
 //    with one ds_write_b128 per quad; a lane fetches four k-values of a row with ONE ds_read_b128.  MFMA number e of a
 //    16-wide k-group multiplies the k-set {e, 4+e, 8+e, 12+e} (the sum over k does not care about the order) and B is
@@ -691,7 +527,7 @@ __global__ __launch_bounds__(TALL_THREADS) void gemm_tall_kc_kernel(GemmArgs g) 
 static int pick_tall_mt(int M) {
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("PTTS_TALL_MT"); forced = e ? atoi(e) : 0; }
-    if (forced >= 2 && forced <= 8) return forced;
+    if (forced >= 4 && forced <= 8) return forced;
     int best = 8; double best_eff = -1.0;
     for (int mt = 4; mt <= 8; ++mt) {
         const long long blocks = (M + 16 * mt - 1) / (16 * mt);
@@ -767,15 +603,9 @@ extern "C" int ptts_gemm(const float* A, const float* Bm, const float* bias, flo
     if (transA == 0 && N > 128 && N <= TBN && M >= 2048 && K <= tall_kmax) {
         const int mt = pick_tall_mt(M);
         dim3 tgrid((M + 16 * mt - 1) / (16 * mt)), tblock(TALL_THREADS);
-        static int kc = -1;
-        if (kc < 0) { const char* e = getenv("PTTS_TALL_KC"); kc = e ? atoi(e) : 16; }
-#define PTTS_TALL(TB, MD, MTT) do { if (kc == 32) hipLaunchKernelGGL((gemm_tall_kc_kernel<TB, MD, MTT, 32>), tgrid, tblock, 0, st, g); \
-                                    else if (kc == 16) hipLaunchKernelGGL((gemm_tall_kc_kernel<TB, MD, MTT, 16>), tgrid, tblock, 0, st, g); \
-                                    else hipLaunchKernelGGL((gemm_tall_kernel<TB, MD, MTT>), tgrid, tblock, 0, st, g); } while (0)
+#define PTTS_TALL(TB, MD, MTT) hipLaunchKernelGGL((gemm_tall_kc_kernel<TB, MD, MTT, 16>), tgrid, tblock, 0, st, g)
 #define PTTS_TALL_MT(TB, MD)                                          \
         switch (mt) {                                                 \
-            case 2: PTTS_TALL(TB, MD, 2); break;                      \
-            case 3: PTTS_TALL(TB, MD, 3); break;                      \
             case 4: PTTS_TALL(TB, MD, 4); break;                      \
             case 5: PTTS_TALL(TB, MD, 5); break;                      \
             case 6: PTTS_TALL(TB, MD, 6); break;                      \
