@@ -1,0 +1,166 @@
+"""Parity at BASELINE.json's full size (configs[1]: B=64, T=400, ctx=601, 86 outputs, H=256, 8 x Conv2D(4, 5x5)),
+where the CPU oracle needs minutes per step: size-independent properties of the domain plus oracle checks on crops.
+
+ * the kernels at the real layer shapes against the fp64 oracle on crops (conv2d with its halo) / row samples (GEMM);
+ * linearity of the convolution and of the GEMM at full size;
+ * sample independence of the critic (no BatchNorm): a sub-batch gives the same values as the rows of the full batch;
+ * critic(real) + critic(fake) stacked as one 2B pass == two separate passes, losses and gradients;
+ * data parallelism by construction: the critic gradient of the batch is the mean of the gradients of its two halves
+   (what the flat-bucket all-reduce averages), with the same interpolation weights.
+fp32 kernels vs fp64 oracle: rtol 2e-4 (the north star's bar is 1e-3)."""
+import io
+import contextlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import percival_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+B, T, CTX, SPEC, NM = 64, 400, 601, 65, 20
+
+
+def close(got, want, rtol, atol, what):
+    got = got.detach().double().cpu(); want = want.detach().double().cpu()
+    assert got.shape == want.shape, '{}: {} vs {}'.format(what, tuple(got.shape), tuple(want.shape))
+    err = (got - want).abs(); tol = atol + rtol * want.abs()
+    if (err > tol).any():
+        i = int(torch.argmax(err - tol))
+        raise AssertionError('{}: {}/{} off, worst {:.3e} (got {:.6e}, want {:.6e})'.format(
+            what, int((err > tol).sum()), err.numel(), float(err.flatten()[i]), float(got.flatten()[i]), float(want.flatten()[i])))
+
+
+def rel_l2(a, b):
+    a = a.detach().double(); b = b.detach().double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+
+@pytest.fixture(scope='module')
+def setup():
+    import bench
+    from percivaltts_amd import vocoders, modeltts_common, networks_critic, optimizertts_wgan, backend_hip
+
+    class A: batch = B; frames = T; ctx = CTX
+    cfg = bench.make_cfg(A)
+    dev = backend_hip.device()
+    voc = vocoders.VocoderPML(16000, 0.005, SPEC, NM)
+    with contextlib.redirect_stdout(io.StringIO()):
+        mod = modeltts_common.DCNNF0SpecNoiseFeatures(CTX, voc, cfg)
+        crit = networks_critic.Critic(voc, CTX, cfg)
+        opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype='WLSWGAN', critic=crit)
+        opt.prepare()
+    X, Y = bench.synthetic(B, T, CTX, voc.featuressize(), SPEC, 321, dev)
+    return cfg, opt, crit, X, Y
+
+
+def test_conv2d_full_size_against_oracle_crops_and_linearity():
+    from percivaltts_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x1 = torch.randn(B, T, SPEC, 4, generator=g).cuda()
+    x2 = torch.randn(B, T, SPEC, 4, generator=g).cuda()
+    w = (torch.randn(5, 5, 4, 4, generator=g) * 0.2).cuda()
+    b = torch.randn(4, generator=g).cuda()
+    y1 = ops.conv2d(ops.Lazy(x1, lrelu=True), w, b)
+    # oracle on time crops with the halo (2 frames each side); first, middle (tile borders) and last rows
+    for (bi, t0, n) in ((0, 0, 9), (17, 185, 30), (63, T - 7, 7)):
+        lo, hi = max(0, t0 - 2), min(T, t0 + n + 2)
+        ref = O.conv2d_nhwc(O.lrelu(x1[bi:bi + 1, lo:hi].double().cpu()), w.double().cpu(), b.double().cpu())
+        close(y1[bi:bi + 1, t0:t0 + n], ref[:, t0 - lo:t0 - lo + n], 2e-4, 2e-5, 'conv2d crop b={} t0={}'.format(bi, t0))
+    # linearity (no transform, no bias): conv(2.5 x1 - x2) == 2.5 conv(x1) - conv(x2)
+    ya, yb = ops.conv2d(x1, w, None), ops.conv2d(x2, w, None)
+    yc = ops.conv2d(2.5 * x1 - x2, w, None)
+    assert rel_l2(yc, 2.5 * ya - yb) < 2e-6
+    # the backward of the same layer: dx against the oracle on a crop, dw against a chunked fp64 reduction of crops
+    x1r = x1.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+    dy = torch.randn(B, T, SPEC, 4, generator=g).cuda()
+    ops.conv2d(ops.Lazy(x1r, lrelu=True), wr, b).backward(dy)
+    bi, t0, n = 31, 203, 12
+    lo, hi = t0 - 4, t0 + n + 4
+    xc = x1[bi:bi + 1, lo:hi].double().cpu().requires_grad_(True)
+    yc = O.conv2d_nhwc(O.lrelu(xc), w.double().cpu(), b.double().cpu())
+    # rows within 2 of the crop border see a truncated receptive field: feed dy only where it is complete
+    dyc = torch.zeros_like(yc); dyc[:, 2:-2] = dy[bi:bi + 1, lo + 2:hi - 2].double().cpu()
+    yc.backward(dyc)
+    close(x1r.grad[bi:bi + 1, t0:t0 + n], xc.grad[:, 4:4 + n], 2e-4, 2e-5, 'conv2d dx crop')
+
+
+def test_gemm_full_size_rows_and_linearity():
+    from percivaltts_amd import ops
+    g = torch.Generator().manual_seed(2)
+    M, K, N = B * T, 256, 256
+    A1 = torch.randn(M, K, generator=g).cuda(); A2 = torch.randn(M, K, generator=g).cuda()
+    W = (torch.randn(K, N, generator=g) / 16).cuda(); bias = torch.randn(N, generator=g).cuda()
+    C1 = torch.empty(M, N, device='cuda'); C2 = torch.empty(M, N, device='cuda'); C3 = torch.empty(M, N, device='cuda')
+    ops.gemm_raw(A1, W, C1, M, N, K, bias=bias, mode=ops.IN_LRELU)
+    rows = torch.tensor([0, 1, 111, 112, 113, 12799, 25487, 25599])      # tile borders of the 112-row workgroups
+    want = O.lrelu(A1[rows].double().cpu()) @ W.double().cpu() + bias.double().cpu()
+    close(C1[rows], want, 2e-4, 2e-4, 'dense rows')
+    ops.gemm_raw(A1, W, C1, M, N, K); ops.gemm_raw(A2, W, C2, M, N, K); ops.gemm_raw(0.5 * A1 + 3 * A2, W, C3, M, N, K)
+    assert rel_l2(C3, 0.5 * C1 + 3 * C2) < 2e-6
+    # the context Conv1D as implicit GEMM over the zero-padded frame buffer, a few frames against the oracle
+    KW = 21
+    xp = torch.zeros(B, T + KW - 1, CTX, device='cuda'); x = torch.randn(B, T, CTX, generator=g).cuda()
+    xp[:, KW // 2:KW // 2 + T] = x
+    wc = (torch.randn(KW, CTX, N, generator=g) * 0.01).cuda()
+    y = torch.empty(B, T, N, device='cuda')
+    ops.gemm_raw(xp, wc, y, M, N, KW * CTX, lda=CTX, rows_per_seg=T, seg_stride=(T + KW - 1) * CTX, bias=bias)
+    for (bi, t) in ((0, 0), (5, 9), (40, 399), (63, 200)):
+        win = xp[bi, t:t + KW].double().cpu().reshape(-1)
+        close(y[bi, t], win @ wc.double().cpu().reshape(-1, N) + bias.double().cpu(), 2e-4, 5e-4, 'conv1d frame')
+    # weight gradient of the same product (deep K, split over workgroups): a sample of entries against fp64
+    dyc = torch.randn(B, T, N, generator=g).cuda()
+    dw = torch.empty(KW, CTX, N, device='cuda')
+    ops.gemm_raw(xp, dyc, dw, KW * CTX, N, M, transA=1, lda=CTX, rows_per_seg=T, seg_stride=(T + KW - 1) * CTX)
+    for (kw, ci) in ((0, 0), (10, 300), (20, 600)):
+        col = xp[:, kw:kw + T, ci].double().cpu().reshape(-1)
+        close(dw[kw, ci], col @ dyc.double().cpu().reshape(M, N), 2e-4, 2e-2, 'conv1d dW row')
+
+
+def test_critic_rows_do_not_depend_on_the_batch(setup):
+    cfg, opt, crit, X, Y = setup
+    with torch.no_grad():
+        full = crit.model(Y, X, training=False)
+        sub = crit.model(Y[8:16].contiguous(), X[8:16].contiguous(), training=False)
+    assert rel_l2(full[8:16], sub) < 5e-6
+
+
+def _critic_grads(opt, X, Y, alpha, fake):
+    opt.critic_opti.zero_grad()
+    total, parts = opt.critic_loss(X, Y, alpha, training=True, fake=fake)
+    total.backward()
+    torch.cuda.synchronize()
+    return total.detach().clone(), [p.detach().clone() for p in parts], opt.critic_opti.flat.grad.detach().clone()
+
+
+def test_stacked_real_fake_equals_separate_passes(setup):
+    cfg, opt, crit, X, Y = setup
+    g = torch.Generator().manual_seed(3)
+    alpha = torch.rand(B, generator=g).cuda()
+    with torch.no_grad():
+        fake = opt._fake_sample(X, True).detach()
+    cfg.train_wgan_stack_real_fake = True
+    t1, p1, g1 = _critic_grads(opt, X, Y, alpha, fake)
+    cfg.train_wgan_stack_real_fake = False
+    t2, p2, g2 = _critic_grads(opt, X, Y, alpha, fake)
+    cfg.train_wgan_stack_real_fake = True
+    for a, b, nm in zip(p1, p2, ('valid', 'fake', 'gp')):
+        close(a, b, 1e-5, 1e-6, 'stacked vs separate: ' + nm)
+    assert rel_l2(g1, g2) < 2e-5
+
+
+def test_batch_gradient_is_the_mean_of_the_shard_gradients(setup):
+    """What data parallelism relies on: with per-sample interpolation weights fixed, the critic loss is a mean over the
+    samples (no BatchNorm in the critic), so grad(batch) = (grad(first half) + grad(second half)) / 2."""
+    cfg, opt, crit, X, Y = setup
+    g = torch.Generator().manual_seed(4)
+    alpha = torch.rand(B, generator=g).cuda()
+    with torch.no_grad():
+        fake = opt._fake_sample(X, True).detach()     # BatchNorm of the GENERATOR sees the full batch here, once
+    h = B // 2
+    t, _, gfull = _critic_grads(opt, X, Y, alpha, fake)
+    ta, _, ga = _critic_grads(opt, X[:h].contiguous(), Y[:h].contiguous(), alpha[:h].contiguous(), fake[:h].contiguous())
+    tb, _, gb = _critic_grads(opt, X[h:].contiguous(), Y[h:].contiguous(), alpha[h:].contiguous(), fake[h:].contiguous())
+    close(t, 0.5 * (ta + tb), 2e-5, 1e-6, 'loss of the batch vs mean of the shard losses')
+    assert rel_l2(gfull, 0.5 * (ga + gb)) < 5e-5
