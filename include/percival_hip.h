@@ -101,13 +101,15 @@ int ptts_conv2d_bwd(const float* dy, const float* x, const float* w,
  * The input transform acts on the stored A element; its channel index is the stored column.
  * accumulate != 0 adds to C (beta = 1).
  * out_mask (NULL or laid out like C with ldc): the product is multiplied by (out_mask>0 ? 1 : alpha) before it is
- * stored -- the LeakyReLU mask of a dense layer's backward-data pass, fused into the epilogue. */
+ * stored -- the LeakyReLU mask of a dense layer's backward-data pass, fused into the epilogue.
+ * colsum_b (NULL or [N], needs transA==1 and transB==0): receives sum_k B[k,n] -- the bias gradient that goes with a
+ * weight-gradient product dW = a^T . dy, taken from the B tiles while they are staged (fp32 atomics across workgroups). */
 int ptts_gemm(const float* A, const float* Bm, const float* bias, float* C,
               int M, int N, int K,
               int transA, long long lda, long long rows_per_seg, long long seg_stride,
               int transB, long long ldb, long long ldc,
               int in_mode, const float* in_scale, const float* in_shift, const float* mask_src,
-              float alpha, int accumulate, const float* out_mask, void* stream);
+              float alpha, int accumulate, const float* out_mask, float* colsum_b, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * channel-last reductions and elementwise passes

@@ -26,7 +26,7 @@ SIGNATURES = {
     'ptts_conv2d_fwd': (c_i, [c_p] * 7 + [c_i] * 10 + [c_f, c_p]),
     'ptts_conv2d_bwd_workspace_bytes': (c_sz, [c_i] * 8),
     'ptts_conv2d_bwd': (c_i, [c_p] * 11 + [c_p, c_sz] + [c_i] * 10 + [c_f, c_p]),
-    'ptts_gemm': (c_i, [c_p] * 4 + [c_i] * 3 + [c_i, c_ll, c_ll, c_ll, c_i, c_ll, c_ll, c_i, c_p, c_p, c_p, c_f, c_i, c_p, c_p]),
+    'ptts_gemm': (c_i, [c_p] * 4 + [c_i] * 3 + [c_i, c_ll, c_ll, c_ll, c_i, c_ll, c_ll, c_i, c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p]),
     'ptts_colstats_workspace_bytes': (c_sz, [c_ll, c_i]),
     'ptts_colstats': (c_i, [c_p, c_ll, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_sz, c_p]),
     'ptts_bn_finalize': (c_i, [c_p, c_ll, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),

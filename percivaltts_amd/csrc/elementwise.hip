@@ -115,10 +115,37 @@ __global__ __launch_bounds__(EW_THREADS) void colreduce2_vec4_kernel(Op4 op, lon
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s[e] += fs[e]; q[e] += fq[e]; }
     }
+    double* out = partials + (size_t)blockIdx.x * 2 * C;
+    if (C4 <= 32 && (C4 & (C4 - 1)) == 0 && R * C4 == EW_THREADS) {
+        // few channels (the C = 4 conv stacks: C4 = 1): the lanes of a wave that own the same channels differ in the lane
+        // bits >= log2(C4); butterfly over those, then one LDS slot per wave instead of a serial sum over R rows
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            for (int m = 32; m >= C4; m >>= 1) {
+                s[e] += __shfl_xor(s[e], m, 64);
+                q[e] += __shfl_xor(q[e], m, 64);
+            }
+        }
+        const int lane = tid & 63, wave = tid >> 6;
+        if (lane < C4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sh[e][wave * C4 + lane] = s[e]; sh[4 + e][wave * C4 + lane] = q[e]; }
+        }
+        __syncthreads();
+        if (tid < C4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                double a = 0.0, b = 0.0;
+                for (int wv = 0; wv < EW_THREADS / 64; ++wv) { a += sh[e][wv * C4 + tid]; b += sh[4 + e][wv * C4 + tid]; }
+                out[tid * 4 + e] = a;
+                out[C + tid * 4 + e] = b;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) { sh[e][tid] = s[e]; sh[4 + e][tid] = q[e]; }
     __syncthreads();
-    double* out = partials + (size_t)blockIdx.x * 2 * C;
     if (tid < C4) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

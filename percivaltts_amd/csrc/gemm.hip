@@ -43,6 +43,7 @@ struct GemmArgs {
     long long iters_total;        // tiles * ksteps
     int workers;
     int prio;                     // raise the issue priority of the second half of the grid (see the kernel)
+    float* colsum_b;              // optional [N]: += column sums of B over k (the bias gradient beside a weight gradient)
 };
 
 __device__ __forceinline__ float a_transform(float v, const GemmArgs& g, long long off, int ch) {
@@ -163,8 +164,14 @@ __device__ __forceinline__ void load_tiles(const GemmArgs& g, int m0, int n0, in
 }
 
 template <int TRANSA, int TRANSB, int MODE>
-__device__ __forceinline__ void store_tiles(const GemmArgs& g, float* As, float* Bs, const Frag& fr) {
+__device__ __forceinline__ void store_tiles(const GemmArgs& g, float* As, float* Bs, const Frag& fr, float* bsum) {
     const int tid = threadIdx.x;
+    if (TRANSB == 0 && bsum) {           // this lane's four columns of B, every k row it stages
+#pragma unroll
+        for (int j = 0; j < NLD; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bsum[e] += fr.b[j][e];
+    }
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
         const int q = tid + j * GEMM_THREADS;
@@ -243,8 +250,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_mfma_kernel(GemmArgs g)
             else load_tiles<TRANSA, TRANSB, MODE, true>(g, m0, n0, k0, ar, fr);
             arows_advance<TRANSA>(g, ar);
         };
+        // bias gradient: the workgroups of the first row of tiles also sum the columns of B over their k range
+        float bsum_r[4] = {0.f, 0.f, 0.f, 0.f};
+        float* bsum = (TRANSB == 0 && g.colsum_b != nullptr && m0 == 0) ? bsum_r : nullptr;
         load(kbeg);
-        store_tiles<TRANSA, TRANSB, MODE>(g, As[0], Bs[0], fr);
+        store_tiles<TRANSA, TRANSB, MODE>(g, As[0], Bs[0], fr, bsum);
         __syncthreads();
         int buf = 0;
         for (int k0 = kbeg; k0 < kend; k0 += BK, buf ^= 1) {
@@ -267,7 +277,21 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_mfma_kernel(GemmArgs g)
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[kk][1], rb[kk][0], acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[kk][1], rb[kk][1], acc[1][1], 0, 0, 0);
             }
-            if (more) store_tiles<TRANSA, TRANSB, MODE>(g, As[buf ^ 1], Bs[buf ^ 1], fr);
+            if (more) store_tiles<TRANSA, TRANSB, MODE>(g, As[buf ^ 1], Bs[buf ^ 1], fr, bsum);
+            __syncthreads();
+        }
+        if (bsum) {
+            // lanes tid and tid+32k hold the same four columns (rows k differ): combine the 8 through LDS (As is free)
+            float* red = As[0];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[(tid >> 5) * BN + (tid & 31) * 4 + e] = bsum_r[e];
+            __syncthreads();
+            if (tid < BN) {
+                float t = 0.f;
+#pragma unroll
+                for (int r = 0; r < GEMM_THREADS / 32; ++r) t += red[r * BN + tid];
+                if (n0 + tid < g.N) atomicAdd(g.colsum_b + n0 + tid, t);
+            }
             __syncthreads();
         }
 
@@ -558,8 +582,9 @@ extern "C" int ptts_gemm(const float* A, const float* Bm, const float* bias, flo
                          int transA, long long lda, long long rows_per_seg, long long seg_stride, int transB,
                          long long ldb, long long ldc, int in_mode, const float* in_scale,
                          const float* in_shift, const float* mask_src, float alpha, int accumulate,
-                         const float* out_mask, void* stream) {
+                         const float* out_mask, float* colsum_b, void* stream) {
     PTTS_REQUIRE(A && Bm && C, "gemm: null matrix");
+    PTTS_REQUIRE(!colsum_b || (transA == 1 && transB == 0), "gemm: colsum_b needs transA=1, transB=0 (a weight-gradient product)");
     PTTS_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad dims M=%d N=%d K=%d", M, N, K);
     PTTS_REQUIRE(rows_per_seg > 0 && rows_per_seg < (1LL << 31) && lda > 0 && ldb > 0 && ldc >= N, "gemm: bad leading dims");
     PTTS_REQUIRE(in_mode >= 0 && in_mode <= 2, "gemm: bad in_mode %d", in_mode);
@@ -574,12 +599,13 @@ extern "C" int ptts_gemm(const float* A, const float* Bm, const float* bias, flo
     g.in_mode = in_mode; g.in_scale = in_scale; g.in_shift = in_shift; g.mask_src = mask_src; g.alpha = alpha;
     g.accumulate = accumulate;
     g.out_mask = out_mask; g.out_alpha = alpha;
+    g.colsum_b = colsum_b;
     static int prio = -1;
     if (prio < 0) { const char* e = getenv("PTTS_GEMM_PRIO"); prio = e ? atoi(e) : 1; }
     g.prio = prio;
 
     // thin products (N <= 4 heads, K <= 4 outer products, 1-2 weighted column sums) never reach the MFMA tiles
-    if (thin_enabled()) {
+    if (thin_enabled() && !colsum_b) {
         const int thin = thin_gemm_dispatch(A, Bm, bias, C, M, N, K, transA, lda, rows_per_seg, seg_stride, transB, ldb, ldc,
                                             in_mode, in_scale, in_shift, mask_src, alpha, accumulate, out_mask, st);
         if (thin < 0) return thin;
@@ -590,11 +616,11 @@ extern "C" int ptts_gemm(const float* A, const float* Bm, const float* bias, flo
         const int n1 = TBN, n2 = N - TBN;
         const float* B2 = transB == 0 ? Bm + n1 : Bm + (long long)n1 * ldb;
         int rc = ptts_gemm(A, Bm, bias, C, M, n1, K, transA, lda, rows_per_seg, seg_stride, transB, ldb, ldc, in_mode,
-                           in_scale, in_shift, mask_src, alpha, accumulate, out_mask, stream);
+                           in_scale, in_shift, mask_src, alpha, accumulate, out_mask, nullptr, stream);
         if (rc) return rc;
         return ptts_gemm(A, B2, bias ? bias + n1 : nullptr, C + n1, M, n2, K, transA, lda, rows_per_seg, seg_stride,
                          transB, ldb, ldc, in_mode, in_scale, in_shift, mask_src, alpha, accumulate,
-                         out_mask ? out_mask + n1 : nullptr, stream);
+                         out_mask ? out_mask + n1 : nullptr, nullptr, stream);
     }
     // tall products (M >> N, N in (128, 256]) take the full-width tile kernel: A read once, one round, no atomics
     // (for deep K the stream-K 128x128 kernel below is faster: its two co-resident workgroups per CU overlap better)
@@ -652,6 +678,10 @@ extern "C" int ptts_gemm(const float* A, const float* Bm, const float* bias, flo
         if (ldc == N) e = hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), st);
         else e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, st);
         if (e != hipSuccess) { set_error("gemm: memset failed: %s", hipGetErrorString(e)); return PTTS_ELAUNCH; }
+    }
+    if (colsum_b && hipMemsetAsync(colsum_b, 0, (size_t)N * sizeof(float), st) != hipSuccess) {
+        set_error("gemm: colsum memset failed");
+        return PTTS_ELAUNCH;
     }
     dim3 grid(g.workers), block(GEMM_THREADS);
     const bool conv = seg_stride != 0;

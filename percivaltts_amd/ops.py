@@ -143,7 +143,8 @@ def _conv2d_bwd_raw(dy, x, w, scale, shift, mask_src, mode, alpha, dil_t, pad_mo
 
 
 def gemm_raw(A, Bm, C, M, N, K, transA=0, lda=None, rows_per_seg=None, seg_stride=0, transB=0, ldb=None, ldc=None,
-             bias=None, mode=IN_NONE, scale=None, shift=None, mask_src=None, alpha=0.3, accumulate=0, out_mask=None):
+             bias=None, mode=IN_NONE, scale=None, shift=None, mask_src=None, alpha=0.3, accumulate=0, out_mask=None,
+             colsum_b=None):
     """C[M,N] (+)= opA(A).opB(B) (+bias).  Pointers may be views with offsets; dims are the caller's contract."""
     for t in (A, Bm, C, bias, scale, shift, mask_src):
         if t is not None:
@@ -157,7 +158,7 @@ def gemm_raw(A, Bm, C, M, N, K, transA=0, lda=None, rows_per_seg=None, seg_strid
     if ldc is None:
         ldc = N
     call('ptts_gemm', ptr(A), ptr(Bm), ptr(bias), ptr(C), M, N, K, transA, lda, rows_per_seg, seg_stride,
-         transB, ldb, ldc, mode, ptr(scale), ptr(shift), ptr(mask_src), alpha, accumulate, ptr(out_mask), stream(),
+         transB, ldb, ldc, mode, ptr(scale), ptr(shift), ptr(mask_src), alpha, accumulate, ptr(out_mask), ptr(colsum_b), stream(),
          tag=(M, N, K, transA, transB, int(seg_stride != 0)))
     return C
 
@@ -170,7 +171,7 @@ def colsums(x2d, mode=IN_NONE, scale=None, shift=None, mask_src=None, alpha=0.3)
     nws = _hip.lib().ptts_colstats_workspace_bytes(rows, C)
     ws = _workspace(nws, x2d.device)
     call('ptts_colstats', ptr(x2d), rows, C, mode, ptr(scale), ptr(shift), ptr(mask_src), alpha, ptr(sums),
-         ptr(ws), ws.numel(), stream())
+         ptr(ws), ws.numel(), stream(), tag=(rows, C, mode))
     return sums
 
 
@@ -320,9 +321,13 @@ class DenseFn(torch.autograd.Function):
                 _, dscale, dshift = _dense_bwd_data(dy2, x2, w, mode, scale, shift, alpha, True)
             if need_w:
                 dw = torch.empty_like(w)
+                # the bias gradient (column sums of dy) rides on the weight-gradient product, whose B operand is dy
+                fuse_b = need_b and N > 4
+                if fuse_b:
+                    db = torch.empty(N, dtype=torch.float32, device=dy.device)
                 gemm_raw(x2, dy2, dw, K, N, M, transA=1, lda=K, rows_per_seg=M,
-                         mode=mode, scale=scale, shift=shift, alpha=alpha)
-            if need_b:
+                         mode=mode, scale=scale, shift=shift, alpha=alpha, colsum_b=db if fuse_b else None)
+            if need_b and db is None:
                 db = _colsum_f32(dy2)
         return dx, dw, db, dscale, dshift, None, None
 
@@ -398,11 +403,14 @@ class Conv1dFn(torch.autograd.Function):
         B, T, Cin, KW, N, pl = ctx.dims
         dy = dy.contiguous()
         da = dw = db = None
+        need_b = ctx.has_b and ctx.needs_input_grad[2] and not _Flags.skip_param_grads
         if ctx.needs_input_grad[1] and not _Flags.skip_param_grads:
             dw = torch.empty_like(w)
+            if need_b and N > 4:          # bias gradient taken from the B tiles of the weight-gradient product
+                db = torch.empty(N, dtype=torch.float32, device=dy.device)
             gemm_raw(ap, dy, dw, KW * Cin, N, B * T, transA=1, lda=Cin, rows_per_seg=T,
-                     seg_stride=(T + KW - 1) * Cin)
-        if ctx.has_b and ctx.needs_input_grad[2] and not _Flags.skip_param_grads:
+                     seg_stride=(T + KW - 1) * Cin, colsum_b=db)
+        if need_b and db is None:
             db = _colsum_f32(dy.view(B * T, N))
         if ctx.needs_input_grad[0]:
             # da[b,t,:] = sum_j dyp[b,t+j,:] . wf[j],  wf[j,n,ci] = w[KW-1-j,ci,n],  dyp padded (KW-1-pl, pl)

@@ -168,6 +168,20 @@ def test_gemm(ops, case):
     close(C, 2 * want - bias, rtol=2e-4, atol=4e-4 * math.sqrt(K), what='C+=')
 
 
+@pytest.mark.parametrize('case', [(300, 200, 5000), (256, 256, 25600), (70, 260, 900)])
+def test_gemm_weight_gradient_with_fused_bias_gradient(ops, case):
+    """dW = a^T.dy and db = column sums of dy from ONE product (colsum_b): split and unsplit, ragged tiles."""
+    M, N, K = case
+    g = gen(18)
+    A = torch.randn(K, M, generator=g, dtype=torch.float64)
+    D = torch.randn(K, N, generator=g, dtype=torch.float64) + 0.3
+    W = torch.empty(M, N, dtype=torch.float32, device='cuda')
+    db = torch.full((N,), 5.0, dtype=torch.float32, device='cuda')      # must be overwritten, not added to
+    ops.gemm_raw(dev(A), dev(D), W, M, N, K, transA=1, lda=M, rows_per_seg=K, mode=ops.IN_LRELU, colsum_b=db)
+    close(W, O.lrelu(A).t() @ D, rtol=2e-4, atol=2e-4 * math.sqrt(K), what='dW')
+    close(db, D.sum(0), rtol=2e-4, atol=2e-4 * math.sqrt(K), what='db')
+
+
 def test_gemm_transforms(ops):
     g = gen(4)
     M, N, K = 200, 96, 50
@@ -363,7 +377,7 @@ def test_affine_act(ops, act):
     close(ops.affine_act(dev(x2), None, None, act), f(x2), what='y-noaffine')
 
 
-@pytest.mark.parametrize('C', [256, 260, 1024, 86, 2044])
+@pytest.mark.parametrize('C', [4, 8, 32, 128, 256, 260, 1024, 86, 2044])
 def test_colsums_modes_wide(ops, C):
     """Column sums / sums of squares at the layer widths of the networks, vectorised and scalar paths, all transforms."""
     g = gen(15)

@@ -24,6 +24,8 @@ for name, fn in (('critic', lambda: opt.critic_step(X, Y)), ('generator', lambda
         with _hip.KernelTimer() as kt:
             fn()
         for n, tag, d in kt.durations_ms():
+            if n == 'ptts_colstats' and tag:
+                n = 'colstats rows{} C{} mode{}'.format(*tag)
             key = n if n != 'ptts_gemm' else 'gemm M{} N{} K{} tA{} tB{}{}'.format(*tag[:5], ' conv' if tag[5] else '')
             tot[key] += d / reps; cnt[key] += 1.0 / reps
     print('==', name, 'step: sum of C-ABI calls {:.2f} ms'.format(sum(tot.values())))
