@@ -29,5 +29,5 @@ for name, fn in (('critic', lambda: opt.critic_step(X, Y)), ('generator', lambda
             key = n if n != 'ptts_gemm' else 'gemm M{} N{} K{} tA{} tB{}{}'.format(*tag[:5], ' conv' if tag[5] else '')
             tot[key] += d / reps; cnt[key] += 1.0 / reps
     print('==', name, 'step: sum of C-ABI calls {:.2f} ms'.format(sum(tot.values())))
-    for k, v in tot.most_common(22):
+    for k, v in tot.most_common(45):
         print('  {:<46} {:7.3f} ms  x{:<5.0f} avg {:7.1f} us'.format(k, v, cnt[k], v / cnt[k] * 1e3))
