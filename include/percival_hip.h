@@ -111,6 +111,22 @@ int ptts_gemm(const float* A, const float* Bm, const float* bias, float* C,
               int in_mode, const float* in_scale, const float* in_shift, const float* mask_src,
               float alpha, int accumulate, const float* out_mask, float* colsum_b, void* stream);
 
+/* Weight gradients of several layers in ONE launch: for every product  C[M,N] += T(A)[K,M]^T . B[K,N]  and, when
+ * colsum_b is given,  colsum_b[N] += sum_k B[k,:]  (the bias gradient).  A is the layer input as stored ([K rows][lda]),
+ * B the incoming gradient; T is the same fused transform as in ptts_gemm (in_mode on the stored A element, channel =
+ * stored column).  Every C / colsum_b is ACCUMULATED into with fp32 atomics (zero it beforehand for a plain product):
+ * the caller's gradient buffers, as keras accumulates the gradients of the layers of one K.gradients call.  One
+ * workgroup grid walks the (product, tile, k-step) space, so a 256x256x25600 product no longer pays its own launch,
+ * zero-fill and 128-way split. */
+typedef struct ptts_wgrad_desc {
+    const float* A; const float* B; float* C; float* colsum_b;
+    const float* in_scale; const float* in_shift; const float* mask_src;
+    int M, N, K;
+    long long lda, ldb, ldc;
+    int in_mode; float alpha;
+} ptts_wgrad_desc;
+int ptts_gemm_wgrad_grouped(const ptts_wgrad_desc* descs, int n, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * channel-last reductions and elementwise passes
  * ------------------------------------------------------------------------------------- */

@@ -18,6 +18,12 @@ c_ll = ctypes.c_longlong
 c_p = ctypes.c_void_p
 c_sz = ctypes.c_size_t
 
+class WGradDesc(ctypes.Structure):
+    """struct ptts_wgrad_desc of include/percival_hip.h (one weight-gradient product of a grouped launch)."""
+    _fields_ = [('A', c_p), ('B', c_p), ('C', c_p), ('colsum_b', c_p), ('in_scale', c_p), ('in_shift', c_p), ('mask_src', c_p),
+                ('M', c_i), ('N', c_i), ('K', c_i), ('lda', c_ll), ('ldb', c_ll), ('ldc', c_ll), ('in_mode', c_i), ('alpha', c_f)]
+
+
 # name -> (restype, argtypes); must mirror include/percival_hip.h exactly
 SIGNATURES = {
     'ptts_version': (ctypes.c_char_p, []),
@@ -27,6 +33,7 @@ SIGNATURES = {
     'ptts_conv2d_bwd_workspace_bytes': (c_sz, [c_i] * 8),
     'ptts_conv2d_bwd': (c_i, [c_p] * 11 + [c_p, c_sz] + [c_i] * 10 + [c_f, c_p]),
     'ptts_gemm': (c_i, [c_p] * 4 + [c_i] * 3 + [c_i, c_ll, c_ll, c_ll, c_i, c_ll, c_ll, c_i, c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p]),
+    'ptts_gemm_wgrad_grouped': (c_i, [c_p, c_i, c_p]),
     'ptts_colstats_workspace_bytes': (c_sz, [c_ll, c_i]),
     'ptts_colstats': (c_i, [c_p, c_ll, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_sz, c_p]),
     'ptts_bn_finalize': (c_i, [c_p, c_ll, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),

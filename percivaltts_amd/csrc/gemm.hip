@@ -208,14 +208,109 @@ __device__ __forceinline__ void store_tiles(const GemmArgs& g, float* As, float*
 
 // CONV != 0 marks the implicit-convolution instantiation (same code; its own symbol so that a profile separates the
 // context-Conv1D products from the small Dense ones).
+// One contiguous run of k-steps [ks0, ks1) of one 128x128 tile: the body of both the single-product kernel and the
+// grouped weight-gradient kernel.  ATOMIC forces the fp32-atomic epilogue (accumulation into a buffer other
+// workgroups / streams also add to).
+template <int TRANSA, int TRANSB, int MODE, bool ATOMIC>
+__device__ __forceinline__ void gemm_segment(const GemmArgs& g, float (*As)[BK * LDA_S], float (*Bs)[BK * LDB_S],
+                                             int tile, int ks0, int ks1) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int m0 = (tile / g.tiles_n) * BM, n0 = (tile % g.tiles_n) * BN;
+    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+    const int kbeg = ks0 * BK;
+    const int kend = min(g.K, ks1 * BK);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    Frag fr;
+    ARows ar;
+    arows_begin<TRANSA>(g, m0, kbeg, ar);
+    auto load = [&](int k0) {           // called for kbeg, kbeg + BK, ... in order
+        if (interior && k0 + BK <= g.K) load_tiles<TRANSA, TRANSB, MODE, false>(g, m0, n0, k0, ar, fr);
+        else load_tiles<TRANSA, TRANSB, MODE, true>(g, m0, n0, k0, ar, fr);
+        arows_advance<TRANSA>(g, ar);
+    };
+    // bias gradient: the workgroups of the first row of tiles also sum the columns of B over their k range
+    float bsum_r[4] = {0.f, 0.f, 0.f, 0.f};
+    float* bsum = (TRANSB == 0 && g.colsum_b != nullptr && m0 == 0) ? bsum_r : nullptr;
+    load(kbeg);
+    store_tiles<TRANSA, TRANSB, MODE>(g, As[0], Bs[0], fr, bsum);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK, buf ^= 1) {
+        const bool more = k0 + BK < kend;
+        if (more) load(k0 + BK);                 // global -> registers, in flight during the MFMAs below
+        const float* as = As[buf] + lh * LDA_S + wm + l31;
+        const float* bs = Bs[buf] + lh * LDB_S + wn + l31;
+        float ra[BK / 2][2], rb[BK / 2][2];
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            ra[kk][0] = as[2 * kk * LDA_S];
+            ra[kk][1] = as[2 * kk * LDA_S + 32];
+            rb[kk][0] = bs[2 * kk * LDB_S];
+            rb[kk][1] = bs[2 * kk * LDB_S + 32];
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[kk][0], rb[kk][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[kk][0], rb[kk][1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[kk][1], rb[kk][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[kk][1], rb[kk][1], acc[1][1], 0, 0, 0);
+        }
+        if (more) store_tiles<TRANSA, TRANSB, MODE>(g, As[buf ^ 1], Bs[buf ^ 1], fr, bsum);
+        __syncthreads();
+    }
+    if (bsum) {
+        // lanes tid and tid+32k hold the same four columns (rows k differ): combine the 8 through LDS (As is free)
+        float* red = As[0];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[(tid >> 5) * BN + (tid & 31) * 4 + e] = bsum_r[e];
+        __syncthreads();
+        if (tid < BN) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < GEMM_THREADS / 32; ++r) t += red[r * BN + tid];
+            if (n0 + tid < g.N) atomicAdd(g.colsum_b + n0 + tid, t);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool whole = !ATOMIC && (ks0 == 0) && (ks1 == g.ksteps);
+    const bool add_bias = g.bias != nullptr && ks0 == 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn + j * 32 + l31;
+            if (n >= g.N) continue;
+            const float bv = add_bias ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= g.M) continue;
+                float* cp = g.C + (long long)m * g.ldc + n;
+                float v = acc[i][j][r] + bv;
+                if (g.out_mask) v *= lrelu_d(g.out_mask[(long long)m * g.ldc + n], g.out_alpha);
+                if (!whole) atomicAdd(cp, v);
+                else if (g.accumulate) *cp += v;
+                else *cp = v;
+            }
+        }
+}
+
 template <int TRANSA, int TRANSB, int CONV, int MODE>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_mfma_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float As[2][BK * LDA_S];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB_S];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    const int l31 = lane & 31, lh = lane >> 5;
-
     // Two workgroups share a CU and run the same program: left alone they fall into lockstep (MFMA phases together,
     // then load/store/barrier phases together with the matrix pipe idle).  Giving one of the pair -- the second half
     // of the grid, dispatched onto the CUs the first half already occupies -- a higher issue priority breaks the tie.
@@ -223,100 +318,63 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_mfma_kernel(GemmArgs g)
     // this workgroup's contiguous share of the (tile, k-step) space
     long long it = g.iters_total * blockIdx.x / g.workers;
     const long long it_end = g.iters_total * (blockIdx.x + 1) / g.workers;
-
     while (it < it_end) {
         const int tile = (int)(it / g.ksteps);
         const int ks0 = (int)(it - (long long)tile * g.ksteps);
         const int ks1 = (int)min((long long)g.ksteps, ks0 + (it_end - it));
         it += ks1 - ks0;
-        const int m0 = (tile / g.tiles_n) * BM, n0 = (tile % g.tiles_n) * BN;
-        const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
-        const int kbeg = ks0 * BK;
-        const int kend = min(g.K, ks1 * BK);
+        gemm_segment<TRANSA, TRANSB, MODE, false>(g, As, Bs, tile, ks0, ks1);
+    }
+}
 
-        f32x16 acc[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+// ------------------------------------------------------------------------------------------------
+// Grouped weight gradients: up to WG_MAX products C_i += a_i^T . dy_i (+ column sums of dy_i) in ONE launch.  A Dense
+// layer's weight gradient alone (256 x 256 x 25 600) has 4 tiles: split over 512 workgroups each gets 12 k-steps and
+// pays the launch, the zero-fill and a 64 KB atomic epilogue for them (47 TF).  All layers of a backward pass together
+// give every workgroup a long contiguous run of k-steps and few partial tiles.  Every product accumulates with fp32
+// atomics into its (zero-initialised or already partly filled) gradient buffer.
+// ------------------------------------------------------------------------------------------------
+constexpr int WG_MAX = 12;
+struct WGroup {
+    const float* A; const float* B; float* C; float* colsum_b;
+    const float* in_scale; const float* in_shift; const float* mask_src;
+    int M, N, K, lda, ldb, ldc, in_mode; float alpha;
+};
+struct WGroupArgs {
+    int n, workers;
+    long long it_begin[WG_MAX + 1];       // first (tile, k-step) iteration of each product; [n] = total
+    WGroup gr[WG_MAX];
+};
 
-        Frag fr;
-        ARows ar;
-        arows_begin<TRANSA>(g, m0, kbeg, ar);
-        auto load = [&](int k0) {           // called for kbeg, kbeg + BK, ... in order
-            if (interior && k0 + BK <= g.K) load_tiles<TRANSA, TRANSB, MODE, false>(g, m0, n0, k0, ar, fr);
-            else load_tiles<TRANSA, TRANSB, MODE, true>(g, m0, n0, k0, ar, fr);
-            arows_advance<TRANSA>(g, ar);
-        };
-        // bias gradient: the workgroups of the first row of tiles also sum the columns of B over their k range
-        float bsum_r[4] = {0.f, 0.f, 0.f, 0.f};
-        float* bsum = (TRANSB == 0 && g.colsum_b != nullptr && m0 == 0) ? bsum_r : nullptr;
-        load(kbeg);
-        store_tiles<TRANSA, TRANSB, MODE>(g, As[0], Bs[0], fr, bsum);
-        __syncthreads();
-        int buf = 0;
-        for (int k0 = kbeg; k0 < kend; k0 += BK, buf ^= 1) {
-            const bool more = k0 + BK < kend;
-            if (more) load(k0 + BK);                 // global -> registers, in flight during the MFMAs below
-            const float* as = As[buf] + lh * LDA_S + wm + l31;
-            const float* bs = Bs[buf] + lh * LDB_S + wn + l31;
-            float ra[BK / 2][2], rb[BK / 2][2];
-#pragma unroll
-            for (int kk = 0; kk < BK / 2; ++kk) {
-                ra[kk][0] = as[2 * kk * LDA_S];
-                ra[kk][1] = as[2 * kk * LDA_S + 32];
-                rb[kk][0] = bs[2 * kk * LDB_S];
-                rb[kk][1] = bs[2 * kk * LDB_S + 32];
-            }
-#pragma unroll
-            for (int kk = 0; kk < BK / 2; ++kk) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[kk][0], rb[kk][0], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[kk][0], rb[kk][1], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[kk][1], rb[kk][0], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[kk][1], rb[kk][1], acc[1][1], 0, 0, 0);
-            }
-            if (more) store_tiles<TRANSA, TRANSB, MODE>(g, As[buf ^ 1], Bs[buf ^ 1], fr, bsum);
-            __syncthreads();
-        }
-        if (bsum) {
-            // lanes tid and tid+32k hold the same four columns (rows k differ): combine the 8 through LDS (As is free)
-            float* red = As[0];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) red[(tid >> 5) * BN + (tid & 31) * 4 + e] = bsum_r[e];
-            __syncthreads();
-            if (tid < BN) {
-                float t = 0.f;
-#pragma unroll
-                for (int r = 0; r < GEMM_THREADS / 32; ++r) t += red[r * BN + tid];
-                if (n0 + tid < g.N) atomicAdd(g.colsum_b + n0 + tid, t);
-            }
-            __syncthreads();
-        }
-
-        // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-        const bool whole = (ks0 == 0) && (ks1 == g.ksteps);
-        const bool add_bias = g.bias != nullptr && ks0 == 0;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n = n0 + wn + j * 32 + l31;
-                if (n >= g.N) continue;
-                const float bv = add_bias ? g.bias[n] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (m >= g.M) continue;
-                    float* cp = g.C + (long long)m * g.ldc + n;
-                    float v = acc[i][j][r] + bv;
-                    if (g.out_mask) v *= lrelu_d(g.out_mask[(long long)m * g.ldc + n], g.out_alpha);
-                    if (!whole) atomicAdd(cp, v);
-                    else if (g.accumulate) *cp += v;
-                    else *cp = v;
-                }
-            }
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_wgrad_grouped_kernel(WGroupArgs ga) {
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA_S];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB_S];
+    if ((int)blockIdx.x >= (int)(gridDim.x / 2)) __builtin_amdgcn_s_setprio(3);
+    const long long total = ga.it_begin[ga.n];
+    long long it = total * blockIdx.x / ga.workers;
+    const long long it_end = total * (blockIdx.x + 1) / ga.workers;
+    int gi = 0;
+    while (it < it_end) {
+        while (it >= ga.it_begin[gi + 1]) ++gi;
+        const WGroup& w = ga.gr[gi];
+        GemmArgs g;
+        g.A = w.A; g.B = w.B; g.bias = nullptr; g.C = w.C; g.M = w.M; g.N = w.N; g.K = w.K;
+        g.transA = 1; g.lda = w.lda; g.rows_per_seg = w.K; g.seg_stride = 0;
+        g.transB = 0; g.ldb = w.ldb; g.ldc = w.ldc;
+        g.in_mode = w.in_mode; g.in_scale = w.in_scale; g.in_shift = w.in_shift; g.mask_src = w.mask_src; g.alpha = w.alpha;
+        g.accumulate = 1; g.out_mask = nullptr; g.out_alpha = w.alpha;
+        g.tiles_n = (w.N + BN - 1) / BN; g.ksteps = (w.K + BK - 1) / BK;
+        g.colsum_b = w.colsum_b;
+        const long long rel = it - ga.it_begin[gi];
+        const int tile = (int)(rel / g.ksteps);
+        const int ks0 = (int)(rel - (long long)tile * g.ksteps);
+        long long room = ga.it_begin[gi + 1] - it;            // stay inside this product
+        if (room > it_end - it) room = it_end - it;
+        const int ks1 = (int)min((long long)g.ksteps, ks0 + room);
+        it += ks1 - ks0;
+        if (w.in_mode == PTTS_IN_LRELU) gemm_segment<1, 0, PTTS_IN_LRELU, true>(g, As, Bs, tile, ks0, ks1);
+        else if (w.in_mode == PTTS_IN_MASKMUL) gemm_segment<1, 0, PTTS_IN_MASKMUL, true>(g, As, Bs, tile, ks0, ks1);
+        else gemm_segment<1, 0, PTTS_IN_NONE, true>(g, As, Bs, tile, ks0, ks1);
     }
 }
 
@@ -576,6 +634,40 @@ static long long gemm_slots() {
     static long long slots_env = -1;
     if (slots_env < 0) { const char* e = getenv("PTTS_GEMM_SLOTS"); slots_env = e ? atoll(e) : 0; }
     return slots_env > 0 ? slots_env : 512;
+}
+
+extern "C" int ptts_gemm_wgrad_grouped(const ptts_wgrad_desc* descs, int n, void* stream) {
+    PTTS_REQUIRE(descs && n > 0, "gemm_wgrad_grouped: no products");
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < n; base += WG_MAX) {
+        WGroupArgs ga;
+        ga.n = n - base < WG_MAX ? n - base : WG_MAX;
+        long long total = 0;
+        for (int i = 0; i < ga.n; ++i) {
+            const ptts_wgrad_desc& d = descs[base + i];
+            PTTS_REQUIRE(d.A && d.B && d.C && d.M > 0 && d.N > 0 && d.K > 0, "gemm_wgrad_grouped: bad product %d", base + i);
+            PTTS_REQUIRE(d.lda >= d.M && d.ldb >= d.N && d.ldc >= d.N && d.lda < (1LL << 31) && d.ldb < (1LL << 31) &&
+                         d.ldc < (1LL << 31), "gemm_wgrad_grouped: bad leading dims in product %d", base + i);
+            PTTS_REQUIRE(d.in_mode >= 0 && d.in_mode <= 2 && (d.in_mode != PTTS_IN_MASKMUL || d.mask_src) &&
+                         ((d.in_scale == nullptr) == (d.in_shift == nullptr)), "gemm_wgrad_grouped: bad transform in product %d", base + i);
+            WGroup& w = ga.gr[i];
+            w.A = d.A; w.B = d.B; w.C = d.C; w.colsum_b = d.colsum_b;
+            w.in_scale = d.in_scale; w.in_shift = d.in_shift; w.mask_src = d.mask_src;
+            w.M = d.M; w.N = d.N; w.K = d.K; w.lda = (int)d.lda; w.ldb = (int)d.ldb; w.ldc = (int)d.ldc;
+            w.in_mode = d.in_mode; w.alpha = d.alpha;
+            ga.it_begin[i] = total;
+            total += (long long)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN) * ((d.K + BK - 1) / BK);
+        }
+        ga.it_begin[ga.n] = total;
+        long long workers = gemm_slots();
+        if (workers > total / 8) workers = total / 8;
+        if (workers < 1) workers = 1;
+        ga.workers = (int)workers;
+        hipLaunchKernelGGL(gemm_wgrad_grouped_kernel, dim3(ga.workers), dim3(GEMM_THREADS), 0, st, ga);
+        int rc = check_launch("gemm_wgrad_grouped");
+        if (rc) return rc;
+    }
+    return PTTS_OK;
 }
 
 extern "C" int ptts_gemm(const float* A, const float* Bm, const float* bias, float* C, int M, int N, int K,

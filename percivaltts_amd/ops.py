@@ -90,6 +90,95 @@ def input_grad_only():
         _Flags.skip_param_grads = old
 
 
+# ----------------------------------------------------------------------------------------------
+# Deferred weight gradients: inside `deferred_weight_grads()` the Dense layers do not launch their
+# dW = a^T.dy product (4 tiles of 128x128 over K = 25 600: launch, zero-fill and a 128-way split for
+# 3.4 GFLOP) one by one; they queue it, and flush_weight_grads() runs every queued product of the
+# backward pass in ONE grouped launch that accumulates straight into the parameters' .grad buffers
+# (ptts_gemm_wgrad_grouped).  Only parameters whose .grad exists beforehand (FlatParams views) take
+# part; everything else keeps the immediate path.
+# ----------------------------------------------------------------------------------------------
+class _Deferred(object):
+    active = False
+    items = []          # (x2, dy2, mask, scale, shift, gw, gb, M_out, N, K_rows, mode, alpha)
+    streams = []
+
+
+@contextlib.contextmanager
+def deferred_weight_grads():
+    old = _Deferred.active
+    _Deferred.active = True
+    try:
+        yield
+        flush_weight_grads()
+    finally:
+        _Deferred.active = old
+        _Deferred.items = []
+        _Deferred.streams = []
+
+
+def grad_target(p):
+    """The persistent gradient buffer behind parameter `p` (a leaf with .grad allocated, or a contiguous row slice of
+    one), as a tensor view with p's shape -- or None."""
+    if p is None or not p.requires_grad:
+        return None
+    if p.is_leaf:
+        g = p.grad
+        return g if (g is not None and g.is_contiguous() and g.shape == p.shape) else None
+    base = p._base
+    if base is None or not base.is_leaf or base.grad is None or not p.is_contiguous() or not base.grad.is_contiguous():
+        return None
+    if base.stride() != base.grad.stride():
+        return None
+    off = p.storage_offset() - base.storage_offset()
+    return base.grad.view(-1)[off:off + p.numel()].view(p.shape)
+
+
+_WG_FLUSH_AT = int(__import__('os').environ.get('PTTS_WG_FLUSH', '3'))     # > 0: launch a stream's queue once it holds this many
+
+
+def _defer_wgrad(x2, dy2, gw, gb, K_in, N, M_rows, mode, scale, shift, mask_src, alpha):
+    cur = torch.cuda.current_stream()
+    if all(cur.cuda_stream != s.cuda_stream for s in _Deferred.streams):
+        _Deferred.streams.append(cur)
+    _Deferred.items.append((cur.cuda_stream, x2, dy2, mask_src, scale, shift, gw, gb, K_in, N, M_rows, mode, alpha))
+    if _WG_FLUSH_AT > 0:
+        mine = [it for it in _Deferred.items if it[0] == cur.cuda_stream]
+        if len(mine) >= _WG_FLUSH_AT:
+            _Deferred.items = [it for it in _Deferred.items if it[0] != cur.cuda_stream]
+            _launch_wgrads(mine)
+
+
+def _launch_wgrads(items):
+    cur = torch.cuda.current_stream()
+    descs = (_hip.WGradDesc * len(items))()
+    for d, (_, x2, dy2, mask_src, scale, shift, gw, gb, K_in, N, M_rows, mode, alpha) in zip(descs, items):
+        for t in (x2, dy2, mask_src):
+            if t is not None:
+                t.record_stream(cur)
+        d.A, d.B, d.C, d.colsum_b = x2.data_ptr(), dy2.data_ptr(), gw.data_ptr(), (gb.data_ptr() if gb is not None else None)
+        d.in_scale = scale.data_ptr() if scale is not None else None
+        d.in_shift = shift.data_ptr() if shift is not None else None
+        d.mask_src = mask_src.data_ptr() if mask_src is not None else None
+        d.M, d.N, d.K = K_in, N, M_rows
+        d.lda, d.ldb, d.ldc = x2.stride(0), dy2.stride(0), gw.stride(0)
+        d.in_mode, d.alpha = mode, alpha
+    call('ptts_gemm_wgrad_grouped', ctypes.cast(descs, ctypes.c_void_p), len(items), stream(), tag=(len(items),))
+
+
+def flush_weight_grads():
+    items = _Deferred.items
+    if not items:
+        return
+    cur = torch.cuda.current_stream()
+    for s in _Deferred.streams:           # operands produced on the side streams of the backward pass
+        if s.cuda_stream != cur.cuda_stream:
+            cur.wait_stream(s)
+    _launch_wgrads(items)
+    _Deferred.items = []
+    _Deferred.streams = []
+
+
 _ws_cache = {}
 
 
@@ -293,6 +382,9 @@ class DenseFn(torch.autograd.Function):
         ctx.save_for_backward(x, w, scale, shift)
         ctx.has_b = b is not None
         ctx.cfg = (mode, alpha)
+        # persistent gradient buffers of the kernel / bias (for the deferred, grouped weight-gradient launch)
+        ctx.gw = grad_target(w) if _Deferred.active else None
+        ctx.gb = grad_target(b) if (_Deferred.active and b is not None) else None
         return y
 
     @staticmethod
@@ -312,13 +404,18 @@ class DenseFn(torch.autograd.Function):
         if second_order:
             if scale is not None:
                 raise RuntimeError('second-order gradients through a BatchNorm-fused dense layer are not supported')
-            dx = DenseBwdDataFn.apply(dy, x, w, mode, alpha)
+            dx = DenseBwdDataFn.apply(dy, x, w, mode, alpha, ctx.gw)
         with torch.no_grad():
             if need_x and not second_order:
                 dx2, dscale, dshift = _dense_bwd_data(dy2, x2, w, mode, scale, shift, alpha, need_aff)
                 dx = dx2.view(x.shape)
             elif need_aff:
                 _, dscale, dshift = _dense_bwd_data(dy2, x2, w, mode, scale, shift, alpha, True)
+            if need_w and _Deferred.active and ctx.gw is not None and N > 4 and (not need_b or ctx.gb is not None) \
+                    and M >= 4096 and (scale is None or mode == IN_LRELU):
+                # queued for the grouped launch, which adds into the .grad buffers itself (no dw / db for autograd)
+                _defer_wgrad(x2, dy2, ctx.gw, ctx.gb if need_b else None, K, N, M, mode, scale, shift, None, alpha)
+                need_w = need_b = False
             if need_w:
                 dw = torch.empty_like(w)
                 # the bias gradient (column sums of dy) rides on the weight-gradient product, whose B operand is dy
@@ -334,11 +431,12 @@ class DenseFn(torch.autograd.Function):
 
 class DenseBwdDataFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, dy, x, w, mode, alpha):
+    def forward(ctx, dy, x, w, mode, alpha, gw=None):
         K, N = w.shape
         M = x.numel() // K
         ctx.save_for_backward(dy, x, w)
         ctx.cfg = (mode, alpha)
+        ctx.gw = gw                      # the kernel's persistent gradient buffer (deferred grouped launch), or None
         dx2, _, _ = _dense_bwd_data(dy.view(M, N), x.view(M, K), w, mode, None, None, alpha, False)
         return dx2.view(x.shape)
 
@@ -357,10 +455,13 @@ class DenseBwdDataFn(torch.autograd.Function):
             gemm_raw(u2, w, cot_dy, M, N, K, mode=m2, mask_src=msk, alpha=alpha)
             cot_dy = cot_dy.view(dy.shape)
         if ctx.needs_input_grad[2]:
-            cot_w = torch.empty_like(w)
-            gemm_raw(u2, dy.view(M, N), cot_w, K, N, M, transA=1, lda=K, rows_per_seg=M,
-                     mode=m2, mask_src=msk, alpha=alpha)
-        return cot_dy, None, cot_w, None, None
+            if _Deferred.active and ctx.gw is not None and N > 4 and M >= 4096:
+                _defer_wgrad(u2, dy.view(M, N), ctx.gw, None, K, N, M, m2, None, None, msk, alpha)
+            else:
+                cot_w = torch.empty_like(w)
+                gemm_raw(u2, dy.view(M, N), cot_w, K, N, M, transA=1, lda=K, rows_per_seg=M,
+                         mode=m2, mask_src=msk, alpha=alpha)
+        return cot_dy, None, cot_w, None, None, None
 
 
 def dense(v, w, b=None):

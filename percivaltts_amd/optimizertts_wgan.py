@@ -240,8 +240,9 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
     # ---- device-side steps (no host synchronisation) -----------------------------------------------------------
     def critic_step(self, X, Y, alpha=None):
         self.critic_opti.zero_grad()
-        total, _ = self.critic_loss(X, Y, alpha, training=True)
-        total.backward()
+        with ops.deferred_weight_grads():       # the Dense layers' weight gradients run as one grouped launch at exit
+            total, _ = self.critic_loss(X, Y, alpha, training=True)
+            total.backward()
         self.critic_opti.step(parallel.allreduce_sum_(self.critic_opti.flat.grad))
         if self.cfg.train_wgan_weight_clip:
             c = float(self.cfg.train_wgan_weight_clip)
@@ -253,8 +254,9 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         cps = self.critic_opti.flat.params
         for p in cps: p.requires_grad_(False)      # frozen critic (:160-161)
         try:
-            total, _ = self.generator_loss(X, Y, training=True)
-            total.backward()
+            with ops.deferred_weight_grads():
+                total, _ = self.generator_loss(X, Y, training=True)
+                total.backward()
         finally:
             for p in cps: p.requires_grad_(True)
         self.gen_opti.step(parallel.allreduce_sum_(self.gen_opti.flat.grad))

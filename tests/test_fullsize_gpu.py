@@ -164,3 +164,49 @@ def test_batch_gradient_is_the_mean_of_the_shard_gradients(setup):
     tb, _, gb = _critic_grads(opt, X[h:].contiguous(), Y[h:].contiguous(), alpha[h:].contiguous(), fake[h:].contiguous())
     close(t, 0.5 * (ta + tb), 2e-5, 1e-6, 'loss of the batch vs mean of the shard losses')
     assert rel_l2(gfull, 0.5 * (ga + gb)) < 5e-5
+
+
+def test_grouped_weight_gradients_equal_per_layer_products(setup):
+    """ops.deferred_weight_grads(): the Dense layers' weight (and bias) gradients of a whole backward pass, queued and run
+    as one grouped launch that accumulates into the .grad buffers, against the per-layer products autograd accumulates."""
+    from percivaltts_amd import ops
+    cfg, opt, crit, X, Y = setup
+    g = torch.Generator().manual_seed(6)
+    alpha = torch.rand(B, generator=g).cuda()
+    with torch.no_grad():
+        fake = opt._fake_sample(X, True).detach()
+    t1, p1, g1 = _critic_grads(opt, X, Y, alpha, fake)
+    opt.critic_opti.zero_grad()
+    from percivaltts_amd import _hip
+    with _hip.KernelTimer() as kt:
+        with ops.deferred_weight_grads():
+            total, parts = opt.critic_loss(X, Y, alpha, training=True, fake=fake)
+            assert not ops._Deferred.items
+            total.backward()
+    assert not ops._Deferred.items
+    grouped = [tag[0] for (name, tag, _) in kt.durations_ms() if name == 'ptts_gemm_wgrad_grouped']
+    assert sum(grouped) >= 8                          # the critic's Dense layers, first and second order
+    assert not any(name == 'ptts_gemm' and tag[3] == 1 and tag[1] > 4 and tag[5] == 0 for (name, tag, _) in kt.durations_ms())
+    torch.cuda.synchronize()
+    g2 = opt.critic_opti.flat.grad.detach().clone()
+    close(total, t1, 1e-6, 1e-7, 'loss')
+    assert rel_l2(g2, g1) < 2e-5
+    # generator step: BatchNorm-fused Dense layers (scale/shift in the product's load transform)
+    cps = opt.critic_opti.flat.params
+    for p in cps: p.requires_grad_(False)
+    try:
+        opt.gen_opti.zero_grad()
+        tot, _ = opt.generator_loss(X, Y, training=True)
+        tot.backward(); torch.cuda.synchronize()
+        ga = opt.gen_opti.flat.grad.detach().clone()
+        opt.gen_opti.zero_grad()
+        with ops.deferred_weight_grads():
+            tot2, _ = opt.generator_loss(X, Y, training=True)
+            tot2.backward()
+        torch.cuda.synchronize()
+        gb = opt.gen_opti.flat.grad.detach().clone()
+    finally:
+        for p in cps: p.requires_grad_(True)
+    # two runs of the SAME (immediate) generator step already differ by ~1e-4 relative L2: the split products combine their
+    # partial tiles with fp32 atomics and a last-bit difference can move a LeakyReLU mask (tools/wg_check.py)
+    assert rel_l2(gb, ga) < 5e-4
