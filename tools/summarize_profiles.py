@@ -18,7 +18,7 @@ def short(name):
     return name.split('(')[0][:70]
 
 
-rows = list(csv.DictReader(open(glob.glob(src + '/trace/runc/*_kernel_stats.csv')[0])))
+rows = list(csv.DictReader(open(max(glob.glob(src + '/trace/runc/*_kernel_stats.csv'), key=os.path.getmtime))))
 total = sum(float(r['TotalDurationNs']) for r in rows)
 lines = ['# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline   (round %s)' % tag,
          '# total kernel time %.1f ms' % (total / 1e6),
@@ -32,7 +32,7 @@ open('profiles/%s_bench_under_rocprof.json' % tag, 'w').write(bench + '\n')
 
 
 def pmc(dirname, counter):
-    f = glob.glob(src + '/' + dirname + '/runc/*_counter_collection.csv')
+    f = sorted(glob.glob(src + '/' + dirname + '/runc/*_counter_collection.csv'), key=os.path.getmtime)[-1:]
     out = {}
     if not f:
         return out
