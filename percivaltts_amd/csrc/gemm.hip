@@ -328,6 +328,224 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_mfma_kernel(GemmArgs g)
 }
 
 // ------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the 128x128 kernel for products without an A transform and B stored [k][n] (the context Conv1D
+// forward and weight gradient): the tiles go global -> LDS with global_load_lds_dwordx4 (each lane names its own 16
+// source bytes; a wave-instruction fills 1 KB of LDS: lane L at base + 16 L), three stages deep, so the k-loop holds no
+// staging registers, no ds_write and no wait on loads in front of the MFMAs.  The legacy body serves edge tiles.
+//   A, TRANSA == 0: stage image [128 rows][16 k], the four quads of a row XOR-swizzled by (row>>2)&3 so that the
+//     fragment reads are conflict-free ds_read_b128: lane (l31, lh) takes k = 8 lh + 4 j + e of row l31 (j = 0,1) and
+//     MFMA (j, e) multiplies the k-pair {4j+e, 8+4j+e};  B (and A^T for TRANSA == 1): image [16 k][128], read at row
+//     8 lh + 4 j + e.
+// ------------------------------------------------------------------------------------------------
+typedef const void __attribute__((address_space(1)))* dma_gptr;
+typedef void __attribute__((address_space(3)))* dma_lptr;
+constexpr int DMA_STAGES = 3;
+constexpr int DMA_STAGE_FLOATS = BM * BK + BK * BN;      // 4096 floats = 16 KB
+
+// Issued through inline assembly: the compiler treats its builtin for this instruction as an LDS write that every later
+// LDS read and every following DMA must wait for (s_waitcnt vmcnt(0) after each one), which serialises exactly the loads
+// this path exists to keep in flight.  The kernel orders them itself (s_waitcnt vmcnt(N) + barrier before a stage is read).
+__device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
+    // wave-uniform LDS byte address -> M0
+    const unsigned lds_off = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long)(dma_lptr)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_off) : "memory");
+}
+
+template <int TRANSA, bool ATOMIC>
+__device__ __forceinline__ void gemm_segment_dma(const GemmArgs& g, float* lds, int tile, int ks0, int ks1) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int m0 = (tile / g.tiles_n) * BM, n0 = (tile % g.tiles_n) * BN;
+    const int kfull = g.K / BK;                      // k-steps that lie completely inside K
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // per-lane source addressing of the two A and two B wave-instructions of a k-step
+    long long abase[2];            // TRANSA == 0: element offset of this lane's row (+ swizzled quad);  == 1: column offset
+    int aseg[2], arem[2];          // TRANSA == 1: (segment, row in segment) of this lane's k row at the current step
+    if (TRANSA == 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r = 32 * wave + 16 * q + (lane >> 2);          // row of the tile
+            const int cg = (lane & 3) ^ ((r >> 2) & 3);              // global quad that goes to this lane's LDS slot
+            abase[q] = rowbase(g, m0 + r) + 4 * cg;
+        }
+    } else {
+        const int rps = (int)g.rows_per_seg;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int k = ks0 * BK + 4 * wave + 2 * q + (lane >> 5);
+            aseg[q] = k / rps; arem[q] = k - aseg[q] * rps;
+            abase[q] = m0 + 4 * (lane & 31);
+        }
+    }
+    const float* bsrc = g.B + (long long)(4 * wave + (lane >> 5)) * g.ldb + n0 + 4 * (lane & 31);   // + (k0 + 2q) * ldb
+
+    auto issue = [&](int ks, int stage) {        // the four DMA wave-instructions of k-step ks into `stage`
+        float* st = lds + stage * DMA_STAGE_FLOATS;
+        const int k0 = ks * BK;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (TRANSA == 0) {
+                dma16(g.A + abase[q] + k0, st + (32 * wave + 16 * q) * BK);
+            } else {
+                dma16(g.A + (long long)aseg[q] * g.seg_stride + (long long)arem[q] * g.lda + abase[q], st + (4 * wave + 2 * q) * BM);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) dma16(bsrc + (long long)(k0 + 2 * q) * g.ldb, st + BM * BK + (4 * wave + 2 * q) * BN);
+        if (TRANSA == 1) {
+            const int rps = (int)g.rows_per_seg;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { arem[q] += BK; while (arem[q] >= rps) { arem[q] -= rps; ++aseg[q]; } }
+        }
+    };
+    // a k-step that crosses K (the tail): registers, zeros beyond K, same LDS image
+    auto stage_tail = [&](int ks, int stage) {
+        float* st = lds + stage * DMA_STAGE_FLOATS;
+        const int k0 = ks * BK;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (TRANSA == 0) {
+                const int r = 32 * wave + 16 * q + (lane >> 2);
+                const int cg = (lane & 3) ^ ((r >> 2) & 3);
+                const float* p = g.A + abase[q] + k0;
+                const int k = k0 + 4 * cg;
+                if (k < g.K) v.x = p[0];
+                if (k + 1 < g.K) v.y = p[1];
+                if (k + 2 < g.K) v.z = p[2];
+                if (k + 3 < g.K) v.w = p[3];
+                *reinterpret_cast<float4*>(st + r * BK + 4 * (lane & 3)) = v;
+            } else {
+                const int kr = 4 * wave + 2 * q + (lane >> 5);
+                if (k0 + kr < g.K) {
+                    const f32x4u t = *reinterpret_cast<const f32x4u*>(g.A + (long long)aseg[q] * g.seg_stride + (long long)arem[q] * g.lda + abase[q]);
+                    v = make_float4(t[0], t[1], t[2], t[3]);
+                }
+                *reinterpret_cast<float4*>(st + kr * BM + 4 * (lane & 31)) = v;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int kr = 4 * wave + 2 * q + (lane >> 5);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k0 + kr < g.K) {
+                const f32x4u t = *reinterpret_cast<const f32x4u*>(bsrc + (long long)(k0 + 2 * q) * g.ldb);
+                v = make_float4(t[0], t[1], t[2], t[3]);
+            }
+            *reinterpret_cast<float4*>(st + BM * BK + kr * BN + 4 * (lane & 31)) = v;
+        }
+    };
+    auto feed = [&](int ks, int stage) { if (ks < kfull) issue(ks, stage); else stage_tail(ks, stage); };
+
+    const bool want_bsum = g.colsum_b != nullptr && m0 == 0;
+    float bsum = 0.f;
+    const int nsteps = ks1 - ks0;
+    feed(ks0, 0);
+    if (nsteps > 1) feed(ks0 + 1, 1);
+    for (int s = 0; s < nsteps; ++s) {
+        // this wave's DMAs of step s have landed when at most the four of step s+1 are still in flight
+        if (s + 1 < nsteps && ks0 + s + 1 < kfull) __builtin_amdgcn_s_waitcnt(0xF74);     // vmcnt(4)
+        else __builtin_amdgcn_s_waitcnt(0xF70);                                           // vmcnt(0)
+        __syncthreads();           // every wave's part of stage s is in LDS; stage (s+2)%3 is no longer read
+        if (s + 2 < nsteps) feed(ks0 + s + 2, (s + 2) % DMA_STAGES);
+        const float* st = lds + (s % DMA_STAGES) * DMA_STAGE_FLOATS;
+        const float* bt = st + BM * BK;
+        if (want_bsum && tid < BN) {          // bias gradient: column sums of the B tile (first row of tiles only)
+#pragma unroll
+            for (int kk = 0; kk < BK; ++kk) bsum += bt[kk * BN + tid];
+        }
+        float av[2][2][4], bv[2][2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (TRANSA == 0) {
+                const int r = wm + 32 * i + l31;
+                const int sw = (r >> 2) & 3;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float4 t = *reinterpret_cast<const float4*>(st + r * BK + 4 * ((2 * lh + j) ^ sw));
+                    av[i][j][0] = t.x; av[i][j][1] = t.y; av[i][j][2] = t.z; av[i][j][3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) av[i][j][e] = st[(8 * lh + 4 * j + e) * BM + wm + 32 * i + l31];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[t][j][e] = bt[(8 * lh + 4 * j + e) * BN + wn + 32 * t + l31];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][j][e], bv[0][j][e], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][j][e], bv[1][j][e], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][j][e], bv[0][j][e], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][j][e], bv[1][j][e], acc[1][1], 0, 0, 0);
+            }
+    }
+    __syncthreads();               // the stages may be refilled by the next segment
+    if (want_bsum && tid < BN) atomicAdd(g.colsum_b + n0 + tid, bsum);
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool whole = !ATOMIC && (ks0 == 0) && (ks1 == g.ksteps);
+    const bool add_bias = g.bias != nullptr && ks0 == 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn + j * 32 + l31;
+            const float bv2 = add_bias ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float* cp = g.C + (long long)m * g.ldc + n;
+                const float v = acc[i][j][r] + bv2;
+                if (!whole) atomicAdd(cp, v);
+                else if (g.accumulate) *cp += v;
+                else *cp = v;
+            }
+        }
+}
+
+template <int TRANSA>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_dma_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float lds[DMA_STAGES * DMA_STAGE_FLOATS];
+    if (g.prio && (int)blockIdx.x >= (int)(gridDim.x / 2)) __builtin_amdgcn_s_setprio(3);
+    long long it = g.iters_total * blockIdx.x / g.workers;
+    const long long it_end = g.iters_total * (blockIdx.x + 1) / g.workers;
+    while (it < it_end) {
+        const int tile = (int)(it / g.ksteps);
+        const int ks0 = (int)(it - (long long)tile * g.ksteps);
+        const int ks1 = (int)min((long long)g.ksteps, ks0 + (it_end - it));
+        it += ks1 - ks0;
+        const int m0 = (tile / g.tiles_n) * BM, n0 = (tile % g.tiles_n) * BN;
+        if ((m0 + BM <= g.M) && (n0 + BN <= g.N)) {
+            gemm_segment_dma<TRANSA, false>(g, lds, tile, ks0, ks1);
+        } else {
+            // edge tile: the register-staged body (its two double-buffered images fit in the same LDS)
+            float (*As)[BK * LDA_S] = reinterpret_cast<float (*)[BK * LDA_S]>(lds);
+            float (*Bs)[BK * LDB_S] = reinterpret_cast<float (*)[BK * LDB_S]>(lds + 2 * BK * LDA_S);
+            gemm_segment<TRANSA, 0, PTTS_IN_NONE, false>(g, As, Bs, tile, ks0, ks1);
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Grouped weight gradients: up to WG_MAX products C_i += a_i^T . dy_i (+ column sums of dy_i) in ONE launch.  A Dense
 // layer's weight gradient alone (256 x 256 x 25 600) has 4 tiles: split over 512 workgroups each gets 12 k-steps and
 // pays the launch, the zero-fill and a 64 KB atomic epilogue for them (47 TF).  All layers of a backward pass together
@@ -784,7 +1002,13 @@ extern "C" int ptts_gemm(const float* A, const float* Bm, const float* bias, flo
         case PTTS_IN_MASKMUL: PTTS_GEMM_LAUNCH(TA, TB, 0, PTTS_IN_MASKMUL); break; \
         default: PTTS_GEMM_LAUNCH(TA, TB, 0, PTTS_IN_NONE); break;               \
     }
-    if (conv && in_mode == PTTS_IN_NONE && transA == 0 && transB == 0) PTTS_GEMM_LAUNCH(0, 0, 1, PTTS_IN_NONE);
+    static int use_dma = -1;
+    if (use_dma < 0) { const char* e = getenv("PTTS_GEMM_DMA"); use_dma = e ? atoi(e) : 1; }
+    // A rows are fetched as 16-byte pieces by the LDS-DMA path: the product must not need masking inside a row
+    const bool dma_ok = use_dma && in_mode == PTTS_IN_NONE && transB == 0 && !out_mask && K >= 4 * BK;
+    if (dma_ok && conv && transA == 0) hipLaunchKernelGGL((gemm_dma_kernel<0>), grid, block, 0, st, g);
+    else if (dma_ok && conv && transA == 1) hipLaunchKernelGGL((gemm_dma_kernel<1>), grid, block, 0, st, g);
+    else if (conv && in_mode == PTTS_IN_NONE && transA == 0 && transB == 0) PTTS_GEMM_LAUNCH(0, 0, 1, PTTS_IN_NONE);
     else if (conv && in_mode == PTTS_IN_NONE && transA == 1 && transB == 0) PTTS_GEMM_LAUNCH(1, 0, 1, PTTS_IN_NONE);
     else if (transA == 0 && transB == 0) { PTTS_GEMM_MODES(0, 0) }
     else if (transA == 0 && transB == 1) { PTTS_GEMM_MODES(0, 1) }
