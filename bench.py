@@ -161,7 +161,7 @@ def roofline_leg(opt, X, Y, args):
     if conv1d_fwd:
         t = sum(conv1d_fwd) / len(conv1d_fwd) * 1e-3
         fl = 2.0 * M * N * K
-        out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_f32_mfma_kernel<0,0,1> (context Conv1D as implicit GEMM, M={} N={} K={})'.format(M, N, K),
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_dma_kernel<0> (context Conv1D as implicit GEMM, M={} N={} K={})'.format(M, N, K),
                            'achieved': fl / t / 1e12, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                            'frac': fl / t / 1e12 / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
                            'launch_ms': t * 1e3, 'launches_per_critic_step': len(conv1d_fwd)}
@@ -195,8 +195,9 @@ def roofline_leg(opt, X, Y, args):
         cands = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_traffic.json'))
         if cands and B == 64 and T == 400 and X.shape[2] == 601:
             tr = json.load(open(os.path.join(ROOT, 'profiles', cands[-1])))
-            if 'roofline' in out and 'gemm_f32_mfma_kernel<0, 0, 1, 0>' in tr:
-                out['roofline']['traffic'] = tr['gemm_f32_mfma_kernel<0, 0, 1, 0>']['hbm_bytes_per_launch']
+            key = next((k for k in ('gemm_dma_kernel<0>', 'gemm_f32_mfma_kernel<0, 0, 1, 0>') if k in tr), None)
+            if 'roofline' in out and key:
+                out['roofline']['traffic'] = tr[key]['hbm_bytes_per_launch']
                 out['roofline']['traffic_source'] = 'profiles/' + cands[-1]
             if 'roofline_conv2d' in out and 'conv2d_fwd_kernel<4, 4, 5, 5, 1, false>' in tr:
                 out['roofline_conv2d']['traffic_fwd_4to4_per_launch'] = tr['conv2d_fwd_kernel<4, 4, 5, 5, 1, false>']['hbm_bytes_per_launch']

@@ -449,14 +449,21 @@ __device__ __forceinline__ void gemm_segment_dma(const GemmArgs& g, float* lds, 
     const bool want_bsum = g.colsum_b != nullptr && m0 == 0;
     float bsum = 0.f;
     const int nsteps = ks1 - ks0;
-    feed(ks0, 0);
-    if (nsteps > 1) feed(ks0 + 1, 1);
+    constexpr int AHEAD = DMA_STAGES - 1;          // k-steps in flight beyond the one being multiplied
+#pragma unroll
+    for (int p = 0; p < AHEAD; ++p)
+        if (p < nsteps) feed(ks0 + p, p);
     for (int s = 0; s < nsteps; ++s) {
-        // this wave's DMAs of step s have landed when at most the four of step s+1 are still in flight
-        if (s + 1 < nsteps && ks0 + s + 1 < kfull) __builtin_amdgcn_s_waitcnt(0xF74);     // vmcnt(4)
-        else __builtin_amdgcn_s_waitcnt(0xF70);                                           // vmcnt(0)
-        __syncthreads();           // every wave's part of stage s is in LDS; stage (s+2)%3 is no longer read
-        if (s + 2 < nsteps) feed(ks0 + s + 2, (s + 2) % DMA_STAGES);
+        // this wave's DMAs of step s have landed when at most those of the later steps already issued (4 each) are in
+        // flight; a tail step (staged through registers) drains everything itself
+        int later = nsteps - 1 - s;
+        if (later > AHEAD - 1) later = AHEAD - 1;
+        if (ks0 + s + later >= kfull) later = 0;
+        if (later >= 2) __builtin_amdgcn_s_waitcnt(0xF78);           // vmcnt(8)
+        else if (later == 1) __builtin_amdgcn_s_waitcnt(0xF74);      // vmcnt(4)
+        else __builtin_amdgcn_s_waitcnt(0xF70);                      // vmcnt(0)
+        __syncthreads();           // every wave's part of stage s is in LDS; the stage of step s-1 is no longer read
+        if (s + AHEAD < nsteps) feed(ks0 + s + AHEAD, (s + AHEAD) % DMA_STAGES);
         const float* st = lds + (s % DMA_STAGES) * DMA_STAGE_FLOATS;
         const float* bt = st + BM * BK;
         if (want_bsum && tid < BN) {          // bias gradient: column sums of the B tile (first row of tiles only)
@@ -487,6 +494,8 @@ __device__ __forceinline__ void gemm_segment_dma(const GemmArgs& g, float* lds, 
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bv[t][j][e] = bt[(8 * lh + 4 * j + e) * BN + wn + 32 * t + l31];
+        // (forcing all fragment reads ahead of the MFMAs with a sched_barrier measured 10 % slower than the scheduler's
+        // interleaving; so did a fourth stage: the loop is not bound by load latency any more)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
