@@ -1015,8 +1015,8 @@ extern "C" int ptts_gemm(const float* A, const float* Bm, const float* bias, flo
     if (use_dma < 0) { const char* e = getenv("PTTS_GEMM_DMA"); use_dma = e ? atoi(e) : 1; }
     // A rows are fetched as 16-byte pieces by the LDS-DMA path: the product must not need masking inside a row
     const bool dma_ok = use_dma && in_mode == PTTS_IN_NONE && transB == 0 && !out_mask && K >= 4 * BK;
-    if (dma_ok && conv && transA == 0) hipLaunchKernelGGL((gemm_dma_kernel<0>), grid, block, 0, st, g);
-    else if (dma_ok && conv && transA == 1) hipLaunchKernelGGL((gemm_dma_kernel<1>), grid, block, 0, st, g);
+    if (dma_ok && transA == 0) hipLaunchKernelGGL((gemm_dma_kernel<0>), grid, block, 0, st, g);
+    else if (dma_ok && transA == 1) hipLaunchKernelGGL((gemm_dma_kernel<1>), grid, block, 0, st, g);
     else if (conv && in_mode == PTTS_IN_NONE && transA == 0 && transB == 0) PTTS_GEMM_LAUNCH(0, 0, 1, PTTS_IN_NONE);
     else if (conv && in_mode == PTTS_IN_NONE && transA == 1 && transB == 0) PTTS_GEMM_LAUNCH(1, 0, 1, PTTS_IN_NONE);
     else if (transA == 0 && transB == 0) { PTTS_GEMM_MODES(0, 0) }
