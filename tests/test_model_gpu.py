@@ -40,6 +40,9 @@ GEOMS = {
     'default': dict(ctx=61, spec=65, nm=20, H=32, nctx=1, kctx=21, L=8, C=4, kt=5, kf=5, B=3, T=50),
     # no conv layers: the critic's FC spectral branch (networks_critic.py:72-76)
     'nocnn': dict(ctx=20, spec=9, nm=3, H=8, nctx=1, kctx=5, L=0, C=2, kt=3, kf=3, B=2, T=12),
+    # 4160 frames: large enough for the paths the small geometries never reach -- LDS-DMA GEMM tiles (interior and edge),
+    # split-K weight gradients, the grouped (deferred) weight-gradient launch, multi-tile conv2d, the packed LSTM kernels
+    'mid': dict(ctx=61, spec=65, nm=20, H=64, nctx=1, kctx=21, L=2, C=4, kt=5, kf=5, B=8, T=520),
 }
 
 
@@ -91,10 +94,12 @@ def test_predict_and_critic_forward(geom):
         close(t, w, 1e-6, 1e-7, 'weights untouched ' + k)
 
 
-@pytest.mark.parametrize('errtype', ['WLSWGAN', 'WGAN'])
-@pytest.mark.parametrize('geom', ['test', 'default', 'nocnn'])
+@pytest.mark.parametrize('geom,errtype', [(g, e) for g in ('test', 'default', 'nocnn') for e in ('WLSWGAN', 'WGAN')] + [('mid', 'WLSWGAN')])
 def test_critic_and_generator_steps(geom, errtype):
-    from percivaltts_amd import optimizertts_wgan
+    from percivaltts_amd import optimizertts_wgan, ops
+    import contextlib
+    # 'mid' runs the device side the way critic_step / generator_step do: Dense weight gradients queued and grouped
+    deferred = ops.deferred_weight_grads if geom == 'mid' else contextlib.nullcontext
     cfg, voc, mod, crit, a, gw, cw, X, Y, al = build(geom)
     cfg.train_wgan_critic_LSWGANtransidx = 30.0 if geom != 'nocnn' else 4.0
     opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype=errtype, critic=crit)
@@ -106,12 +111,13 @@ def test_critic_and_generator_steps(geom, errtype):
     total, parts = O.critic_step_loss(cw, gw, a, X, Y, al, gp_lambda=10.0)
     grads = torch.autograd.grad(total, cw)
     opt.critic_opti.zero_grad()
-    tot_d, (lv, lf, gp) = opt.critic_loss(Xd, Yd, ald, training=True)
-    close(lv, parts['valid'], 5e-4, 1e-5, 'L valid')
-    close(lf, parts['fake'], 5e-4, 1e-5, 'L fake')
-    close(gp, parts['gp'], 5e-4, 1e-5, 'gradient penalty')
-    close(tot_d, total, 5e-4, 1e-5, 'critic loss')
-    tot_d.backward()
+    with deferred():
+        tot_d, (lv, lf, gp) = opt.critic_loss(Xd, Yd, ald, training=True)
+        close(lv, parts['valid'], 5e-4, 1e-5, 'L valid')
+        close(lf, parts['fake'], 5e-4, 1e-5, 'L fake')
+        close(gp, parts['gp'], 5e-4, 1e-5, 'gradient penalty')
+        close(tot_d, total, 5e-4, 1e-5, 'critic loss')
+        tot_d.backward()
     gmax = max(float(g.abs().max()) for g in grads)
     num = den = 0.0
     for p, g_ in zip(opt.critic_opti.flat.params, grads):
@@ -145,12 +151,13 @@ def test_critic_and_generator_steps(geom, errtype):
     ggrads = torch.autograd.grad(ltot, [gw_t[i] for i in trainable], allow_unused=True)
     opt.gen_opti.zero_grad()
     for p in opt.critic_opti.flat.params: p.requires_grad_(False)
-    ltot_d, (lw_d, lls_d) = opt.generator_loss(Xd, Yd, training=True)
-    close(lw_d, lparts['wgan'], 5e-4, 1e-5, 'generator wgan term')
-    if errtype == 'WLSWGAN':
-        close(lls_d, lparts['ls'], 5e-4, 1e-5, 'generator ls term')
-    close(ltot_d, ltot, 5e-4, 1e-5, 'generator loss')
-    ltot_d.backward()
+    with deferred():
+        ltot_d, (lw_d, lls_d) = opt.generator_loss(Xd, Yd, training=True)
+        close(lw_d, lparts['wgan'], 5e-4, 1e-5, 'generator wgan term')
+        if errtype == 'WLSWGAN':
+            close(lls_d, lparts['ls'], 5e-4, 1e-5, 'generator ls term')
+        close(ltot_d, ltot, 5e-4, 1e-5, 'generator loss')
+        ltot_d.backward()
     for p in opt.critic_opti.flat.params: p.requires_grad_(True)
     ggmax = max(float(g.abs().max()) for g in ggrads if g is not None)
     num = den = 0.0
