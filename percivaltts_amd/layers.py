@@ -650,8 +650,10 @@ class FlatParams(object):
                 self.flat[off:off + k].copy_(p.detach().reshape(-1).to(device))
                 p.data = self.flat[off:off + k].view(p.shape)
                 p.grad = self.grad[off:off + k].view(p.shape)
+                p._ptts_flat = self        # the buffer whose `epoch` counts in-place updates by raw kernels (Adam, clip)
                 off += k
         self.numel = n
+        self.epoch = 0
 
     def zero_grad(self):
         self.grad.zero_()

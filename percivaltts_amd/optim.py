@@ -27,9 +27,11 @@ class KerasAdam(object):
     def step(self, gscale=1.0):
         ops.adam_keras_step_(self.flat.flat, self.flat.grad, self.m, self.v, self.step_count,
                              self.lr, self.beta_1, self.beta_2, self.epsilon, gscale)
+        self.flat.epoch += 1          # the weights changed behind torch's version counters
 
     def clip_weights(self, lo, hi):
         ops.weight_clip_(self.flat.flat, lo, hi)
+        self.flat.epoch += 1
 
     # Keras optimizer.weights order: iterations, then all m, then all v
     def get_weights(self):

@@ -107,6 +107,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         cfg.train_wgan_hipgraph = False
         cfg.train_wgan_parallel_streams = False      # the critic evaluations on separate HIP streams
         cfg.train_wgan_stack_real_fake = True        # critic(real) and critic(fake) as one stacked 2B pass (exact: no BatchNorm)
+        cfg.train_wgan_reuse_ctx_conv = True         # generator step reuses the critic step's G-context-Conv1D product (same batch)
         return cfg
 
     # ---------------------------------------------------------------------------------------------------------
@@ -292,12 +293,19 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         """One `train_on_batch` worth of device work on resident tensors; returns (critic_loss, generator_loss|None)
         as device scalars."""
         use_graph = bool(self.cfg.train_wgan_hipgraph) and self.world == 1
-        lc = self._graphed('critic', X, Y) if use_graph else self.critic_step(X, Y)
         critic_runs = 10 if (self.generator_updates < 25) or (self.generator_updates % 500 == 0) else 5   # (:225-228)
-        lg = None
-        if batchid % critic_runs == 0:
-            lg = self._graphed('generator', X, Y) if use_graph else self.generator_step(X, Y)
-            self.generator_updates += 1
+        gen_too = batchid % critic_runs == 0
+        # the generator step that follows on the same batch reuses the generator's context-Conv1D product of the critic
+        # step's fake sample (same input, same not-yet-updated kernel): ops._C1Cache, valid inside this call only
+        ops.conv1d_cache(gen_too and not use_graph and bool(getattr(self.cfg, 'train_wgan_reuse_ctx_conv', True)))
+        try:
+            lc = self._graphed('critic', X, Y) if use_graph else self.critic_step(X, Y)
+            lg = None
+            if gen_too:
+                lg = self._graphed('generator', X, Y) if use_graph else self.generator_step(X, Y)
+                self.generator_updates += 1
+        finally:
+            ops.conv1d_cache(False)
         return lc, lg
 
     # ---- the reference's hooks --------------------------------------------------------------------------------------

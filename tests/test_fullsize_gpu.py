@@ -140,11 +140,11 @@ def test_stacked_real_fake_equals_separate_passes(setup):
     alpha = torch.rand(B, generator=g).cuda()
     with torch.no_grad():
         fake = opt._fake_sample(X, True).detach()
-    cfg.train_wgan_stack_real_fake = True
+    opt.cfg.train_wgan_stack_real_fake = True       # (the optimiser holds its own merged configuration object)
     t1, p1, g1 = _critic_grads(opt, X, Y, alpha, fake)
-    cfg.train_wgan_stack_real_fake = False
+    opt.cfg.train_wgan_stack_real_fake = False
     t2, p2, g2 = _critic_grads(opt, X, Y, alpha, fake)
-    cfg.train_wgan_stack_real_fake = True
+    opt.cfg.train_wgan_stack_real_fake = True
     for a, b, nm in zip(p1, p2, ('valid', 'fake', 'gp')):
         close(a, b, 1e-5, 1e-6, 'stacked vs separate: ' + nm)
     assert rel_l2(g1, g2) < 2e-5
@@ -210,3 +210,45 @@ def test_grouped_weight_gradients_equal_per_layer_products(setup):
     # two runs of the SAME (immediate) generator step already differ by ~1e-4 relative L2: the split products combine their
     # partial tiles with fp32 atomics and a last-bit difference can move a LeakyReLU mask (tools/wg_check.py)
     assert rel_l2(gb, ga) < 5e-4
+
+
+def test_generator_step_reuses_the_context_conv_of_the_critic_step(setup):
+    """device_step on a batch that also trains the generator: with ops._C1Cache the generator step takes the generator's
+    context-Conv1D product from the critic step's fake sample; weights after the step must equal the recomputing path."""
+    from percivaltts_amd import ops, _hip
+    cfg, opt, crit, X, Y = setup
+
+    def snapshot():
+        return [t.detach().clone() for t in (opt.critic_opti.flat.flat, opt.critic_opti.m, opt.critic_opti.v, opt.critic_opti.step_count,
+                                             opt.gen_opti.flat.flat, opt.gen_opti.m, opt.gen_opti.v, opt.gen_opti.step_count)]
+
+    def restore(snap):
+        for dst, src in zip((opt.critic_opti.flat.flat, opt.critic_opti.m, opt.critic_opti.v, opt.critic_opti.step_count,
+                             opt.gen_opti.flat.flat, opt.gen_opti.m, opt.gen_opti.v, opt.gen_opti.step_count), snap):
+            dst.copy_(src)
+        opt.critic_opti.flat.epoch += 1; opt.gen_opti.flat.epoch += 1
+
+    bn_state = [(k, t.detach().clone()) for k, t in opt._model.kerasmodel.weights() if 'moving' in k]
+    snap = snapshot()
+    torch.manual_seed(7)
+    results = []
+    for reuse in (True, False):
+        restore(snap)
+        for (k, t), (_, t0) in zip([(k, t) for k, t in opt._model.kerasmodel.weights() if 'moving' in k], bn_state):
+            t.copy_(t0)
+        opt.cfg.train_wgan_reuse_ctx_conv = reuse
+        torch.manual_seed(7)                       # same interpolation weights
+        with _hip.KernelTimer() as kt:
+            opt.device_step(0, X, Y)               # batchid 0: critic step + generator step
+        torch.cuda.synchronize()
+        nconv = sum(1 for (name, tag, _) in kt.durations_ms()
+                    if name == 'ptts_gemm' and tag[5] == 1 and tag[3] == 0)      # context-Conv1D forward products
+        results.append((opt.gen_opti.flat.grad.detach().clone(), opt.critic_opti.flat.grad.detach().clone(), nconv))
+    opt.cfg.train_wgan_reuse_ctx_conv = True
+    restore(snap)
+    assert results[0][2] == results[1][2] - 1, 'one context-Conv1D forward fewer with the cache: {} vs {}'.format(results[0][2], results[1][2])
+    # the gradients the two Adam steps consumed (still in the flat buffers).  Two runs of the same step already differ by
+    # ~1e-4 relative L2 in the generator gradient (fp32 atomics in the split products, tools/wg_check.py); the weights
+    # themselves are a poor yardstick here: Adam's first step moves every weight by lr*sign(g)
+    assert rel_l2(results[0][1], results[1][1]) < 1e-4          # the critic's gradient does not depend on the cache
+    assert rel_l2(results[0][0], results[1][0]) < 5e-4          # the generator's gradient
