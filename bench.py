@@ -41,6 +41,7 @@ def parse():
     ap.add_argument('--eager', action='store_true', help='(default) eager launches; kept for compatibility')
     ap.add_argument('--no-prune', action='store_true', help="also run G's f0/noise branches in the critic step")
     ap.add_argument('--no-stack', action='store_true', help='evaluate critic(real) and critic(fake) separately instead of as one 2B pass')
+    ap.add_argument('--no-ctx-reuse', action='store_true', help="recompute the generator's context Conv1D in the generator step instead of taking the critic step's product of the same batch")
     ap.add_argument('--no-streams', action='store_true', help='single HIP stream (default: the three critic evaluations and the BLSTM branch on side streams)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -225,6 +226,7 @@ def main():
     cfg.train_wgan_prune_dead_branches = not args.no_prune
     cfg.train_wgan_parallel_streams = (not args.no_streams) and not cfg.train_wgan_hipgraph
     cfg.train_wgan_stack_real_fake = not args.no_stack
+    cfg.train_wgan_reuse_ctx_conv = not args.no_ctx_reuse
     spec, nm = 65, 20
     voc = vocoders.VocoderPML(16000, 0.005, spec, nm)
     import io, contextlib
@@ -302,6 +304,8 @@ def main():
                        'parallelism': 'dp{}'.format(world), 'hipgraph': bool(cfg.train_wgan_hipgraph),
                        'hip_streams': 3 if par_streams else 1,
                        'prune_dead_generator_branches_in_critic_step': bool(cfg.train_wgan_prune_dead_branches),
+                       'stack_real_fake_critic_pass': bool(cfg.train_wgan_stack_real_fake),
+                       'reuse_generator_ctx_conv_within_train_on_batch': bool(cfg.train_wgan_reuse_ctx_conv),
                        'generator_params': mod.count_params(), 'critic_params': crit.model.count_params()},
         }
         res.update(extra)
