@@ -162,7 +162,7 @@ def roofline_leg(opt, X, Y, args):
     if conv1d_fwd:
         t = sum(conv1d_fwd) / len(conv1d_fwd) * 1e-3
         fl = 2.0 * M * N * K
-        out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_dma_kernel<0> (context Conv1D as implicit GEMM, M={} N={} K={})'.format(M, N, K),
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_dma_kernel<0, 1> (context Conv1D as implicit GEMM, M={} N={} K={})'.format(M, N, K),
                            'achieved': fl / t / 1e12, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                            'frac': fl / t / 1e12 / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
                            'launch_ms': t * 1e3, 'launches_per_critic_step': len(conv1d_fwd)}
@@ -196,7 +196,7 @@ def roofline_leg(opt, X, Y, args):
         cands = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_traffic.json'))
         if cands and B == 64 and T == 400 and X.shape[2] == 601:
             tr = json.load(open(os.path.join(ROOT, 'profiles', cands[-1])))
-            key = next((k for k in ('gemm_dma_kernel<0>', 'gemm_f32_mfma_kernel<0, 0, 1, 0>') if k in tr), None)
+            key = next((k for k in ('gemm_dma_kernel<0, 1>', 'gemm_dma_kernel<0>', 'gemm_f32_mfma_kernel<0, 0, 1, 0>') if k in tr), None)
             if 'roofline' in out and key:
                 out['roofline']['traffic'] = tr[key]['hbm_bytes_per_launch']
                 out['roofline']['traffic_source'] = 'profiles/' + cands[-1]

@@ -530,7 +530,9 @@ __device__ __forceinline__ void gemm_segment_dma(const GemmArgs& g, float* lds, 
         }
 }
 
-template <int TRANSA>
+// CONV != 0 marks the implicit-convolution instantiation (same code; its own symbol so that a profile separates the
+// context-Conv1D products from the other ones that take this path).
+template <int TRANSA, int CONV>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_dma_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float lds[DMA_STAGES * DMA_STAGE_FLOATS];
     if (g.prio && (int)blockIdx.x >= (int)(gridDim.x / 2)) __builtin_amdgcn_s_setprio(3);
@@ -1015,8 +1017,10 @@ extern "C" int ptts_gemm(const float* A, const float* Bm, const float* bias, flo
     if (use_dma < 0) { const char* e = getenv("PTTS_GEMM_DMA"); use_dma = e ? atoi(e) : 1; }
     // A rows are fetched as 16-byte pieces by the LDS-DMA path: the product must not need masking inside a row
     const bool dma_ok = use_dma && in_mode == PTTS_IN_NONE && transB == 0 && !out_mask && K >= 4 * BK;
-    if (dma_ok && transA == 0) hipLaunchKernelGGL((gemm_dma_kernel<0>), grid, block, 0, st, g);
-    else if (dma_ok && transA == 1) hipLaunchKernelGGL((gemm_dma_kernel<1>), grid, block, 0, st, g);
+    if (dma_ok && transA == 0 && conv) hipLaunchKernelGGL((gemm_dma_kernel<0, 1>), grid, block, 0, st, g);
+    else if (dma_ok && transA == 1 && conv) hipLaunchKernelGGL((gemm_dma_kernel<1, 1>), grid, block, 0, st, g);
+    else if (dma_ok && transA == 0) hipLaunchKernelGGL((gemm_dma_kernel<0, 0>), grid, block, 0, st, g);
+    else if (dma_ok && transA == 1) hipLaunchKernelGGL((gemm_dma_kernel<1, 0>), grid, block, 0, st, g);
     else if (conv && in_mode == PTTS_IN_NONE && transA == 0 && transB == 0) PTTS_GEMM_LAUNCH(0, 0, 1, PTTS_IN_NONE);
     else if (conv && in_mode == PTTS_IN_NONE && transA == 1 && transB == 0) PTTS_GEMM_LAUNCH(1, 0, 1, PTTS_IN_NONE);
     else if (transA == 0 && transB == 0) { PTTS_GEMM_MODES(0, 0) }
