@@ -11,7 +11,6 @@ fp32 kernels vs fp64 oracle: rtol 2e-4 (the north star's bar is 1e-3)."""
 import io
 import contextlib
 
-import numpy as np
 import pytest
 import torch
 

@@ -1,6 +1,5 @@
 """CPU tests of the host-side mirror of the reference API (no kernels are launched)."""
 import os
-import pickle
 
 import numpy as np
 import pytest

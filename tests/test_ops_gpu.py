@@ -3,7 +3,6 @@ fp32 kernels vs fp64 oracle: rtol 1e-4 / atol 1e-5 unless a test states otherwis
 (the north star's bar is 1e-3 rtol)."""
 import math
 
-import numpy as np
 import pytest
 import torch
 

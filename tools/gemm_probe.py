@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from percivaltts_amd import ops
 
-B, T, Cin, N, KW = 64, 400, int(os.environ.get("CIN", 601)), 256, 21
+B, T, Cin, N, KW = 64, 400, int(os.environ.get("CIN", 601)), int(os.environ.get("NOUT", 256)), 21
 which = sys.argv[1] if len(sys.argv) > 1 else 'both'
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = 'cuda'
