@@ -463,16 +463,17 @@ __global__ __launch_bounds__(CONV_THREADS) void conv2d_bwd_kernel(
             const int fs = (s - r * nspr) * P;
             const int t = t0 + r;
             if (t >= T) continue;
-            constexpr bool PKI = (CIN % 2 == 0);
-            constexpr int HI = PKI ? CIN / 2 : 1;
+            // packed over PAIRS OF co: da[p][ci] keeps the partial sums of the even and of the odd output channels in the two
+            // halves of one register pair; g's pairs are the natural halves of the loaded pixel and the weight pairs
+            // (w[tap][ci][co], w[tap][ci][co+1]) are adjacent in the kernel as stored -- no transposed copy of w is needed
+            constexpr bool PKI = (COUT % 2 == 0);
+            constexpr int HO2 = PKI ? COUT / 2 : 1;
             float da[P][CIN];
-            f2 da2[P][HI];
+            f2 da2[P][CIN];
 #pragma unroll
             for (int p = 0; p < P; ++p) {
 #pragma unroll
-                for (int ci = 0; ci < CIN; ++ci) da[p][ci] = 0.f;
-#pragma unroll
-                for (int h = 0; h < HI; ++h) da2[p][h] = (f2){0.f, 0.f};
+                for (int ci = 0; ci < CIN; ++ci) { da[p][ci] = 0.f; da2[p][ci] = (f2){0.f, 0.f}; }
             }
 #pragma unroll 1
             for (int kt = 0; kt < KT; ++kt) {
@@ -485,14 +486,15 @@ __global__ __launch_bounds__(CONV_THREADS) void conv2d_bwd_kernel(
                     for (int kf = 0; kf < KF; ++kf) {
                         const int p = j - (KF - 1 - kf);
                         if (p < 0 || p >= P) continue;
+                        const float* wk = w + ((kt * KF + kf) * CIN) * COUT;
                         if (PKI) {
-                            const f2* wt2 = reinterpret_cast<const f2*>(wt + ((kt * KF + kf) * COUT) * CIN);
+                            const f2* wk2 = reinterpret_cast<const f2*>(wk);
 #pragma unroll
-                            for (int co = 0; co < COUT; ++co)
+                            for (int ci = 0; ci < CIN; ++ci)
 #pragma unroll
-                                for (int h = 0; h < HI; ++h) da2[p][h] = pkfma(g[co], wt2[co * HI + h], da2[p][h]);
+                                for (int h = 0; h < HO2; ++h)
+                                    da2[p][ci] = __builtin_elementwise_fma((f2){g[2 * h], g[2 * h + (PKI ? 1 : 0)]}, wk2[ci * HO2 + h], da2[p][ci]);
                         } else {
-                            const float* wk = w + ((kt * KF + kf) * CIN) * COUT;
 #pragma unroll
                             for (int ci = 0; ci < CIN; ++ci)
 #pragma unroll
@@ -506,10 +508,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv2d_bwd_kernel(
 #pragma unroll
                 for (int p = 0; p < P; ++p)
 #pragma unroll
-                    for (int h = 0; h < HI; ++h) {
-                        da[p][2 * h] = da2[p][h].x;
-                        da[p][2 * h + (PKI ? 1 : 0)] = da2[p][h].y;
-                    }
+                    for (int ci = 0; ci < CIN; ++ci) da[p][ci] = da2[p][ci].x + da2[p][ci].y;
             }
             const float* arow = at + ((size_t)r * Fp + fs) * CIN;
             const float* xrow = xt + ((size_t)r * Fp + fs) * CIN;
@@ -1054,8 +1053,6 @@ extern "C" int ptts_conv2d_bwd(const float* dy, const float* x, const float* w, 
             }                                                                                              \
             float* wt = (float*)workspace;                                                                 \
             float* parts = (float*)((char*)workspace + WT_BYTES);                                          \
-            if ((want_dx || want_aff) && (CI % 2 == 0))                                                    \
-                hipLaunchKernelGGL(transpose_w_kernel, dim3(2), dim3(256), 0, st, w, wt, KTT * KFF, CI, CO);\
             hipLaunchKernelGGL((conv2d_bwd_kernel<CI, CO, KTT, KFF>), dim3(p.tl.ntiles, B),                \
                                dim3(CONV_THREADS), p.lds, st, dy, x, w, in_scale, in_shift, mask_src, dx,  \
                                parts, (const float*)wt, want_dx, want_dw, want_aff, T, F, p.tl.TT, dil_t,  \
