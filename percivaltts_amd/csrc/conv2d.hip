@@ -424,7 +424,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv2d_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ w,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift,
     const float* __restrict__ mask_src, float* __restrict__ dx, float* __restrict__ partials,
-    const float* __restrict__ wt /*[KT][KF][COUT][CIN]: w transposed, for pairs over ci*/,
+    const float* __restrict__ wt /*unused: head of the workspace, kept for the layout of the partials behind it*/,
     int want_dx, int want_dw, int want_affine,
     int T, int F, int TT, int dil_t, int pad_t, int in_mode, float alpha) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -660,15 +660,6 @@ __global__ __launch_bounds__(CONV_THREADS) void conv2d_bwd_kernel(
 #pragma unroll
         for (int wv = 0; wv < CONV_THREADS / 64; ++wv) s += red2[wv * (COUT + 2 * CIN) + tid];
         out[NW + tid] = s;
-    }
-}
-
-// wt[tap][co][ci] = w[tap][ci][co]
-__global__ void transpose_w_kernel(const float* __restrict__ w, float* __restrict__ wt, int ntaps, int cin, int cout) {
-    const int n = ntaps * cin * cout;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int ci = i % cin, co = (i / cin) % cout, tap = i / (cin * cout);
-        wt[i] = w[(tap * cin + ci) * cout + co];
     }
 }
 
