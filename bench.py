@@ -131,7 +131,7 @@ def cpu_baseline(args, cfg_dims):
 def roofline_leg(opt, X, Y, args):
     """HIP-event timing of every C-ABI call of one eager critic step (and one generator step)."""
     import torch
-    from percivaltts_amd import _hip
+    from percivaltts_amd import _hip, ops
     B, T = X.shape[0], X.shape[1]
     voc = opt._model.vocoder
     F, C, L = voc.specsize(), opt.cfg.arch_gen_nbfilters, opt.cfg.arch_gen_nbcnnlayers
@@ -177,8 +177,9 @@ def roofline_leg(opt, X, Y, args):
     for _ in range(reps):
         opt.critic_opti.zero_grad()
         with _hip.KernelTimer() as kt:
-            total, _ = opt.critic_loss(X, Y, None, training=True, fake=fake)
-            total.backward()
+            with ops.deferred_weight_grads():          # as critic_step runs it (grouped reductions included in the sum)
+                total, _ = opt.critic_loss(X, Y, None, training=True, fake=fake)
+                total.backward()
         crit_recs.append(kt.durations_ms())
     n = len(crit_recs[0])
     t_conv2d = sum(sum(r[i][2] for r in crit_recs) / reps for i in range(n) if crit_recs[0][i][0].startswith('ptts_conv2d')) * 1e-3

@@ -85,6 +85,23 @@ int ptts_conv2d_bwd(const float* dy, const float* x, const float* w,
                     int B, int T, int F, int Cin, int Cout, int KT, int KF,
                     int dil_t, int pad_mode, int in_mode, float alpha, void* stream);
 
+/* The same pass with the weight-shaped sums left unreduced: dx as above (NULL to skip), and the per-workgroup partial sums
+ * of dw / dbias as rows [nblocks][npart] (npart = KT*KF*Cin*Cout + Cout + 2*Cin) behind a 4096-byte head of the caller's
+ * workspace; *nblocks_out receives nblocks.  Only for shapes with a tiled kernel (workspace_bytes > 16) and without a
+ * BatchNorm-fused input.  ptts_conv2d_reduce_grouped then adds up to any number of such passes into their gradient
+ * buffers (dw[nw], dbias[cout]; fp32 atomics: several passes may share a buffer) in one launch per 16 passes -- the
+ * 8 layers x 3 passes of a critic step otherwise pay one 7 us reduction launch each. */
+int ptts_conv2d_bwd_partials(const float* dy, const float* x, const float* w, const float* mask_src,
+                             float* dx, void* workspace, size_t workspace_bytes, int* nblocks_out,
+                             int B, int T, int F, int Cin, int Cout, int KT, int KF,
+                             int dil_t, int pad_mode, int in_mode, float alpha, void* stream);
+typedef struct ptts_conv2d_reduce_desc {
+    const float* partials;      /* workspace + 4096 bytes */
+    int nblocks, npart, nw, cout;
+    float* dw; float* dbias;    /* accumulated into; either may be NULL */
+} ptts_conv2d_reduce_desc;
+int ptts_conv2d_reduce_grouped(const ptts_conv2d_reduce_desc* descs, int n, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * fp32 GEMM on the MFMA pipe (v_mfma_f32_32x32x2_f32), with implicit-convolution row
  * addressing for the context Conv1D.  Replaces keras Dense (networktts.py:60; heads at

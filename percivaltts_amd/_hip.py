@@ -24,6 +24,11 @@ class WGradDesc(ctypes.Structure):
                 ('M', c_i), ('N', c_i), ('K', c_i), ('lda', c_ll), ('ldb', c_ll), ('ldc', c_ll), ('in_mode', c_i), ('alpha', c_f)]
 
 
+class Conv2dReduceDesc(ctypes.Structure):
+    """struct ptts_conv2d_reduce_desc of include/percival_hip.h (one queued conv2d backward pass)."""
+    _fields_ = [('partials', c_p), ('nblocks', c_i), ('npart', c_i), ('nw', c_i), ('cout', c_i), ('dw', c_p), ('dbias', c_p)]
+
+
 # name -> (restype, argtypes); must mirror include/percival_hip.h exactly
 SIGNATURES = {
     'ptts_version': (ctypes.c_char_p, []),
@@ -34,6 +39,8 @@ SIGNATURES = {
     'ptts_conv2d_bwd': (c_i, [c_p] * 11 + [c_p, c_sz] + [c_i] * 10 + [c_f, c_p]),
     'ptts_gemm': (c_i, [c_p] * 4 + [c_i] * 3 + [c_i, c_ll, c_ll, c_ll, c_i, c_ll, c_ll, c_i, c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p]),
     'ptts_gemm_wgrad_grouped': (c_i, [c_p, c_i, c_p]),
+    'ptts_conv2d_bwd_partials': (c_i, [c_p] * 5 + [c_p, c_sz, c_p] + [c_i] * 10 + [c_f, c_p]),
+    'ptts_conv2d_reduce_grouped': (c_i, [c_p, c_i, c_p]),
     'ptts_colstats_workspace_bytes': (c_sz, [c_ll, c_i]),
     'ptts_colstats': (c_i, [c_p, c_ll, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_sz, c_p]),
     'ptts_bn_finalize': (c_i, [c_p, c_ll, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),

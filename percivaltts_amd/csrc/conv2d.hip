@@ -1013,11 +1013,14 @@ extern "C" size_t ptts_conv2d_bwd_workspace_bytes(int B, int T, int F, int Cin, 
     return 16;
 }
 
-extern "C" int ptts_conv2d_bwd(const float* dy, const float* x, const float* w, const float* in_scale,
-                               const float* in_shift, const float* mask_src, float* dx, float* dw,
-                               float* dbias, float* dscale, float* dshift, void* workspace,
-                               size_t workspace_bytes, int B, int T, int F, int Cin, int Cout, int KT, int KF,
-                               int dil_t, int pad_mode, int in_mode, float alpha, void* stream) {
+// partials_only: the dw / dbias sums stay as per-workgroup rows in the caller's workspace ([WT_BYTES head][nblocks][npart],
+// nblocks returned through *nblocks_out) for ptts_conv2d_reduce_grouped; dw / dbias are not written.
+static int conv2d_bwd_impl(const float* dy, const float* x, const float* w, const float* in_scale,
+                           const float* in_shift, const float* mask_src, float* dx, float* dw,
+                           float* dbias, float* dscale, float* dshift, void* workspace,
+                           size_t workspace_bytes, int B, int T, int F, int Cin, int Cout, int KT, int KF,
+                           int dil_t, int pad_mode, int in_mode, float alpha, void* stream, int partials_only,
+                           int* nblocks_out) {
     PTTS_REQUIRE(dy && x && w, "conv2d_bwd: null tensor");
     PTTS_REQUIRE(B > 0 && T > 0 && F > 0 && Cin > 0 && Cout > 0 && KT > 0 && KF > 0 && dil_t > 0,
                  "conv2d_bwd: bad dims");
@@ -1030,7 +1033,7 @@ extern "C" int ptts_conv2d_bwd(const float* dy, const float* x, const float* w, 
     PTTS_REQUIRE(B <= 65535, "conv2d_bwd: B too large");
     hipStream_t st = (hipStream_t)stream;
     const ConvGeom g = geom(KT, dil_t, pad_mode);
-    const int want_dx = dx != nullptr, want_dw = (dw != nullptr || dbias != nullptr), want_aff = dscale != nullptr;
+    const int want_dx = dx != nullptr, want_dw = (dw != nullptr || dbias != nullptr || partials_only), want_aff = dscale != nullptr;
     if (!want_dx && !want_dw && !want_aff) return PTTS_OK;
 #define BWD_CASE(CI, CO, KTT, KFF)                                                                         \
     if (Cin == CI && Cout == CO && KT == KTT && KF == KFF) {                                               \
@@ -1050,7 +1053,8 @@ extern "C" int ptts_conv2d_bwd(const float* dy, const float* x, const float* w, 
                                g.pad_t, in_mode, alpha);                                                   \
             int rc = check_launch("conv2d_bwd");                                                           \
             if (rc) return rc;                                                                             \
-            if (want_dw || want_aff) {                                                                     \
+            if (nblocks_out) *nblocks_out = nblocks;                                                       \
+            if ((want_dw || want_aff) && !partials_only) {                                                 \
                 hipLaunchKernelGGL(reduce_partials_kernel, dim3(p.npart), dim3(256), 0, st,                \
                                    (const float*)parts, nblocks, p.npart, want_dw ? dw : nullptr,          \
                                    KTT * KFF * CI * CO, want_dw ? dbias : nullptr, CO, dscale, dshift, CI);\
@@ -1061,6 +1065,7 @@ extern "C" int ptts_conv2d_bwd(const float* dy, const float* x, const float* w, 
     }
     PTTS_CONV_CASES(BWD_CASE)
 #undef BWD_CASE
+    PTTS_REQUIRE(!partials_only, "conv2d_bwd_partials: this shape has no tiled kernel (workspace_bytes == 16): use ptts_conv2d_bwd");
     const long long npix = (long long)B * T * F;
     if (want_dx) {
         const long long total = npix * Cin;
@@ -1077,6 +1082,76 @@ extern "C" int ptts_conv2d_bwd(const float* dy, const float* x, const float* w, 
                            mask_src, want_dw ? dw : nullptr, want_dw ? dbias : nullptr, dscale, dshift, npix, T,
                            F, Cin, Cout, KT, KF, dil_t, g.pad_t, in_mode, alpha);
         return check_launch("conv2d_bwd_w_generic");
+    }
+    return PTTS_OK;
+}
+
+extern "C" int ptts_conv2d_bwd(const float* dy, const float* x, const float* w, const float* in_scale,
+                               const float* in_shift, const float* mask_src, float* dx, float* dw,
+                               float* dbias, float* dscale, float* dshift, void* workspace,
+                               size_t workspace_bytes, int B, int T, int F, int Cin, int Cout, int KT, int KF,
+                               int dil_t, int pad_mode, int in_mode, float alpha, void* stream) {
+    return conv2d_bwd_impl(dy, x, w, in_scale, in_shift, mask_src, dx, dw, dbias, dscale, dshift, workspace, workspace_bytes,
+                           B, T, F, Cin, Cout, KT, KF, dil_t, pad_mode, in_mode, alpha, stream, 0, nullptr);
+}
+
+extern "C" int ptts_conv2d_bwd_partials(const float* dy, const float* x, const float* w, const float* mask_src,
+                                        float* dx, void* workspace, size_t workspace_bytes, int* nblocks_out,
+                                        int B, int T, int F, int Cin, int Cout, int KT, int KF,
+                                        int dil_t, int pad_mode, int in_mode, float alpha, void* stream) {
+    PTTS_REQUIRE(nblocks_out, "conv2d_bwd_partials: nblocks_out is NULL");
+    return conv2d_bwd_impl(dy, x, w, nullptr, nullptr, mask_src, dx, nullptr, nullptr, nullptr, nullptr, workspace,
+                           workspace_bytes, B, T, F, Cin, Cout, KT, KF, dil_t, pad_mode, in_mode, alpha, stream, 1, nblocks_out);
+}
+
+// dw[j] += sum_blk partials[blk][j] (j < nw), dbias[j - nw] += ... (nw <= j < nw + cout) for up to RG_MAX queued passes in
+// one launch: block -> (pass, column); fp32 atomics because several passes may add into the same gradient buffer.
+constexpr int RG_MAX = 16;
+struct ReduceGroupArgs {
+    int n;
+    int col_begin[RG_MAX + 1];
+    const float* partials[RG_MAX]; int nblocks[RG_MAX], npart[RG_MAX], nw[RG_MAX];
+    float* dw[RG_MAX]; float* dbias[RG_MAX];
+};
+
+__global__ __launch_bounds__(256) void conv2d_reduce_grouped_kernel(ReduceGroupArgs a) {
+    __shared__ double sh[4];
+    int gi = 0;
+    while ((int)blockIdx.x >= a.col_begin[gi + 1]) ++gi;
+    const int j = blockIdx.x - a.col_begin[gi];
+    const float* p = a.partials[gi];
+    const int npart = a.npart[gi], nblocks = a.nblocks[gi];
+    double s = 0.0;
+    for (int blk = threadIdx.x; blk < nblocks; blk += 256) s += (double)p[(size_t)blk * npart + j];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+        if (j < a.nw[gi]) { if (a.dw[gi]) atomicAdd(a.dw[gi] + j, v); }
+        else if (a.dbias[gi]) atomicAdd(a.dbias[gi] + (j - a.nw[gi]), v);
+    }
+}
+
+extern "C" int ptts_conv2d_reduce_grouped(const ptts_conv2d_reduce_desc* descs, int n, void* stream) {
+    PTTS_REQUIRE(descs && n > 0, "conv2d_reduce_grouped: nothing to reduce");
+    for (int base = 0; base < n; base += RG_MAX) {
+        ReduceGroupArgs a;
+        a.n = n - base < RG_MAX ? n - base : RG_MAX;
+        int cols = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const ptts_conv2d_reduce_desc& d = descs[base + i];
+            PTTS_REQUIRE(d.partials && d.nblocks > 0 && d.nw > 0 && d.cout > 0 && d.npart >= d.nw + d.cout,
+                         "conv2d_reduce_grouped: bad pass %d", base + i);
+            a.col_begin[i] = cols;
+            cols += d.nw + d.cout;
+            a.partials[i] = d.partials; a.nblocks[i] = d.nblocks; a.npart[i] = d.npart; a.nw[i] = d.nw;
+            a.dw[i] = d.dw; a.dbias[i] = d.dbias;
+        }
+        a.col_begin[a.n] = cols;
+        hipLaunchKernelGGL(conv2d_reduce_grouped_kernel, dim3(cols), dim3(256), 0, (hipStream_t)stream, a);
+        int rc = check_launch("conv2d_reduce_grouped");
+        if (rc) return rc;
     }
     return PTTS_OK;
 }

@@ -101,6 +101,7 @@ def input_grad_only():
 class _Deferred(object):
     active = False
     items = []          # (x2, dy2, mask, scale, shift, gw, gb, M_out, N, K_rows, mode, alpha)
+    conv_items = []     # (partials buffer, nblocks, npart, nw, cout, gw, gb): conv2d backward passes awaiting their reduction
     streams = []
 
 
@@ -114,6 +115,7 @@ def deferred_weight_grads():
     finally:
         _Deferred.active = old
         _Deferred.items = []
+        _Deferred.conv_items = []
         _Deferred.streams = []
 
 
@@ -167,15 +169,26 @@ def _launch_wgrads(items):
 
 
 def flush_weight_grads():
-    items = _Deferred.items
-    if not items:
+    items, conv_items = _Deferred.items, _Deferred.conv_items
+    if not items and not conv_items:
         return
     cur = torch.cuda.current_stream()
     for s in _Deferred.streams:           # operands produced on the side streams of the backward pass
         if s.cuda_stream != cur.cuda_stream:
             cur.wait_stream(s)
-    _launch_wgrads(items)
+    if items:
+        _launch_wgrads(items)
+    if conv_items:
+        descs = (_hip.Conv2dReduceDesc * len(conv_items))()
+        for d, (buf, nblocks, npart, nw, cout, gw, gb) in zip(descs, conv_items):
+            buf.record_stream(cur)
+            d.partials = buf.data_ptr() + 4096
+            d.nblocks, d.npart, d.nw, d.cout = nblocks, npart, nw, cout
+            d.dw = gw.data_ptr() if gw is not None else None
+            d.dbias = gb.data_ptr() if gb is not None else None
+        call('ptts_conv2d_reduce_grouped', ctypes.cast(descs, ctypes.c_void_p), len(conv_items), stream(), tag=(len(conv_items),))
     _Deferred.items = []
+    _Deferred.conv_items = []
     _Deferred.streams = []
 
 
@@ -229,6 +242,30 @@ def _conv2d_bwd_raw(dy, x, w, scale, shift, mask_src, mode, alpha, dil_t, pad_mo
          B, T, F, Cin, Cout, KT, KF, dil_t, pad_mode, mode, alpha, stream(),
          tag=(B, T, F, Cin, Cout, mode, int(want_dx), int(want_dw or want_db), int(want_affine)))
     return dx, (dw if want_dw else None), db, dscale, dshift
+
+
+def _conv2d_bwd_deferred(dy, x, w, mask_src, mode, alpha, dil_t, pad_mode, want_dx, gw, gb):
+    """conv2d backward whose dw / dbias stay as per-workgroup partial sums in a buffer of their own; the reduction into
+    the gradient buffers gw / gb is queued for the grouped launch at flush time.  Returns dx (or None), or False when
+    this shape has no tiled kernel."""
+    B, T, F, Cin = x.shape
+    KT, KF, _, Cout = w.shape
+    nws = _hip.lib().ptts_conv2d_bwd_workspace_bytes(B, T, F, Cin, Cout, KT, KF, dil_t)
+    if nws <= 16:
+        return False
+    dev = x.device
+    buf = torch.empty(int(nws), dtype=torch.uint8, device=dev)
+    dx = torch.empty_like(x) if want_dx else None
+    nblocks = ctypes.c_int(0)
+    call('ptts_conv2d_bwd_partials', ptr(dy), ptr(x), ptr(w), ptr(mask_src), ptr(dx), ptr(buf), buf.numel(),
+         ctypes.byref(nblocks), B, T, F, Cin, Cout, KT, KF, dil_t, pad_mode, mode, alpha, stream(),
+         tag=(B, T, F, Cin, Cout, mode, int(want_dx), 1, 0))
+    cur = torch.cuda.current_stream()
+    if all(cur.cuda_stream != s.cuda_stream for s in _Deferred.streams):
+        _Deferred.streams.append(cur)
+    nw = KT * KF * Cin * Cout
+    _Deferred.conv_items.append((buf, nblocks.value, nw + Cout + 2 * Cin, nw, Cout, gw, gb))
+    return dx
 
 
 def gemm_raw(A, Bm, C, M, N, K, transA=0, lda=None, rows_per_seg=None, seg_stride=0, transB=0, ldb=None, ldc=None,
@@ -290,6 +327,9 @@ class Conv2dFn(torch.autograd.Function):
         ctx.save_for_backward(x, w, scale, shift)
         ctx.has_b = b is not None
         ctx.cfg = (mode, alpha, dil_t, pad_mode)
+        # persistent gradient buffers of kernel / bias (deferred, grouped reduction of the backward's partial sums)
+        ctx.gw = grad_target(w) if _Deferred.active else None
+        ctx.gb = grad_target(b) if (_Deferred.active and b is not None) else None
         return _conv2d_fwd_raw(x, w, b, scale, shift, None, mode, alpha, dil_t, pad_mode)
 
     @staticmethod
@@ -305,24 +345,38 @@ class Conv2dFn(torch.autograd.Function):
             # differentiable backward (gradient penalty): dx is itself a Function of (dy, w)
             if scale is not None:
                 raise RuntimeError('second-order gradients through a BatchNorm-fused conv2d are not supported')
-            dx = Conv2dBwdDataFn.apply(dy, x, w, mode, alpha, dil_t, pad_mode)
+            dx = Conv2dBwdDataFn.apply(dy, x, w, mode, alpha, dil_t, pad_mode, ctx.gw)
             dw = db = None
             if need_w or need_b:
                 with torch.no_grad():
+                    if _conv2d_can_defer(ctx, need_w, need_b) and \
+                            _conv2d_bwd_deferred(dy, x, w, None, mode, alpha, dil_t, pad_mode, False,
+                                                 ctx.gw if need_w else None, ctx.gb if need_b else None) is not False:
+                        return dx, None, None, None, None, None, None, None, None
                     _, dw, db, _, _ = _conv2d_bwd_raw(dy, x, w, None, None, None, mode, alpha, dil_t, pad_mode,
                                                       False, need_w, need_b, False)
             return dx, dw, db, None, None, None, None, None, None
+        if (need_w or need_b) and not need_aff and scale is None and _conv2d_can_defer(ctx, need_w, need_b):
+            dxd = _conv2d_bwd_deferred(dy, x, w, None, mode, alpha, dil_t, pad_mode, need_x,
+                                       ctx.gw if need_w else None, ctx.gb if need_b else None)
+            if dxd is not False:
+                return dxd, None, None, None, None, None, None, None, None
         dx, dw, db, dscale, dshift = _conv2d_bwd_raw(dy, x, w, scale, shift, None, mode, alpha, dil_t, pad_mode,
                                                      need_x, need_w, need_b, need_aff)
         return dx, dw, db, dscale, dshift, None, None, None, None
 
 
+def _conv2d_can_defer(ctx, need_w, need_b):
+    return _Deferred.active and (not need_w or ctx.gw is not None) and (not need_b or ctx.gb is not None)
+
+
 class Conv2dBwdDataFn(torch.autograd.Function):
     """dx = d(a)/d(x) * conv^T(dy, w).  Linear in dy and in w; its backward is the second-order sweep."""
     @staticmethod
-    def forward(ctx, dy, x, w, mode, alpha, dil_t, pad_mode):
+    def forward(ctx, dy, x, w, mode, alpha, dil_t, pad_mode, gw=None):
         ctx.save_for_backward(dy, x, w)
         ctx.cfg = (mode, alpha, dil_t, pad_mode)
+        ctx.gw = gw
         dx, _, _, _, _ = _conv2d_bwd_raw(dy, x, w, None, None, None, mode, alpha, dil_t, pad_mode,
                                          True, False, False, False)
         return dx
@@ -338,9 +392,12 @@ class Conv2dBwdDataFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             cot_dy = _conv2d_fwd_raw(u, w, None, None, None, msk, m2, alpha, dil_t, pad_mode)
         if ctx.needs_input_grad[2]:
+            if _Deferred.active and ctx.gw is not None and \
+                    _conv2d_bwd_deferred(dy, u, w, msk, m2, alpha, dil_t, pad_mode, False, ctx.gw, None) is not False:
+                return cot_dy, None, None, None, None, None, None, None
             _, cot_w, _, _, _ = _conv2d_bwd_raw(dy, u, w, None, None, msk, m2, alpha, dil_t, pad_mode,
                                                 False, True, False, False)
-        return cot_dy, None, cot_w, None, None, None, None
+        return cot_dy, None, cot_w, None, None, None, None, None
 
 
 def conv2d(v, w, b=None, dil_t=1, pad_mode=PAD_SAME):
