@@ -42,6 +42,7 @@ def parse():
     ap.add_argument('--no-prune', action='store_true', help="also run G's f0/noise branches in the critic step")
     ap.add_argument('--no-stack', action='store_true', help='evaluate critic(real) and critic(fake) separately instead of as one 2B pass')
     ap.add_argument('--no-ctx-reuse', action='store_true', help="recompute the generator's context Conv1D in the generator step instead of taking the critic step's product of the same batch")
+    ap.add_argument('--no-early-critic', action='store_true', help='generator step: critic(G(x)) on the concatenated output (waits for the BLSTM branch) instead of on the spectral branch')
     ap.add_argument('--no-streams', action='store_true', help='single HIP stream (default: the three critic evaluations and the BLSTM branch on side streams)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -228,6 +229,7 @@ def main():
     cfg.train_wgan_parallel_streams = (not args.no_streams) and not cfg.train_wgan_hipgraph
     cfg.train_wgan_stack_real_fake = not args.no_stack
     cfg.train_wgan_reuse_ctx_conv = not args.no_ctx_reuse
+    cfg.train_wgan_early_critic = not args.no_early_critic
     spec, nm = 65, 20
     voc = vocoders.VocoderPML(16000, 0.005, spec, nm)
     import io, contextlib

@@ -462,8 +462,11 @@ class Model(nn.Module):
                     s |= self.deps[id(p)]
                 self.deps[id(n)] = s
 
-    def _run(self, feed, training, memo, values=None, only_dep=None):
-        """Evaluate the nodes not yet in `values`.  Nodes tagged `stream = 1` (an independent branch such as the
+    def _run(self, feed, training, memo, values=None, only_dep=None, hold=None):
+        """Evaluate the nodes not yet in `values`.  `hold` (ids of nodes): these and everything that depends on them is
+        left for a later call with the same `values` -- e.g. the generator's final concatenation, so that the critic can
+        start on the spectral part while the side-stream branch still runs; the side-stream bookkeeping travels in
+        values['__side__'].  Nodes tagged `stream = 1` (an independent branch such as the
         generator's latency-bound BLSTM) are enqueued on a side HIP stream when `self.parallel_branches` is set, so
         that they overlap with the rest of the graph; autograd replays the same streams in the backward pass (and,
         processing nodes in reverse creation order, enqueues the main-stream backward first)."""
@@ -471,6 +474,9 @@ class Model(nn.Module):
         use_side = bool(getattr(self, 'parallel_branches', False)) and torch.cuda.is_available()
         side, cur, pending = None, None, False
         on_side = set()
+        if '__side__' in values:
+            on_side, pending, side, cur = values.pop('__side__')
+        held = set()
         order = self.order
         if use_side and os.environ.get('PTTS_SIDE_DEFER', '0') != '0':
             # (experiment, off: enqueue the main-stream nodes that do not need a side-stream result first.  Measured
@@ -489,6 +495,9 @@ class Model(nn.Module):
             if not n.parents:
                 values[id(n)] = feed[id(n)]
                 given.add(id(n))
+                continue
+            if hold and (id(n) in hold or any(id(p) in held for p in n.parents)):
+                held.add(id(n))
                 continue
             vals = [values[id(p)] for p in n.parents]
             if use_side and getattr(n, 'stream', 0):
@@ -517,7 +526,9 @@ class Model(nn.Module):
                         if torch.is_tensor(t):
                             t.record_stream(cur)
             values[id(n)] = n.layer.compute(vals, training, memo)
-        if pending:
+        if held:
+            values['__side__'] = (on_side, pending, side, cur)      # the join happens in the call that finishes the graph
+        elif pending:
             cur.wait_stream(side)
         return values
 

@@ -108,6 +108,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         cfg.train_wgan_parallel_streams = False      # the critic evaluations on separate HIP streams
         cfg.train_wgan_stack_real_fake = True        # critic(real) and critic(fake) as one stacked 2B pass (exact: no BatchNorm)
         cfg.train_wgan_reuse_ctx_conv = True         # generator step reuses the critic step's G-context-Conv1D product (same batch)
+        cfg.train_wgan_early_critic = True           # generator step: critic starts on the spectral branch, BLSTM joins for the LS term
         return cfg
 
     # ---------------------------------------------------------------------------------------------------------
@@ -230,9 +231,31 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         return ok
 
     def generator_loss(self, X, Y, training=True):
-        pred = self._model.kerasmodel(X, training=training)
-        valid = self.critic_net(pred, X, training=training)
-        l_w = wasserstein_loss(-1.0, valid)
+        m = self._model.kerasmodel
+        node_spec = getattr(self._model, 'node_spec', None)
+        if getattr(self, '_gen_spec', None) is not None and node_spec is not None and m.single_output and \
+                bool(getattr(self.cfg, 'train_wgan_early_critic', True)):
+            # The critic reads the spectral columns only (the condition under which the critic step prunes the other
+            # branches).  It is therefore fed the spectral branch as soon as that exists, while the latency-bound f0
+            # branch (BLSTM, side stream) still runs; the final concatenation -- the join with the side stream -- is
+            # needed by the least-squares term alone and comes last.  Same values.  (Also tried: creating the BLSTM's
+            # autograd node last so that its backward chain is enqueued first -- slower, the host then spends 1 ms on
+            # the chain's 400 launches before the wide kernels of the backward pass are queued.)
+            feed = {id(m.inputs[0]): X}
+            out_node = m.outputs[0]
+            values = m._run(feed, training, None, hold={id(out_node)})
+            spec = kl.to_tensor(values[id(node_spec)])
+            voc = self._model.vocoder
+            feat = torch.zeros(X.shape[0], X.shape[1], voc.featuressize(), dtype=torch.float32, device=X.device)
+            feat[:, :, 1:1 + voc.specsize()] = spec
+            valid = self.critic_net(feat, X, training=training)
+            l_w = wasserstein_loss(-1.0, valid)
+            values = m._run(feed, training, None, values=values)
+            pred = kl.to_tensor(values[id(out_node)])
+        else:
+            pred = m(X, training=training)
+            valid = self.critic_net(pred, X, training=training)
+            l_w = wasserstein_loss(-1.0, valid)
         if self._errtype == 'WGAN':
             return l_w, (l_w, None)
         l_ls = specweighted_lse_loss(Y, pred, self._w_ls)
