@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 (same table); the bf16x6 split product spends six bf16 products per fp32 product
 PEAK_HBM_GBPS = 8000.0          # HBM3E spec
 
 
@@ -45,7 +46,9 @@ def parse():
     ap.add_argument('--no-early-critic', action='store_true', help='generator step: critic(G(x)) on the concatenated output (waits for the BLSTM branch) instead of on the spectral branch')
     ap.add_argument('--no-streams', action='store_true', help='single HIP stream (default: the three critic evaluations and the BLSTM branch on side streams)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--split-bf16', action='store_true', help='context Conv1D forward as a bf16x6 split product on the bf16 matrix cores (fp32-level accuracy; off by default, see DESIGN.md)')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-variants', action='store_true', help='skip the extra timed loop of the bf16x6 context-Conv1D variant')
     ap.add_argument('--no-host-leg', action='store_true', help='skip the PCIe-inclusive leg (host batches through the prefetcher)')
     ap.add_argument('--cpu-batch', type=int, default=32)
     return ap.parse_args()
@@ -154,6 +157,7 @@ def roofline_leg(opt, X, Y, args):
     M, N, K = B * T, opt.cfg.arch_hiddenwidth, opt.cfg.arch_ctx_winlen * X.shape[2]
     conv1d_fwd = [d for (nm, tag, d) in avg if nm == 'ptts_gemm' and tag == (M, N, K, 0, 0, 1)]
     conv1d_bww = [d for (nm, tag, d) in avg if nm == 'ptts_gemm' and tag == (K, N, M, 1, 0, 1)]
+    conv1d_split = [d for (nm, tag, d) in avg if nm == 'ptts_conv1d_bf16x6']
     # the critic's conv2d stack: every conv2d call without a BatchNorm affine whose batch is B (G's convs carry scale/shift
     # or are 1->C without bias; separate them by running G first)
     classes = {}
@@ -167,6 +171,14 @@ def roofline_leg(opt, X, Y, args):
                            'achieved': fl / t / 1e12, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                            'frac': fl / t / 1e12 / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
                            'launch_ms': t * 1e3, 'launches_per_critic_step': len(conv1d_fwd)}
+    if conv1d_split:
+        # six bf16 products per fp32 product: the fp32-equivalent peak of this formulation is the dense bf16 peak / 6
+        t = sum(conv1d_split) / len(conv1d_split) * 1e-3
+        fl = 2.0 * M * N * K
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_bf16x6_kernel (context Conv1D, M={} N={} K={}; algorithmic fp32 flop, 6 bf16 MFMA products each)'.format(M, N, K),
+                           'achieved': fl / t / 1e12, 'peak': PEAK_BF16_MFMA_TFLOPS / 6.0, 'unit': 'TFLOP/s',
+                           'frac': fl / t / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 6.0), 'traffic': None,
+                           'launch_ms': t * 1e3, 'launches_per_critic_step': len(conv1d_split)}
     if conv1d_bww:
         t = sum(conv1d_bww) / len(conv1d_bww) * 1e-3
         out['conv1d_bwd_weight'] = {'achieved': 2.0 * M * N * K / t / 1e12, 'unit': 'TFLOP/s', 'launch_ms': t * 1e3}
@@ -182,9 +194,9 @@ def roofline_leg(opt, X, Y, args):
                 total, _ = opt.critic_loss(X, Y, None, training=True, fake=fake)
                 total.backward()
         crit_recs.append(kt.durations_ms())
-    n = len(crit_recs[0])
-    t_conv2d = sum(sum(r[i][2] for r in crit_recs) / reps for i in range(n) if crit_recs[0][i][0].startswith('ptts_conv2d')) * 1e-3
-    n_conv2d = sum(1 for i in range(n) if crit_recs[0][i][0].startswith('ptts_conv2d'))
+    # (summed per repetition: the call list of the first one may hold a refresh of cached operands the others do not)
+    t_conv2d = sum(sum(d for (nm, _, d) in r if nm.startswith('ptts_conv2d')) for r in crit_recs) / reps * 1e-3
+    n_conv2d = sum(1 for (nm, _, _) in crit_recs[-1] if nm.startswith('ptts_conv2d'))
     alg_bytes = (149.0 * C + 3.0) * B * T * F * 4.0 if L == 8 else None
     if alg_bytes and t_conv2d > 0:
         out['roofline_conv2d'] = {'bound': 'hbm', 'kernel': 'critic 2D-conv stack: {} conv2d fwd/bwd launches per critic step'.format(n_conv2d),
@@ -199,7 +211,7 @@ def roofline_leg(opt, X, Y, args):
         if cands and B == 64 and T == 400 and X.shape[2] == 601:
             tr = json.load(open(os.path.join(ROOT, 'profiles', cands[-1])))
             key = next((k for k in ('gemm_dma_kernel<0, 1>', 'gemm_dma_kernel<0>', 'gemm_f32_mfma_kernel<0, 0, 1, 0>') if k in tr), None)
-            if 'roofline' in out and key:
+            if 'roofline' in out and key and not conv1d_split:
                 out['roofline']['traffic'] = tr[key]['hbm_bytes_per_launch']
                 out['roofline']['traffic_source'] = 'profiles/' + cands[-1]
             if 'roofline_conv2d' in out and 'conv2d_fwd_kernel<4, 4, 5, 5, 1, false>' in tr:
@@ -230,6 +242,7 @@ def main():
     cfg.train_wgan_stack_real_fake = not args.no_stack
     cfg.train_wgan_reuse_ctx_conv = not args.no_ctx_reuse
     cfg.train_wgan_early_critic = not args.no_early_critic
+    cfg.train_wgan_split_bf16 = bool(args.split_bf16)
     spec, nm = 65, 20
     voc = vocoders.VocoderPML(16000, 0.005, spec, nm)
     import io, contextlib
@@ -258,6 +271,24 @@ def main():
     torch.cuda.synchronize(); parallel.barrier()
     dt = parallel.max_over_ranks(time.time() - t0, dev)
 
+    # the same timed loop with the context-Conv1D forward as a bf16x6 split product (off by default):
+    # reported beside the headline number, never as `value`
+    variant = None
+    if not args.split_bf16 and not args.no_variants:
+        from percivaltts_amd import ops
+        opt.cfg.train_wgan_split_bf16 = True
+        run(max(6, args.warmup), 0)
+        parallel.barrier(); torch.cuda.synchronize()
+        tv = time.time()
+        run(args.steps, 0)
+        torch.cuda.synchronize(); parallel.barrier()
+        dtv = parallel.max_over_ranks(time.time() - tv, dev)
+        opt.cfg.train_wgan_split_bf16 = False
+        ops.conv1d_split(False)
+        variant = {'what': 'context Conv1D forward as a three-way bf16 split product (six bf16 MFMA products, fp32 accumulation; '
+                           'fp32-level accuracy, tests/test_ops_gpu.py::test_conv1d_bf16x6_split_product); python bench.py --split-bf16',
+                   'value': args.steps * B * T * world / dtv, 'unit': 'frames/s', 'ms_per_step': dtv / args.steps * 1e3}
+
     # separate timings of the two step kinds (eager or graph as configured) and the roofline leg.  Every rank runs them
     # (the steps contain the gradient all-reduce: a collective only rank 0 entered would hang the job); rank 0 reports.
     extra = {}
@@ -271,6 +302,8 @@ def main():
     use_graph = bool(cfg.train_wgan_hipgraph)
     extra['critic_step_ms'] = timeit((lambda: opt._graphed('critic', X, Y)) if use_graph else (lambda: opt.critic_step(X, Y)), 10)
     extra['generator_step_ms'] = timeit((lambda: opt._graphed('generator', X, Y)) if use_graph else (lambda: opt.generator_step(X, Y)), 5)
+    if variant is not None:
+        extra['variant_ctx_conv1d_bf16x6'] = variant
     if not args.no_roofline:
         extra.update(roofline_leg(opt, X, Y, args))
     if not args.no_host_leg:
@@ -309,6 +342,7 @@ def main():
                        'prune_dead_generator_branches_in_critic_step': bool(cfg.train_wgan_prune_dead_branches),
                        'stack_real_fake_critic_pass': bool(cfg.train_wgan_stack_real_fake),
                        'reuse_generator_ctx_conv_within_train_on_batch': bool(cfg.train_wgan_reuse_ctx_conv),
+                       'ctx_conv1d_forward': 'bf16x6 split product (bf16 MFMA, fp32 accumulate)' if cfg.train_wgan_split_bf16 else 'fp32 MFMA',
                        'generator_params': mod.count_params(), 'critic_params': crit.model.count_params()},
         }
         res.update(extra)

@@ -144,6 +144,20 @@ typedef struct ptts_wgrad_desc {
 } ptts_wgrad_desc;
 int ptts_gemm_wgrad_grouped(const ptts_wgrad_desc* descs, int n, void* stream);
 
+/* The context Conv1D forward (reference networktts.py:116-120: kl.Conv1D(width, winlen, padding='same')) as an fp32
+ * product on the bf16 matrix cores by a three-way operand split ("bf16x6"; split.hip): x = x1 + x2 + x3 in bf16 (round
+ * to nearest), six bf16 products per operand pair, fp32 accumulation -- fp32-level accuracy at 2.7x less matrix-pipe time.
+ *   ptts_split3_frames   x [B][T][C] fp32 -> three bf16 planes [Cp/32][B*(pad_left+T+pad_right)][32]: 32-channel blocks
+ *                        of the time-padded frames, zero padded in time and in the channels C..Cp-1 (Cp % 32 == 0);
+ *   ptts_split3_weight_t w [KW][C][N] fp32 -> three bf16 planes [Cp/32][N][KW][32] (transposed, zero channels C..Cp-1);
+ *   ptts_conv1d_bf16x6   y[b][t][n] = bias[n] + sum_{j,c} x[b][t + j - pad_left][c] w[j][c][n] from those planes, with
+ *                        pad_left + pad_right = KW - 1.  N % 128 == 0, Cp % 32 == 0, T >= 128 (or B == 1), KW <= 24. */
+int ptts_split3_frames(const float* x, void* p1, void* p2, void* p3, int B, int T, int C, int pad_left, int pad_right,
+                       int Cp, void* stream);
+int ptts_split3_weight_t(const float* w, void* p1, void* p2, void* p3, int KW, int C, int N, int Cp, void* stream);
+int ptts_conv1d_bf16x6(const void* a1, const void* a2, const void* a3, const void* bt1, const void* bt2, const void* bt3,
+                       const float* bias, float* y, int B, int T, int KW, int Cp, int N, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * channel-last reductions and elementwise passes
  * ------------------------------------------------------------------------------------- */

@@ -16,6 +16,7 @@ one weight-gradient sweep.
 """
 import contextlib
 import ctypes
+import os
 
 import torch
 
@@ -553,6 +554,65 @@ def conv1d_cache(on):
     _C1Cache.key = _C1Cache.ap = _C1Cache.y = None
 
 
+class _C1Split(object):
+    """Context-Conv1D forward as an fp32 product on the bf16 matrix cores (csrc/split.hip: three-way bf16 split of both
+    operands, six bf16 MFMA products, fp32 accumulation -- fp32-level accuracy, see tools/bf16x6_accuracy.py and
+    tests/test_ops_gpu.py).  Off unless PTTS_CONV1D_SPLIT=1 or conv1d_split(True) (cfg.train_wgan_split_bf16).
+    The planes of the frames are kept for the tensor they were made from (generator and critic convolve the same
+    context input, in the critic step and again in the generator step); the planes of a kernel until it is updated."""
+    enabled = os.environ.get('PTTS_CONV1D_SPLIT', '0') == '1'
+    x_src = None        # the tensor (kept alive: its address cannot be reused) ...
+    x_key = None        # ... its version / shape / padding
+    x_planes = None
+    w_planes = {}       # id(w) -> (w, version, flat epoch, planes)
+
+    @staticmethod
+    def eligible(a, w):
+        B, T, Cin = a.shape
+        KW, _, N = w.shape
+        return a.is_cuda and N % 128 == 0 and (T >= 128 or B == 1) and 2 * (KW - 1) + 127 < 176
+
+    @classmethod
+    def frames(cls, a, pl, pr):
+        B, T, Cin = a.shape
+        Cp = (Cin + 31) // 32 * 32
+        key = (a._version, tuple(a.shape), pl, pr, torch.cuda.current_stream().cuda_stream)
+        if cls.x_src is a and cls.x_key == key:
+            return cls.x_planes, Cp
+        planes = torch.empty((3, Cp // 32, B, T + pl + pr, 32), dtype=torch.bfloat16, device=a.device)
+        call('ptts_split3_frames', ptr(a), ptr(planes[0]), ptr(planes[1]), ptr(planes[2]), B, T, Cin, pl, pr, Cp, stream(),
+             tag=(B, T, Cin))
+        cls.x_src, cls.x_key, cls.x_planes = a, key, planes
+        return planes, Cp
+
+    @classmethod
+    def kernel(cls, w):
+        KW, Cin, N = w.shape
+        Cp = (Cin + 31) // 32 * 32
+        flat = getattr(w, '_ptts_flat', None)
+        epoch = None if flat is None else flat.epoch
+        ent = cls.w_planes.get(id(w))
+        sid = torch.cuda.current_stream().cuda_stream
+        if ent is not None and ent[0] is w and ent[1] == w._version and ent[2] == epoch and ent[4] == sid and flat is not None:
+            return ent[3]
+        planes = ent[3] if ent is not None and ent[0] is w and ent[4] == sid else torch.empty((3, Cp // 32, N, KW, 32), dtype=torch.bfloat16, device=w.device)
+        call('ptts_split3_weight_t', ptr(w), ptr(planes[0]), ptr(planes[1]), ptr(planes[2]), KW, Cin, N, Cp, stream(),
+             tag=(KW, Cin, N))
+        cls.w_planes[id(w)] = (w, w._version, epoch, planes, sid)
+        return planes
+
+    @classmethod
+    def clear(cls):
+        cls.x_src = cls.x_key = cls.x_planes = None
+        cls.w_planes = {}
+
+
+def conv1d_split(on):
+    """Switch the bf16x6 split product of the context Conv1D forward on or off (see _C1Split)."""
+    _C1Split.enabled = bool(on)
+    _C1Split.clear()
+
+
 class Conv1dFn(torch.autograd.Function):
     """y[b,t,:] = b + sum_k a[b,t+k-pl,:].w[k];  `a` (already activated) is given, 'same' zero padding.
     pre = (padded input, product) computed earlier for exactly these operands (see _C1Cache)."""
@@ -566,9 +626,18 @@ class Conv1dFn(torch.autograd.Function):
         if pre is not None:
             ap, y = pre
         else:
-            ap = _pad_time(a, pl, KW - 1 - pl)
             y = torch.empty((B, T, N), dtype=torch.float32, device=a.device)
-            gemm_raw(ap, w, y, B * T, N, KW * Cin, lda=Cin, rows_per_seg=T, seg_stride=(T + KW - 1) * Cin, bias=b)
+            if _C1Split.enabled and _C1Split.eligible(a, w):
+                xp, Cp = _C1Split.frames(a, pl, KW - 1 - pl)
+                wp = _C1Split.kernel(w)
+                call('ptts_conv1d_bf16x6', ptr(xp[0]), ptr(xp[1]), ptr(xp[2]), ptr(wp[0]), ptr(wp[1]), ptr(wp[2]), ptr(b), ptr(y),
+                     B, T, KW, Cp, N, stream(), tag=(B, T, KW, Cp, N))
+                # the fp32 padded frames are the weight gradient's operand: only made when a backward can follow
+                need_ap = _C1Cache.capture or ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+                ap = _pad_time(a, pl, KW - 1 - pl) if need_ap else a.new_empty(0)
+            else:
+                ap = _pad_time(a, pl, KW - 1 - pl)
+                gemm_raw(ap, w, y, B * T, N, KW * Cin, lda=Cin, rows_per_seg=T, seg_stride=(T + KW - 1) * Cin, bias=b)
             if _C1Cache.capture:
                 _C1Cache.ap = ap
         ctx.save_for_backward(ap, w)

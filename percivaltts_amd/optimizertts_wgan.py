@@ -109,6 +109,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         cfg.train_wgan_stack_real_fake = True        # critic(real) and critic(fake) as one stacked 2B pass (exact: no BatchNorm)
         cfg.train_wgan_reuse_ctx_conv = True         # generator step reuses the critic step's G-context-Conv1D product (same batch)
         cfg.train_wgan_early_critic = True           # generator step: critic starts on the spectral branch, BLSTM joins for the LS term
+        cfg.train_wgan_split_bf16 = None             # context Conv1D forward as a bf16x6 split product (fp32-level accuracy, ops._C1Split); None: PTTS_CONV1D_SPLIT
         return cfg
 
     # ---------------------------------------------------------------------------------------------------------
@@ -321,6 +322,9 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         # the generator step that follows on the same batch reuses the generator's context-Conv1D product of the critic
         # step's fake sample (same input, same not-yet-updated kernel): ops._C1Cache, valid inside this call only
         ops.conv1d_cache(gen_too and not use_graph and bool(getattr(self.cfg, 'train_wgan_reuse_ctx_conv', True)))
+        split = getattr(self.cfg, 'train_wgan_split_bf16', None)
+        if split is not None and bool(split) != ops._C1Split.enabled:
+            ops.conv1d_split(split)
         try:
             lc = self._graphed('critic', X, Y) if use_graph else self.critic_step(X, Y)
             lg = None

@@ -251,3 +251,45 @@ def test_generator_step_reuses_the_context_conv_of_the_critic_step(setup):
     # themselves are a poor yardstick here: Adam's first step moves every weight by lr*sign(g)
     assert rel_l2(results[0][1], results[1][1]) < 1e-4          # the critic's gradient does not depend on the cache
     assert rel_l2(results[0][0], results[1][0]) < 5e-4          # the generator's gradient
+
+
+def test_train_step_with_the_bf16x6_context_conv_matches_the_fp32_one(setup):
+    """device_step at BASELINE configs[1] sizes with the context-Conv1D forward as a bf16x6 split product
+    (cfg.train_wgan_split_bf16, csrc/split.hip) against the same step on the fp32 MFMA kernel: same losses, and gradients
+    within the run-to-run spread of the fp32 path itself (fp32 atomics: ~1e-4 relative L2)."""
+    from percivaltts_amd import ops, _hip
+    cfg, opt, crit, X, Y = setup
+    state = (opt.critic_opti.flat.flat, opt.critic_opti.m, opt.critic_opti.v, opt.critic_opti.step_count,
+             opt.gen_opti.flat.flat, opt.gen_opti.m, opt.gen_opti.v, opt.gen_opti.step_count)
+    snap = [t.detach().clone() for t in state]
+    moving = [t for k, t in opt._model.kerasmodel.weights() if 'moving' in k]
+    moving0 = [t.detach().clone() for t in moving]
+    results = []
+    try:
+        for split in (True, False):
+            for dst, src in zip(state, snap):
+                dst.copy_(src)
+            for dst, src in zip(moving, moving0):
+                dst.copy_(src)
+            opt.critic_opti.flat.epoch += 1; opt.gen_opti.flat.epoch += 1
+            opt.cfg.train_wgan_split_bf16 = split
+            torch.manual_seed(11)                      # same interpolation weights
+            with _hip.KernelTimer() as kt:
+                lc, lg = opt.device_step(0, X, Y)      # batchid 0: critic step + generator step
+            torch.cuda.synchronize()
+            names = [r[0] for r in kt.records]
+            results.append((float(lc), float(lg), opt.critic_opti.flat.grad.detach().clone(),
+                            opt.gen_opti.flat.grad.detach().clone(), names.count('ptts_conv1d_bf16x6')))
+    finally:
+        opt.cfg.train_wgan_split_bf16 = False
+        ops.conv1d_split(False)
+        for dst, src in zip(state, snap):
+            dst.copy_(src)
+        for dst, src in zip(moving, moving0):
+            dst.copy_(src)
+        opt.critic_opti.flat.epoch += 1; opt.gen_opti.flat.epoch += 1
+    (lc1, lg1, gc1, gg1, n1), (lc0, lg0, gc0, gg0, n0) = results
+    assert n1 == 3 and n0 == 0, (n1, n0)       # G and D context convs in the critic step, D's again in the generator step
+    assert abs(lc1 - lc0) <= 1e-4 * max(1.0, abs(lc0)) and abs(lg1 - lg0) <= 1e-4 * max(1.0, abs(lg0)), (lc1, lc0, lg1, lg0)
+    assert rel_l2(gc1, gc0) < 3e-4, rel_l2(gc1, gc0)
+    assert rel_l2(gg1, gg0) < 1e-3, rel_l2(gg1, gg0)

@@ -323,6 +323,58 @@ def test_conv1d(ops, case):
     close(bd.grad, br.grad, rtol=2e-4, atol=3e-4, what='db')
 
 
+def test_split3_planes_are_exact(ops):
+    """The three bf16 planes of the split pass add up to the fp32 operand EXACTLY (3 x 8 significant bits = 24), sit in
+    the documented 32-channel-block layout, and are zero in the time padding and in the channels C..Cp-1."""
+    from percivaltts_amd.ops import call, ptr, stream
+    g = gen(31)
+    B, T, C, KW, N = 3, 37, 45, 5, 128
+    x = (torch.randn(B, T, C, generator=g) * torch.exp(4 * torch.randn(B, T, C, generator=g))).cuda()     # wide dynamic range
+    w = (torch.randn(KW, C, N, generator=g) * 0.1).cuda()
+    pl, pr, Cp = 2, 2, 64
+    xp = torch.full((3, Cp // 32, B, T + pl + pr, 32), 7.0, dtype=torch.bfloat16, device='cuda')
+    wp = torch.full((3, Cp // 32, N, KW, 32), 7.0, dtype=torch.bfloat16, device='cuda')
+    call('ptts_split3_frames', ptr(x), ptr(xp[0]), ptr(xp[1]), ptr(xp[2]), B, T, C, pl, pr, Cp, stream())
+    call('ptts_split3_weight_t', ptr(w), ptr(wp[0]), ptr(wp[1]), ptr(wp[2]), KW, C, N, Cp, stream())
+    xs = (xp[0].float() + xp[1].float() + xp[2].float()).permute(1, 2, 0, 3).reshape(B, T + pl + pr, Cp)
+    assert torch.equal(xs[:, pl:pl + T, :C], x)
+    assert (xs[:, :pl] == 0).all() and (xs[:, pl + T:] == 0).all() and (xs[..., C:] == 0).all()
+    ws = (wp[0].float() + wp[1].float() + wp[2].float()).permute(1, 2, 0, 3).reshape(N, KW, Cp)
+    assert torch.equal(ws[..., :C].permute(1, 2, 0), w)
+    assert (ws[..., C:] == 0).all()
+    # each plane is what rounding the running remainder to bf16 gives
+    assert torch.equal(xp[0].permute(1, 2, 0, 3).reshape(B, T + pl + pr, Cp)[:, pl:pl + T, :C], x.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize('case', [(2, 130, 37, 128, 5), (3, 129, 70, 256, 21), (1, 50, 33, 128, 3), (2, 300, 601, 256, 21)])
+def test_conv1d_bf16x6_split_product(ops, case):
+    """Context Conv1D forward as a bf16x6 split product (csrc/split.hip) against the fp64 oracle: the error must be of the
+    size of the fp32 MFMA kernel's own, and far below what a plain bf16 product would give (2^-9 relative).  The cases
+    put an utterance boundary inside a 128-frame tile, an M edge tile, a single short utterance, and the real K."""
+    B, T, Cin, N, KW = case
+    g = gen(32)
+    x = torch.randn(B, T, Cin, generator=g, dtype=torch.float64)
+    w = torch.randn(KW, Cin, N, generator=g, dtype=torch.float64) * (1.0 / (KW * Cin) ** 0.5)
+    b = torch.randn(N, generator=g, dtype=torch.float64)
+    x32, w32, b32 = x.float(), w.float(), b.float()          # the fp32 operands both kernels see
+    yr = O.conv1d_ntc(x32.double(), w32.double(), b32.double())
+    xd, wd, bd = x32.cuda(), w32.cuda(), b32.cuda()
+    ops.conv1d_split(False)
+    y_f32 = ops.conv1d(xd, wd, bd).cpu().double()
+    ops.conv1d_split(True)
+    try:
+        with ops._hip.KernelTimer() as kt:
+            y_split = ops.conv1d(xd, wd, bd).cpu().double()
+        assert any(r[0] == 'ptts_conv1d_bf16x6' for r in kt.records), 'the split kernel did not run'
+    finally:
+        ops.conv1d_split(False)
+    scale = yr.abs().mean()
+    e_f32 = ((y_f32 - yr).abs().max() / scale).item()
+    e_split = ((y_split - yr).abs().max() / scale).item()
+    assert e_split < 3e-5, (e_split, e_f32)                 # tolerance: fp32 rounding of a K <= 12 621 accumulation
+    assert e_split < 4 * max(e_f32, 2e-6), (e_split, e_f32)
+
+
 @pytest.mark.parametrize('shape', [(4, 6, 3), (2, 50, 256), (2, 10, 9, 4), (3, 7, 300)])
 def test_batchnorm_train_and_infer(ops, shape):
     g = gen(8)

@@ -1,0 +1,64 @@
+"""Context-Conv1D forward as a bf16x6 split product (split.hip) against the fp32 MFMA kernel: error vs fp64 and time."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from percivaltts_amd import ops
+from percivaltts_amd.ops import call, ptr, stream
+
+B, T, Cin, N, KW = int(os.environ.get("BATCH", 64)), int(os.environ.get("FRAMES", 400)), 601, 256, 21
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+dev = 'cuda'
+torch.manual_seed(0)
+x = torch.randn(B, T, Cin, device=dev)
+w = torch.randn(KW, Cin, N, device=dev) * 0.02
+bias = torch.randn(N, device=dev)
+pl = (KW - 1) // 2
+Cp = (Cin + 31) // 32 * 32
+Tp = T + KW - 1
+
+ap = ops._pad_time(x, pl, KW - 1 - pl)
+y32 = torch.empty(B, T, N, device=dev)
+def f32():
+    ops.gemm_raw(ap, w, y32, B * T, N, KW * Cin, lda=Cin, rows_per_seg=T, seg_stride=Tp * Cin, bias=bias)
+
+xa = torch.empty(3, Cp // 32, B, Tp, 32, dtype=torch.bfloat16, device=dev)
+wb = torch.empty(3, Cp // 32, N, KW, 32, dtype=torch.bfloat16, device=dev)
+y6 = torch.empty(B, T, N, device=dev)
+def split_x():
+    call('ptts_split3_frames', ptr(x), ptr(xa[0]), ptr(xa[1]), ptr(xa[2]), B, T, Cin, pl, KW - 1 - pl, Cp, stream())
+def split_w():
+    call('ptts_split3_weight_t', ptr(w), ptr(wb[0]), ptr(wb[1]), ptr(wb[2]), KW, Cin, N, Cp, stream())
+def x6():
+    call('ptts_conv1d_bf16x6', ptr(xa[0]), ptr(xa[1]), ptr(xa[2]), ptr(wb[0]), ptr(wb[1]), ptr(wb[2]), ptr(bias), ptr(y6),
+         B, T, KW, Cp, N, stream())
+
+split_x(); split_w(); torch.cuda.synchronize()
+# the planes add up to the operand (to 2^-24 relative) and are laid out as documented
+xs = xa.float().sum(0).permute(1, 2, 0, 3).reshape(B, Tp, Cp)
+print('planes(x): max |sum - x| / |x|max = %.3e' % ((xs[:, pl:pl + T, :Cin] - x).abs().max() / x.abs().max()).item(),
+      ' pad rows/channels zero:', bool((xs[:, :pl] == 0).all() and (xs[:, pl + T:] == 0).all() and (xs[..., Cin:] == 0).all()))
+ws = wb.float().sum(0).permute(1, 2, 0, 3).reshape(N, KW, Cp)
+print('planes(w): max |sum - w| / |w|max = %.3e' % ((ws[..., :Cin].permute(1, 2, 0) - w).abs().max() / w.abs().max()).item())
+f32(); x6(); torch.cuda.synchronize()
+# fp64 reference on a sample of frames
+gen = torch.Generator().manual_seed(1)
+bs = torch.randint(0, B, (64,), generator=gen); ts = torch.randint(0, T, (64,), generator=gen)
+bs[:4] = torch.tensor([0, 0, B - 1, B - 1]); ts[:4] = torch.tensor([0, T - 1, 0, T - 1])
+apd = ap.double(); wd = w.double().reshape(KW * Cin, N)
+ref = torch.stack([apd[b, t:t + KW].reshape(-1) @ wd for b, t in zip(bs.tolist(), ts.tolist())]) + bias.double()
+sc = ref.abs().mean()
+e32 = (y32[bs, ts].double() - ref).abs().max() / sc
+e6 = (y6[bs, ts].double() - ref).abs().max() / sc
+print('max err / mean|ref|: fp32 MFMA %.3e   bf16x6 %.3e   (y6 vs y32 everywhere: %.3e)' % (e32.item(), e6.item(), ((y6 - y32).abs().max() / sc).item()))
+
+def timeit(fn):
+    fn(); torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+flop = 2.0 * B * T * N * KW * Cin
+for name, fn in (('fp32 mfma', f32), ('bf16x6', x6), ('split x', split_x), ('split w', split_w)):
+    ms = timeit(fn)
+    print('%-10s %.3f ms' % (name, ms) + ('  %.1f TF (algorithmic)' % (flop / ms / 1e9) if fn in (f32, x6) else ''))
