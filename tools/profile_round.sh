@@ -10,6 +10,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python ben
 echo "trace done" > $OUT/progress.txt
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python tools/gemm_probe.py both 3 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python tools/gemm_probe.py both 3 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_split -- python tools/split_probe.py 3 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_split -- python tools/split_probe.py 3 > /dev/null 2>&1
 echo "gemm pmc done" >> $OUT/progress.txt
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_conv -- python tools/conv2d_probe.py 3 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_conv -- python tools/conv2d_probe.py 3 > /dev/null 2>&1
