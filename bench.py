@@ -211,7 +211,9 @@ def roofline_leg(opt, X, Y, args):
         if cands and B == 64 and T == 400 and X.shape[2] == 601:
             tr = json.load(open(os.path.join(ROOT, 'profiles', cands[-1])))
             key = next((k for k in ('gemm_dma_kernel<0, 1>', 'gemm_dma_kernel<0>', 'gemm_f32_mfma_kernel<0, 0, 1, 0>') if k in tr), None)
-            if 'roofline' in out and key and not conv1d_split:
+            if conv1d_split:
+                key = 'gemm_bf16x6_kernel' if 'gemm_bf16x6_kernel' in tr else None
+            if 'roofline' in out and key:
                 out['roofline']['traffic'] = tr[key]['hbm_bytes_per_launch']
                 out['roofline']['traffic_source'] = 'profiles/' + cands[-1]
             if 'roofline_conv2d' in out and 'conv2d_fwd_kernel<4, 4, 5, 5, 1, false>' in tr:
