@@ -158,6 +158,19 @@ int ptts_split3_weight_t(const float* w, void* p1, void* p2, void* p3, int KW, i
 int ptts_conv1d_bf16x6(const void* a1, const void* a2, const void* a3, const void* bt1, const void* bt2, const void* bt3,
                        const float* bias, float* y, int B, int T, int KW, int Cp, int N, void* stream);
 
+/* The context Conv1D weight gradient (TF's Conv1D kernel backprop of networktts.py:116-120) as a bf16x6 split product:
+ *   dw[j][c][n] = sum_{b,t} xp[b][t + j][c] dy[b][t][n]   (xp: the frames zero-padded in time to T + KW - 1).
+ *   ptts_split3_frames_t  x [B][T][C] fp32 -> three FRAME-MAJOR bf16 planes [Crows][Pp], element (c, b Tp + pad_left + t),
+ *                         zero elsewhere (Crows % 32 == 0, >= C; Pp % 64 == 0, >= B Tp).  Used for the padded frames
+ *                         (B, T + KW - 1, pad_left 0, Tp = T + KW - 1) and for dy (B, T, pad_left 0, Tp = T + KW - 1);
+ *   ptts_conv1d_wgrad_bf16x6  dw (overwritten) from those planes; KW in {3, 5, 21}, N % 32 == 0, Crows % 64 == 0,
+ *                         Pp >= 32 ceil(B (T + KW - 1) / 32) + 64. */
+int ptts_split3_frames_t(const float* x, void* p1, void* p2, void* p3, int B, int T, int C, int pad_left, int Tp, int Crows,
+                         long long Pp, void* stream);
+int ptts_conv1d_wgrad_bf16x6(const void* xt1, const void* xt2, const void* xt3, const void* yt1, const void* yt2,
+                             const void* yt3, float* dw, int B, int T, int KW, int C, int N, int Crows, long long Pp,
+                             void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * channel-last reductions and elementwise passes
  * ------------------------------------------------------------------------------------- */

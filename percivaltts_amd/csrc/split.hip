@@ -387,3 +387,232 @@ extern "C" int ptts_conv1d_bf16x6(const void* a1, const void* a2, const void* a3
     hipLaunchKernelGGL(gemm_bf16x6_kernel, dim3(g.workers), dim3(S_THREADS), S_LDS_BYTES, st, g);
     return check_launch("conv1d_bf16x6");
 }
+
+namespace ptts {
+
+// ================================================================================================
+// Weight gradient of the context Conv1D as a bf16x6 split product.
+//   dW[j][c][n] = sum_{b,t} Xp[b][t + j][c] dY[b][t][n]  =  sum_q Xt[c][q + j] dYt[n][q],   q = b (T + KW - 1) + t
+// with FRAME-MAJOR planes (the reduction index q is the contiguous one, as the MFMA operands want it):
+//   Xt [Crows][Pp]: the zero-padded frames, transposed;  dYt [N][Pp]: the incoming gradient at the frame positions of
+//   the padded buffer, zero in its pad rows.  Both are written by split3_frames_t_kernel.
+// A workgroup (8 waves) owns 64 channels x 32 outputs x ALL KW taps over a slice of q; wave (cf, nf) owns 16 channels x
+// 16 outputs: KW accumulator blocks.  Per q-step of 32 a lane reads its 64 bytes of Xt (32 consecutive frames from
+// 8 (lane>>4)) ONCE and forms the operand of every tap from them in registers: tap j starts j elements further, i.e. at
+// dword j/2 (even j: a register choice) or across two dwords (odd j: one v_alignbyte_b32 per dword).  The B operand (dYt)
+// is the same for all taps.  LDS reads per MFMA: 15 ds_read_b128 per 6 KW MFMAs -- the loop is MFMA-paced.
+// ================================================================================================
+constexpr int W_THREADS = 512;                          // 8 waves
+constexpr int W_CB = 64, W_NB = 32, W_QS = 32;           // channels, outputs per workgroup; frames per step
+constexpr int W_AROW = 64;                               // frames of an Xt row in LDS: 32 + taps (<= 24) + alignment
+constexpr int W_ATILE = W_CB * W_AROW;                   // elements of one plane of the Xt tile: 8 KB
+constexpr int W_BTILE = W_NB * W_QS;                     // dYt tile: 2 KB
+constexpr int W_STAGE = 3 * W_ATILE + 3 * W_BTILE;       // 30 KB
+constexpr int W_STAGES = 3;
+constexpr int W_LDS_BYTES = W_STAGES * W_STAGE * 2;      // 90 KB
+
+struct WgradSplitArgs {
+    const u16* Xt[3]; const u16* Yt[3]; float* dW;
+    int C, N, Crows;
+    long long Pp;                 // row length of the planes (elements)
+    int qsteps, nsplit, steps_per_split;
+    int tiles_n;
+};
+
+// fp32 [B][T][C] -> three bf16 planes [Crows][Pp], element (c, b Tp + pad_left + t); everything else zero.
+__global__ __launch_bounds__(256) void split3_frames_t_kernel(const float* __restrict__ x, u16* __restrict__ p1,
+                                                              u16* __restrict__ p2, u16* __restrict__ p3, int B, int T,
+                                                              int C, int pad_left, int Tp, int Crows, long long Pp) {
+    __shared__ u16 s[3][32][64 + 2];
+    const int tid = threadIdx.x;
+    const long long q0 = (long long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 32;
+    {
+        const int tx = tid & 31, ty = tid >> 5;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ql = ty + 8 * i;
+            const long long q = q0 + ql;
+            const int b = (int)(q / Tp), t = (int)(q - (long long)b * Tp) - pad_left;
+            float v = 0.f;
+            if (b < B && t >= 0 && t < T && c0 + tx < C) v = x[((long long)b * T + t) * C + c0 + tx];
+            u16 h1, h2, h3;
+            split3(v, h1, h2, h3);
+            s[0][tx][ql] = h1; s[1][tx][ql] = h2; s[2][tx][ql] = h3;
+        }
+    }
+    __syncthreads();
+    {
+        const int c = tid >> 3, g8 = tid & 7;
+        if (c0 + c < Crows && q0 + 8 * g8 + 7 < Pp) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                U16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o.v[e] = s[p][c][8 * g8 + e];
+                u16* dst = (p == 0 ? p1 : (p == 1 ? p2 : p3)) + (long long)(c0 + c) * Pp + q0 + 8 * g8;
+                *reinterpret_cast<U16x8*>(dst) = o;
+            }
+        }
+    }
+}
+
+template <int KW>
+__global__ __launch_bounds__(W_THREADS) void wgrad_bf16x6_kernel(WgradSplitArgs g) {
+    extern __shared__ __attribute__((aligned(16))) u16 s_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cf = wave >> 1, nf = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+    const int tile = blockIdx.x / g.nsplit, split = blockIdx.x - tile * g.nsplit;
+    const int c0 = (tile / g.tiles_n) * W_CB, n0 = (tile % g.tiles_n) * W_NB;
+    const int s_begin = split * g.steps_per_split;
+    const int s_end = min(g.qsteps, s_begin + g.steps_per_split);
+    const int nsteps = s_end - s_begin;
+    if (nsteps <= 0) return;
+
+    f32x4 acc[KW];
+#pragma unroll
+    for (int j = 0; j < KW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // DMA sources.  Xt tile: plane p, rows 8 wave .. 8 wave + 7 (a wave-instruction = 8 rows x 128 B): lane -> row
+    // lane>>3, physical 16-byte unit lane&7 holding logical unit (lane&7) ^ (row&7).  dYt tile (waves 0..5): plane wave>>1,
+    // rows 16 (wave&1) .. +15 (16 rows x 64 B): lane -> row lane>>2, slot lane&3 holding quad (lane&3) ^ ((row>>1)&2).
+    long long asrc;
+    {
+        const int r = 8 * wave + (lane >> 3);
+        const int u = (lane & 7) ^ (r & 7);
+        asrc = (long long)(c0 + r) * g.Pp + 8 * u;
+    }
+    long long bsrc = 0;
+    const int bplane = wave >> 1;
+    if (wave < 6) {
+        const int r = 16 * (wave & 1) + (lane >> 2);
+        const int qd = (lane & 3) ^ ((r >> 1) & 2);
+        bsrc = (long long)(n0 + r) * g.Pp + 8 * qd;
+    }
+    auto issue = [&](int s, int stage) {
+        u16* st = s_lds + stage * W_STAGE;
+        const long long q0 = (long long)s * W_QS;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) dma16h(g.Xt[p] + asrc + q0, st + p * W_ATILE + 8 * wave * W_AROW);
+        if (wave < 6) {
+            const u16* yp = bplane == 0 ? g.Yt[0] : (bplane == 1 ? g.Yt[1] : g.Yt[2]);
+            dma16h(yp + bsrc + q0, st + 3 * W_ATILE + bplane * W_BTILE + 16 * (wave & 1) * W_QS);
+        }
+    };
+    // fragment addresses: Xt row 16 cf + li, logical units lg .. lg + 3;  dYt row 16 nf + li, quad lg
+    const int arow = 16 * cf + li;
+    const int abase = arow * W_AROW;
+    const int asw = arow & 7;
+    const int brow = 16 * nf + li;
+    const int boff = brow * W_QS + 8 * (lg ^ ((brow >> 1) & 2));
+
+    issue(s_begin, 0);
+    if (nsteps > 1) issue(s_begin + 1, 1);
+    for (int s = 0; s < nsteps; ++s) {
+        // DMAs of this wave issued after those of step s: the ones of step s+1 (4 for waves 0..5, 3 for waves 6, 7)
+        if (s + 1 < nsteps) { if (wave < 6) __builtin_amdgcn_s_waitcnt(0xF74); else __builtin_amdgcn_s_waitcnt(0xF73); }
+        else __builtin_amdgcn_s_waitcnt(0xF70);
+        __syncthreads();
+        if (s + 2 < nsteps) issue(s_begin + s + 2, (s + 2) % W_STAGES);
+        const u16* st = s_lds + (s % W_STAGES) * W_STAGE;
+        // 32 consecutive frames of this lane's channel row, per plane: 16 dwords
+        unsigned d[3][16];
+        bf16x8 bq[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint4 v = *reinterpret_cast<const uint4*>(st + p * W_ATILE + abase + 8 * ((lg + u) ^ asw));
+                d[p][4 * u] = v.x; d[p][4 * u + 1] = v.y; d[p][4 * u + 2] = v.z; d[p][4 * u + 3] = v.w;
+            }
+            bq[p] = *reinterpret_cast<const bf16x8*>(st + 3 * W_ATILE + p * W_BTILE + boff);
+        }
+#pragma unroll
+        for (int j = 0; j < KW; ++j) {
+            bf16x8 a[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                unsigned w4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    w4[k] = (j & 1) ? __builtin_amdgcn_alignbyte(d[p][j / 2 + k + 1], d[p][j / 2 + k], 2) : d[p][j / 2 + k];
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 t = {w4[0], w4[1], w4[2], w4[3]};
+                a[p] = __builtin_bit_cast(bf16x8, t);
+            }
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], bq[0], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bq[1], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bq[2], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bq[0], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bq[1], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bq[0], acc[j], 0, 0, 0);
+        }
+    }
+    // C/D layout: col = lane&15 -> n, row = 4 (lane>>4) + reg -> c
+    const int n = n0 + 16 * nf + li;
+#pragma unroll
+    for (int j = 0; j < KW; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = c0 + 16 * cf + 4 * lg + r;
+            if (c < g.C && n < g.N) atomicAdd(g.dW + ((long long)j * g.C + c) * g.N + n, acc[j][r]);
+        }
+}
+
+}  // namespace ptts
+
+extern "C" int ptts_split3_frames_t(const float* x, void* p1, void* p2, void* p3, int B, int T, int C, int pad_left,
+                                    int Tp, int Crows, long long Pp, void* stream) {
+    PTTS_REQUIRE(x && p1 && p2 && p3, "split3_frames_t: null pointer");
+    PTTS_REQUIRE(B > 0 && T > 0 && C > 0 && pad_left >= 0 && Tp >= T + pad_left, "split3_frames_t: bad dims");
+    PTTS_REQUIRE(Crows >= C && Crows % 32 == 0 && Pp % 64 == 0 && Pp >= (long long)B * Tp,
+                 "split3_frames_t: Crows=%d must be a multiple of 32 >= C, Pp=%lld a multiple of 64 >= B*Tp", Crows, Pp);
+    dim3 grid((unsigned)(Pp / 64), (unsigned)(Crows / 32));
+    hipLaunchKernelGGL(split3_frames_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (u16*)p1, (u16*)p2, (u16*)p3, B, T, C,
+                       pad_left, Tp, Crows, Pp);
+    return check_launch("split3_frames_t");
+}
+
+extern "C" int ptts_conv1d_wgrad_bf16x6(const void* xt1, const void* xt2, const void* xt3, const void* yt1, const void* yt2,
+                                        const void* yt3, float* dw, int B, int T, int KW, int C, int N, int Crows,
+                                        long long Pp, void* stream) {
+    PTTS_REQUIRE(xt1 && xt2 && xt3 && yt1 && yt2 && yt3 && dw, "conv1d_wgrad_bf16x6: null pointer");
+    PTTS_REQUIRE(B > 0 && T > 0 && C > 0 && N > 0, "conv1d_wgrad_bf16x6: bad dims");
+    PTTS_REQUIRE(KW == 21 || KW == 5 || KW == 3, "conv1d_wgrad_bf16x6: KW=%d is not instantiated (3, 5, 21)", KW);
+    PTTS_REQUIRE(N % W_NB == 0 && Crows % W_CB == 0 && Crows >= C, "conv1d_wgrad_bf16x6: N %% 32 == 0, Crows %% 64 == 0 >= C");
+    const long long frames = (long long)B * (T + KW - 1);
+    const int qsteps = (int)((frames + W_QS - 1) / W_QS);
+    PTTS_REQUIRE(Pp % 64 == 0 && Pp >= (long long)qsteps * W_QS + W_AROW, "conv1d_wgrad_bf16x6: Pp=%lld too short (needs %lld)", Pp,
+                 (long long)qsteps * W_QS + W_AROW);
+    PTTS_REQUIRE((((size_t)xt1 | (size_t)xt2 | (size_t)xt3 | (size_t)yt1 | (size_t)yt2 | (size_t)yt3) & 15) == 0,
+                 "conv1d_wgrad_bf16x6: planes must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    WgradSplitArgs g;
+    g.Xt[0] = (const u16*)xt1; g.Xt[1] = (const u16*)xt2; g.Xt[2] = (const u16*)xt3;
+    g.Yt[0] = (const u16*)yt1; g.Yt[1] = (const u16*)yt2; g.Yt[2] = (const u16*)yt3;
+    g.dW = dw; g.C = C; g.N = N; g.Crows = Crows; g.Pp = Pp; g.qsteps = qsteps;
+    g.tiles_n = N / W_NB;
+    const int tiles = (Crows / W_CB) * g.tiles_n;
+    int nsplit = 256 / tiles;                              // about one workgroup per CU
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > qsteps) nsplit = qsteps;
+    g.nsplit = nsplit; g.steps_per_split = (qsteps + nsplit - 1) / nsplit;
+    hipError_t e = hipMemsetAsync(dw, 0, (size_t)KW * C * N * sizeof(float), st);
+    if (e != hipSuccess) { set_error("conv1d_wgrad_bf16x6: memset failed: %s", hipGetErrorString(e)); return PTTS_ELAUNCH; }
+#define PTTS_WG_LAUNCH(KWV)                                                                                               \
+    {                                                                                                                     \
+        static bool attr = false;                                                                                         \
+        if (!attr) {                                                                                                      \
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16x6_kernel<KWV>),                   \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES);                 \
+            if (e2 != hipSuccess) { set_error("conv1d_wgrad_bf16x6: LDS attribute: %s", hipGetErrorString(e2)); return PTTS_ELAUNCH; } \
+            attr = true;                                                                                                  \
+        }                                                                                                                 \
+        hipLaunchKernelGGL((wgrad_bf16x6_kernel<KWV>), dim3(tiles * nsplit), dim3(W_THREADS), W_LDS_BYTES, st, g);        \
+    }
+    if (KW == 21) PTTS_WG_LAUNCH(21) else if (KW == 5) PTTS_WG_LAUNCH(5) else PTTS_WG_LAUNCH(3)
+#undef PTTS_WG_LAUNCH
+    return check_launch("conv1d_wgrad_bf16x6");
+}

@@ -601,9 +601,48 @@ class _C1Split(object):
         cls.w_planes[id(w)] = (w, w._version, epoch, planes, sid)
         return planes
 
+    WGRAD_KW = (3, 5, 21)        # instantiations of wgrad_bf16x6_kernel<KW>
+    xt_src = None
+    xt_key = None
+    xt_planes = None
+
+    @staticmethod
+    def eligible_wgrad(KW, N):
+        return KW in _C1Split.WGRAD_KW and N % 32 == 0
+
+    @staticmethod
+    def plane_len(B, T, KW):
+        qsteps = (B * (T + KW - 1) + 31) // 32
+        return (qsteps * 32 + 64 + 63) // 64 * 64
+
+    @staticmethod
+    def transposed(x, B, T, C, pl, Tp, Pp):
+        """Three frame-major bf16 planes [3][Crows][Pp] of x [B][T][C]: element (c, b Tp + pl + t), zero elsewhere."""
+        Crows = (C + 63) // 64 * 64
+        planes = torch.empty((3, Crows, Pp), dtype=torch.bfloat16, device=x.device)
+        call('ptts_split3_frames_t', ptr(x), ptr(planes[0]), ptr(planes[1]), ptr(planes[2]), B, T, C, pl, Tp, Crows, Pp, stream(),
+             tag=(B, T, C))
+        return planes, Crows
+
+    @classmethod
+    def frames_t(cls, src, ap, KW):
+        """Frame-major planes of the padded frames ap [B][T+KW-1][C], kept for `src` (the tensor the layer was called
+        with): the weight gradients of generator and critic read the same context input."""
+        B, Tp, C = ap.shape
+        Pp = cls.plane_len(B, Tp - (KW - 1), KW)
+        key = None if src is None else (src._version, tuple(src.shape), KW, torch.cuda.current_stream().cuda_stream)
+        if src is not None and cls.xt_src is src and cls.xt_key == key:
+            return cls.xt_planes
+        planes, Crows = cls.transposed(ap, B, Tp, C, 0, Tp, Pp)
+        out = (planes, Crows, Pp)
+        if src is not None:
+            cls.xt_src, cls.xt_key, cls.xt_planes = src, key, out
+        return out
+
     @classmethod
     def clear(cls):
         cls.x_src = cls.x_key = cls.x_planes = None
+        cls.xt_src = cls.xt_key = cls.xt_planes = None
         cls.w_planes = {}
 
 
@@ -641,6 +680,7 @@ class Conv1dFn(torch.autograd.Function):
             if _C1Cache.capture:
                 _C1Cache.ap = ap
         ctx.save_for_backward(ap, w)
+        ctx.x_src = a if _C1Split.enabled else None
         ctx.has_b = b is not None
         ctx.dims = (B, T, Cin, KW, N, pl)
         return y
@@ -653,7 +693,15 @@ class Conv1dFn(torch.autograd.Function):
         dy = dy.contiguous()
         da = dw = db = None
         need_b = ctx.has_b and ctx.needs_input_grad[2] and not _Flags.skip_param_grads
-        if ctx.needs_input_grad[1] and not _Flags.skip_param_grads:
+        if ctx.needs_input_grad[1] and not _Flags.skip_param_grads and _C1Split.enabled and dy.is_cuda \
+                and _C1Split.eligible_wgrad(KW, N) and ap.numel() > 0:
+            # the weight gradient as a bf16x6 split product over frame-major planes (csrc/split.hip)
+            xt, Crows, Pp = _C1Split.frames_t(ctx.x_src, ap, KW)
+            yt, _ = _C1Split.transposed(dy, B, T, N, 0, T + KW - 1, Pp)
+            dw = torch.empty_like(w)
+            call('ptts_conv1d_wgrad_bf16x6', ptr(xt[0]), ptr(xt[1]), ptr(xt[2]), ptr(yt[0]), ptr(yt[1]), ptr(yt[2]), ptr(dw),
+                 B, T, KW, Cin, N, Crows, Pp, stream(), tag=(B, T, KW, Cin, N))
+        elif ctx.needs_input_grad[1] and not _Flags.skip_param_grads:
             dw = torch.empty_like(w)
             if need_b and N > 4:          # bias gradient taken from the B tiles of the weight-gradient product
                 db = torch.empty(N, dtype=torch.float32, device=dy.device)

@@ -358,21 +358,40 @@ def test_conv1d_bf16x6_split_product(ops, case):
     b = torch.randn(N, generator=g, dtype=torch.float64)
     x32, w32, b32 = x.float(), w.float(), b.float()          # the fp32 operands both kernels see
     yr = O.conv1d_ntc(x32.double(), w32.double(), b32.double())
-    xd, wd, bd = x32.cuda(), w32.cuda(), b32.cuda()
+    dy = torch.randn(B, T, N, generator=g, dtype=torch.float64).float()
+    # weight / bias gradient of the oracle for the same fp32 operands
+    wr = w32.double().requires_grad_(True); br = b32.double().requires_grad_(True)
+    O.conv1d_ntc(x32.double(), wr, br).backward(dy.double())
+    xd = x32.cuda()
+
+    def run():
+        wd, bd = w32.cuda().requires_grad_(True), b32.cuda().requires_grad_(True)
+        with ops._hip.KernelTimer() as kt:
+            y = ops.conv1d(xd, wd, bd)
+            y.backward(dy.cuda())
+        return y.detach().cpu().double(), wd.grad.cpu().double(), bd.grad.cpu().double(), [r[0] for r in kt.records]
+
     ops.conv1d_split(False)
-    y_f32 = ops.conv1d(xd, wd, bd).cpu().double()
+    y_f32, dw_f32, db_f32, _ = run()
     ops.conv1d_split(True)
     try:
-        with ops._hip.KernelTimer() as kt:
-            y_split = ops.conv1d(xd, wd, bd).cpu().double()
-        assert any(r[0] == 'ptts_conv1d_bf16x6' for r in kt.records), 'the split kernel did not run'
+        y_split, dw_split, db_split, names = run()
     finally:
         ops.conv1d_split(False)
+    assert 'ptts_conv1d_bf16x6' in names, 'the split forward kernel did not run'
+    assert ('ptts_conv1d_wgrad_bf16x6' in names) == (KW in (3, 5, 21)), names
     scale = yr.abs().mean()
     e_f32 = ((y_f32 - yr).abs().max() / scale).item()
     e_split = ((y_split - yr).abs().max() / scale).item()
     assert e_split < 3e-5, (e_split, e_f32)                 # tolerance: fp32 rounding of a K <= 12 621 accumulation
     assert e_split < 4 * max(e_f32, 2e-6), (e_split, e_f32)
+    # weight gradient: a reduction over B*T frames
+    gs = wr.grad.abs().mean()
+    g_f32 = ((dw_f32 - wr.grad).abs().max() / gs).item()
+    g_split = ((dw_split - wr.grad).abs().max() / gs).item()
+    assert g_split < 3e-5, (g_split, g_f32)
+    assert g_split < 4 * max(g_f32, 2e-6), (g_split, g_f32)
+    close(db_split, br.grad, rtol=2e-4, atol=3e-4, what='db')
 
 
 @pytest.mark.parametrize('shape', [(4, 6, 3), (2, 50, 256), (2, 10, 9, 4), (3, 7, 300)])

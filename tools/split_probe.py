@@ -51,6 +51,32 @@ e32 = (y32[bs, ts].double() - ref).abs().max() / sc
 e6 = (y6[bs, ts].double() - ref).abs().max() / sc
 print('max err / mean|ref|: fp32 MFMA %.3e   bf16x6 %.3e   (y6 vs y32 everywhere: %.3e)' % (e32.item(), e6.item(), ((y6 - y32).abs().max() / sc).item()))
 
+# weight gradient
+dy = torch.randn(B, T, N, device=dev)
+dw32 = torch.empty_like(w); dw6 = torch.empty_like(w)
+def bww32():
+    ops.gemm_raw(ap, dy, dw32, KW * Cin, N, B * T, transA=1, lda=Cin, rows_per_seg=T, seg_stride=Tp * Cin)
+Pp = ops._C1Split.plane_len(B, T, KW)
+def split_xt():
+    global xt, Crows
+    xt, Crows = ops._C1Split.transposed(ap, B, Tp, Cin, 0, Tp, Pp)
+def split_yt():
+    global yt
+    yt, _ = ops._C1Split.transposed(dy, B, T, N, 0, Tp, Pp)
+def bww6():
+    call('ptts_conv1d_wgrad_bf16x6', ptr(xt[0]), ptr(xt[1]), ptr(xt[2]), ptr(yt[0]), ptr(yt[1]), ptr(yt[2]), ptr(dw6),
+         B, T, KW, Cin, N, Crows, Pp, stream())
+split_xt(); split_yt(); bww32(); bww6(); torch.cuda.synchronize()
+xts = xt.float().sum(0)[:Cin, :B * Tp].reshape(Cin, B, Tp).permute(1, 2, 0)
+print('planes(xt): max |sum - xp| = %.3e' % (xts - ap).abs().max().item(), ' slack zero:', bool((xt[:, :, B * Tp:] == 0).all() and (xt[:, Cin:] == 0).all()))
+js = [0, 1, 10, 19, 20]; cs = [0, 1, 300, 599, 600]
+refw = torch.stack([torch.stack([(apd[:, j:j + T, c].reshape(-1, 1) * dy.double().reshape(B * T, N)).sum(0) for c in cs]) for j in js])
+scw = refw.abs().mean()
+jj = torch.tensor(js, device=dev)[:, None]; cc = torch.tensor(cs, device=dev)[None, :]
+print('dW max err / mean|ref|: fp32 MFMA %.3e   bf16x6 %.3e   (dw6 vs dw32 everywhere: %.3e)' % (
+    ((dw32[jj, cc].double() - refw).abs().max() / scw).item(), ((dw6[jj, cc].double() - refw).abs().max() / scw).item(),
+    ((dw6 - dw32).abs().max() / scw).item()))
+
 def timeit(fn):
     fn(); torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -59,6 +85,6 @@ def timeit(fn):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 flop = 2.0 * B * T * N * KW * Cin
-for name, fn in (('fp32 mfma', f32), ('bf16x6', x6), ('split x', split_x), ('split w', split_w)):
+for name, fn in (('fp32 mfma', f32), ('bf16x6', x6), ('split x', split_x), ('split w', split_w), ('bww fp32', bww32), ('bww x6', bww6), ('split xt', split_xt), ('split yt', split_yt)):
     ms = timeit(fn)
-    print('%-10s %.3f ms' % (name, ms) + ('  %.1f TF (algorithmic)' % (flop / ms / 1e9) if fn in (f32, x6) else ''))
+    print('%-10s %.3f ms' % (name, ms) + ('  %.1f TF (algorithmic)' % (flop / ms / 1e9) if fn in (f32, x6, bww32, bww6) else ''))
