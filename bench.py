@@ -46,7 +46,7 @@ def parse():
     ap.add_argument('--no-early-critic', action='store_true', help='generator step: critic(G(x)) on the concatenated output (waits for the BLSTM branch) instead of on the spectral branch')
     ap.add_argument('--no-streams', action='store_true', help='single HIP stream (default: the three critic evaluations and the BLSTM branch on side streams)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--split-bf16', action='store_true', help='context Conv1D forward as a bf16x6 split product on the bf16 matrix cores (fp32-level accuracy; off by default, see DESIGN.md)')
+    ap.add_argument('--split-bf16', action='store_true', help='context Conv1D forward and weight gradient as bf16x6 split products on the bf16 matrix cores (fp32-level accuracy; off by default, see DESIGN.md)')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-variants', action='store_true', help='skip the extra timed loop of the bf16x6 context-Conv1D variant')
     ap.add_argument('--no-host-leg', action='store_true', help='skip the PCIe-inclusive leg (host batches through the prefetcher)')
@@ -287,7 +287,7 @@ def main():
         dtv = parallel.max_over_ranks(time.time() - tv, dev)
         opt.cfg.train_wgan_split_bf16 = False
         ops.conv1d_split(False)
-        variant = {'what': 'context Conv1D forward as a three-way bf16 split product (six bf16 MFMA products, fp32 accumulation; '
+        variant = {'what': 'context Conv1D forward and weight gradient as three-way bf16 split products (six bf16 MFMA products, fp32 accumulation; '
                            'fp32-level accuracy, tests/test_ops_gpu.py::test_conv1d_bf16x6_split_product); python bench.py --split-bf16',
                    'value': args.steps * B * T * world / dtv, 'unit': 'frames/s', 'ms_per_step': dtv / args.steps * 1e3}
 
@@ -344,7 +344,7 @@ def main():
                        'prune_dead_generator_branches_in_critic_step': bool(cfg.train_wgan_prune_dead_branches),
                        'stack_real_fake_critic_pass': bool(cfg.train_wgan_stack_real_fake),
                        'reuse_generator_ctx_conv_within_train_on_batch': bool(cfg.train_wgan_reuse_ctx_conv),
-                       'ctx_conv1d_forward': 'bf16x6 split product (bf16 MFMA, fp32 accumulate)' if cfg.train_wgan_split_bf16 else 'fp32 MFMA',
+                       'ctx_conv1d_forward_and_weight_gradient': 'bf16x6 split products (bf16 MFMA, fp32 accumulate)' if cfg.train_wgan_split_bf16 else 'fp32 MFMA',
                        'generator_params': mod.count_params(), 'critic_params': crit.model.count_params()},
         }
         res.update(extra)

@@ -240,8 +240,8 @@ def test_generator_step_reuses_the_context_conv_of_the_critic_step(setup):
         with _hip.KernelTimer() as kt:
             opt.device_step(0, X, Y)               # batchid 0: critic step + generator step
         torch.cuda.synchronize()
-        nconv = sum(1 for (name, tag, _) in kt.durations_ms()
-                    if name == 'ptts_gemm' and tag[5] == 1 and tag[3] == 0)      # context-Conv1D forward products
+        nconv = sum(1 for (name, tag, _) in kt.durations_ms()      # context-Conv1D forward products (either kernel)
+                    if (name == 'ptts_gemm' and tag[5] == 1 and tag[3] == 0) or name == 'ptts_conv1d_bf16x6')
         results.append((opt.gen_opti.flat.grad.detach().clone(), opt.critic_opti.flat.grad.detach().clone(), nconv))
     opt.cfg.train_wgan_reuse_ctx_conv = True
     restore(snap)
