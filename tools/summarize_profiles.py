@@ -47,7 +47,7 @@ traffic = {}
 for fdir, wdir in (('pmc_fetch', 'pmc_write'), ('pmc_fetch_conv', 'pmc_write_conv'), ('pmc_fetch_split', 'pmc_write_split')):
     fe, wr = pmc(fdir, 'FETCH_SIZE'), pmc(wdir, 'WRITE_SIZE')
     for k in fe:
-        if not ('gemm' in k or 'conv2d' in k or 'split3' in k) or k in traffic:
+        if not ('gemm' in k or 'conv2d' in k or 'split3' in k or 'wgrad' in k) or k in traffic:
             continue
         f_kib = sum(fe[k]) / len(fe[k])
         w_kib = sum(wr.get(k, [0.0])) / max(1, len(wr.get(k, [0.0])))
