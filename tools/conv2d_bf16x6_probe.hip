@@ -10,7 +10,8 @@
 // Measured on MI355X, [64,400,65,4], against 30 us for the library's packed-FMA kernel (all bit-for-bit fp32-level: max error 1.7e-6 of
 // mean |y| against fp64): this unpipelined version 23.5 us (TR 32 or 16, 512 threads); its staging phase
 // alone (load + activation + split + LDS write + the output stores) 8.0 us = 6.7 TB/s; its MFMA phase alone 11.3 us.  The phases
-// run one after the other inside a workgroup here; a persistent, double-buffered version overlaps them.
+// run one after the other inside a workgroup there.  conv2d_bf16x6_fwd_pipe below (persistent, 9 MFMA + 7 staging waves, double-buffered
+// stage) is bit-identical and measured 21.8 us: one workgroup per CU makes both roles slower (-DPIPE_NO_STAGE 19.3 us, -DPIPE_NO_MFMA 14.0 us).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -148,6 +149,123 @@ __global__ __launch_bounds__(THREADS) void conv2d_bf16x6_fwd(const float* __rest
     }
 }
 
+// ---- pipelined version: persistent workgroups of 16 waves, 9 MFMA waves + 7 staging waves, double-buffered LDS stage ----
+constexpr int PT = 16;                        // time rows per tile (400 = 25 tiles: no tile straddles two utterances)
+constexpr int PROWS = PT + KT - 1;            // 20 staged rows
+constexpr int PPLANE = PROWS * RSTRIDE;
+constexpr int PBUF = 3 * PPLANE;              // one stage: 35.5 KB
+constexpr int PTHREADS = 1024;
+constexpr int MFMA_WAVES = 9;                 // 17 bin groups: waves 0..7 take two (g, g + 9), wave 8 one
+
+__global__ __launch_bounds__(PTHREADS) void conv2d_bf16x6_fwd_pipe(const float* __restrict__ x, const u16* __restrict__ wtab,
+                                                                  const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                                  int T, float alpha) {
+    extern __shared__ __attribute__((aligned(16))) u16 sp[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int tiles_t = T / PT, ntiles = B * tiles_t;
+    const bool mfma_role = wave < MFMA_WAVES;
+
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    // staging waves: the loads of a tile are issued one whole iteration before they are converted (registers), so their
+    // latency is covered by the MFMA waves' work on the tile in between
+    const int stid = tid - MFMA_WAVES * 64;                      // 0 .. 447
+    const int sbin = stid % BINS, sr0 = stid / BINS;             // 6 rows of 72 bins per pass, 4 passes
+    f32x4v pre[4];
+    auto load = [&](int tile) {
+        const int b = tile / tiles_t, t0 = (tile - b * tiles_t) * PT;
+        const int f = sbin - 2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = sr0 + 6 * q, t = t0 + r - 2;
+            pre[q] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            if (sr0 < 6 && r < PROWS && t >= 0 && t < T && f >= 0 && f < F)
+                pre[q] = *reinterpret_cast<const f32x4v*>(x + (((long long)b * T + t) * F + f) * C);
+        }
+    };
+    auto convert = [&](u16* s) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = sr0 + 6 * q;
+            if (sr0 < 6 && r < PROWS) {
+                f32x4v v = pre[q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : alpha * v[e];
+                const bf16x4 h1 = __builtin_convertvector(v, bf16x4);
+                const f32x4v r1 = v - __builtin_convertvector(h1, f32x4v);
+                const bf16x4 h2 = __builtin_convertvector(r1, bf16x4);
+                const f32x4v r2 = r1 - __builtin_convertvector(h2, f32x4v);
+                const bf16x4 h3 = __builtin_convertvector(r2, bf16x4);
+                u16* dst = s + r * RSTRIDE + sbin * C;
+                *reinterpret_cast<bf16x4*>(dst) = h1;
+                *reinterpret_cast<bf16x4*>(dst + PPLANE) = h2;
+                *reinterpret_cast<bf16x4*>(dst + 2 * PPLANE) = h3;
+            }
+        }
+    };
+
+    bf16x8 wb[KT][3];
+    float bv = 0.f;
+    if (mfma_role) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wb[kt][p] = *reinterpret_cast<const bf16x8*>(wtab + ((kt * 3 + p) * 64 + lane) * 8);
+        bv = bias[li & 3];
+    }
+    int tile = blockIdx.x, i = 0;
+    if (!mfma_role && tile < ntiles) {
+        load(tile); convert(sp);
+        if (tile + (int)gridDim.x < ntiles) load(tile + gridDim.x);
+    }
+    __syncthreads();
+    for (; tile < ntiles; tile += gridDim.x, ++i) {
+        if (!mfma_role) {
+            const int nxt = tile + gridDim.x;
+#ifndef PIPE_NO_STAGE
+            if (nxt < ntiles) {
+                convert(sp + ((i + 1) & 1) * PBUF);              // the loads of tile `nxt`, issued an iteration ago
+                if (nxt + (int)gridDim.x < ntiles) load(nxt + gridDim.x);
+            }
+#endif
+        } else {
+            const u16* s = sp + (i & 1) * PBUF;
+            const int b = tile / tiles_t, t0 = (tile - b * tiles_t) * PT;
+            const int g = wave, g2 = wave + MFMA_WAVES;
+            const bool two = g2 < FG;
+            f32x4 acc = {bv, bv, bv, bv}, acc2 = {bv, bv, bv, bv};
+            const int base = li * RSTRIDE + (4 * g + 2 * lg) * C;
+            const int base2 = li * RSTRIDE + (4 * (two ? g2 : g) + 2 * lg) * C;
+#ifndef PIPE_NO_MFMA
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                bf16x8 a[3], a2[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    a[p] = *reinterpret_cast<const bf16x8*>(s + p * PPLANE + base + kt * RSTRIDE);
+                    a2[p] = *reinterpret_cast<const bf16x8*>(s + p * PPLANE + base2 + kt * RSTRIDE);
+                }
+#define P6(PA, PB)                                                                              \
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA], wb[kt][PB], acc, 0, 0, 0);     \
+                if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[PA], wb[kt][PB], acc2, 0, 0, 0);
+                P6(2, 0) P6(1, 1) P6(0, 2) P6(1, 0) P6(0, 1) P6(0, 0)
+#undef P6
+            }
+#endif
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = t0 + 4 * lg + r;
+                const int f = 4 * g + (li >> 2), f2 = 4 * g2 + (li >> 2);
+                if (f < F) y[(((long long)b * T + t) * F + f) * C + (li & 3)] = acc[r];
+                if (two && f2 < F) y[(((long long)b * T + t) * F + f2) * C + (li & 3)] = acc2[r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 int main() {
     const int B = 64, T = 400;
     const size_t n = (size_t)B * T * F * C;
@@ -200,5 +318,25 @@ int main() {
     const double us = ms * 1e3 / reps;
     printf("conv2d 4->4 5x5 forward, [64,400,65,4]: %.1f us per launch; algorithmic %.2f TFLOP/s; %.2f TB/s of the 53.2 MB in + out\n",
            us, 2.0 * B * T * F * C * C * KT * KF / us / 1e6, 2.0 * n * 4 / us / 1e6);
+    // pipelined version: same check (against the first kernel's verified output), then timing
+    {
+        float* dy2; hipMalloc(&dy2, n * 4); hipMemset(dy2, 0, n * 4);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_bf16x6_fwd_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF * 2);
+        int ngrid = 256; if (const char* e = getenv("PIPE_GRID")) ngrid = atoi(e);
+        hipLaunchKernelGGL(conv2d_bf16x6_fwd_pipe, dim3(ngrid), dim3(PTHREADS), 2 * PBUF * 2, 0, dx, dtab, db, dy2, B, T, alpha);
+        hipError_t err = hipDeviceSynchronize();
+        std::vector<float> hy2(n);
+        hipMemcpy(hy2.data(), dy2, n * 4, hipMemcpyDeviceToHost);
+        double dmax = 0;
+        for (size_t k = 0; k < n; ++k) { const double d = std::fabs((double)hy2[k] - hy[k]); dmax = d > dmax ? d : dmax; }
+        printf("pipelined kernel: %s, max |y_pipe - y| = %.3e\n", hipGetErrorString(err), dmax);
+        hipEventRecord(e0);
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(conv2d_bf16x6_fwd_pipe, dim3(ngrid), dim3(PTHREADS), 2 * PBUF * 2, 0, dx, dtab, db, dy2, B, T, alpha);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        const double us2 = ms * 1e3 / reps;
+        printf("pipelined (persistent, 9 MFMA + 7 staging waves, double-buffered): %.1f us per launch; %.2f TB/s of the 53.2 MB = %.2f of 8 TB/s\n",
+               us2, 2.0 * n * 4 / us2 / 1e6, 2.0 * n * 4 / us2 / 1e6 / 8.0);
+    }
     return 0;
 }
