@@ -9,7 +9,8 @@
 // build: hipcc -O3 --offload-arch=gfx950 [-DTR_=16|32 -DTHREADS_=256|512 -DNO_STAGE -DNO_MFMA] tools/conv2d_bf16x6_probe.hip -o tools/conv2d_bf16x6_probe
 // Measured on MI355X, [64,400,65,4], against 30 us for the library's packed-FMA kernel (all bit-for-bit fp32-level: max error 1.7e-6 of
 // mean |y| against fp64): this unpipelined version 23.5 us (TR 32 or 16, 512 threads); its staging phase
-// alone (load + activation + split + LDS write + the output stores) 8.0 us = 6.7 TB/s; its MFMA phase alone 11.3 us.  The phases
+// alone (load + activation + split + LDS write + the output stores, -DNO_MFMA) 8.0 us = 6.7 TB/s; its MFMA phase alone 6.1 us without
+// (-DNO_STAGE -DNO_STORE) and 11.3 us with the output stores (-DNO_STAGE); staging + MFMA without stores (-DNO_STORE) 19.4 us.  The phases
 // run one after the other inside a workgroup there.  conv2d_bf16x6_fwd_pipe below (persistent, 9 MFMA + 7 staging waves, double-buffered
 // stage) is bit-identical and measured 21.8 us: one workgroup per CU makes both roles slower (-DPIPE_NO_STAGE 19.3 us, -DPIPE_NO_MFMA 14.0 us).
 #include <hip/hip_runtime.h>
@@ -142,9 +143,13 @@ __global__ __launch_bounds__(THREADS) void conv2d_bf16x6_fwd(const float* __rest
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int f = 4 * g + (li >> 2), t = t0 + 16 * tb + 4 * lg + r;
+#ifdef NO_STORE
+            if (acc[r] == 12345.678f || acc2[r] == 12345.678f) y[0] = acc[r] + acc2[r];
+#else
             if (t < T && f < F) y[(((long long)b * T + t) * F + f) * C + (li & 3)] = acc[r];
             const int f2 = 4 * g2 + (li >> 2), t2 = t0 + 16 * tb2 + 4 * lg + r;
             if (two && t2 < T && f2 < F) y[(((long long)b * T + t2) * F + f2) * C + (li & 3)] = acc2[r];
+#endif
         }
     }
 }
