@@ -13,6 +13,7 @@
 // (-DNO_STAGE -DNO_STORE) and 11.3 us with the output stores (-DNO_STAGE); staging + MFMA without stores (-DNO_STORE) 19.4 us.  The phases
 // run one after the other inside a workgroup there.  conv2d_bf16x6_fwd_pipe below (persistent, 9 MFMA + 7 staging waves, double-buffered
 // stage) is bit-identical and measured 21.8 us: one workgroup per CU makes both roles slower (-DPIPE_NO_STAGE 19.3 us, -DPIPE_NO_MFMA 14.0 us).
+// conv2d_bf16x6_fwd_v3 (persistent, 8 waves doing both jobs, loads two tiles ahead in registers, two workgroups per CU): 20.3 us.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -271,6 +272,106 @@ __global__ __launch_bounds__(PTHREADS) void conv2d_bf16x6_fwd_pipe(const float* 
     }
 }
 
+// ---- third version: persistent workgroups of 8 waves, every wave does both jobs, software-pipelined over the tiles: the
+// global loads of tile i+2 are in flight (registers) while tile i is multiplied and tile i+1 is converted into the other
+// stage; 71 KB of LDS -> two workgroups per CU. ----
+constexpr int V3_THREADS = 512;
+__global__ __launch_bounds__(V3_THREADS) void conv2d_bf16x6_fwd_v3(const float* __restrict__ x, const u16* __restrict__ wtab,
+                                                                 const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                                 int T, float alpha) {
+    extern __shared__ __attribute__((aligned(16))) u16 sp[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int tiles_t = T / PT, ntiles = B * tiles_t;
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    const int sbin = tid % BINS, sr0 = tid / BINS;               // 7 rows of 72 bins per pass (504 threads), 3 passes
+    f32x4v pre[3];
+    auto load = [&](int tile) {
+        const int b = tile / tiles_t, t0 = (tile - b * tiles_t) * PT;
+        const int f = sbin - 2;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int r = sr0 + 7 * q, t = t0 + r - 2;
+            pre[q] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            if (sr0 < 7 && r < PROWS && t >= 0 && t < T && f >= 0 && f < F)
+                pre[q] = *reinterpret_cast<const f32x4v*>(x + (((long long)b * T + t) * F + f) * C);
+        }
+    };
+    auto convert = [&](u16* s) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int r = sr0 + 7 * q;
+            if (sr0 < 7 && r < PROWS) {
+                f32x4v v = pre[q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : alpha * v[e];
+                const bf16x4 h1 = __builtin_convertvector(v, bf16x4);
+                const f32x4v r1 = v - __builtin_convertvector(h1, f32x4v);
+                const bf16x4 h2 = __builtin_convertvector(r1, bf16x4);
+                const f32x4v r2 = r1 - __builtin_convertvector(h2, f32x4v);
+                const bf16x4 h3 = __builtin_convertvector(r2, bf16x4);
+                u16* dst = s + r * RSTRIDE + sbin * C;
+                *reinterpret_cast<bf16x4*>(dst) = h1;
+                *reinterpret_cast<bf16x4*>(dst + PPLANE) = h2;
+                *reinterpret_cast<bf16x4*>(dst + 2 * PPLANE) = h3;
+            }
+        }
+    };
+    bf16x8 wb[KT][3];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wb[kt][p] = *reinterpret_cast<const bf16x8*>(wtab + ((kt * 3 + p) * 64 + lane) * 8);
+    const float bv = bias[li & 3];
+
+    int tile = blockIdx.x, i = 0;
+    const int step = gridDim.x;
+    if (tile < ntiles) { load(tile); convert(sp); }
+    if (tile + step < ntiles) load(tile + step);
+    __syncthreads();
+    for (; tile < ntiles; tile += step, ++i) {
+        const u16* s = sp + (i & 1) * PBUF;
+        const int b = tile / tiles_t, t0 = (tile - b * tiles_t) * PT;
+        // bin groups of this wave: g = wave, wave + 8, (wave 0 only) 16
+        for (int g = wave; g < FG; g += 16) {
+            const int g2 = g + 8;
+            const bool two = g2 < FG;
+            f32x4 acc = {bv, bv, bv, bv}, acc2 = {bv, bv, bv, bv};
+            const int base = li * RSTRIDE + (4 * g + 2 * lg) * C;
+            const int base2 = li * RSTRIDE + (4 * (two ? g2 : g) + 2 * lg) * C;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                bf16x8 a[3], a2[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    a[p] = *reinterpret_cast<const bf16x8*>(s + p * PPLANE + base + kt * RSTRIDE);
+                    a2[p] = *reinterpret_cast<const bf16x8*>(s + p * PPLANE + base2 + kt * RSTRIDE);
+                }
+#define P6(PA, PB)                                                                              \
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA], wb[kt][PB], acc, 0, 0, 0);     \
+                if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[PA], wb[kt][PB], acc2, 0, 0, 0);
+                P6(2, 0) P6(1, 1) P6(0, 2) P6(1, 0) P6(0, 1) P6(0, 0)
+#undef P6
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = t0 + 4 * lg + r;
+                const int f = 4 * g + (li >> 2), f2 = 4 * g2 + (li >> 2);
+                if (f < F) y[(((long long)b * T + t) * F + f) * C + (li & 3)] = acc[r];
+                if (two && f2 < F) y[(((long long)b * T + t) * F + f2) * C + (li & 3)] = acc2[r];
+            }
+        }
+        // the next tile's registers (loaded an iteration ago) into the other stage, then the loads of the one after
+        if (tile + step < ntiles) {
+            convert(sp + ((i + 1) & 1) * PBUF);
+            if (tile + 2 * step < ntiles) load(tile + 2 * step);
+        }
+        __syncthreads();
+    }
+}
+
 int main() {
     const int B = 64, T = 400;
     const size_t n = (size_t)B * T * F * C;
@@ -342,6 +443,25 @@ int main() {
         const double us2 = ms * 1e3 / reps;
         printf("pipelined (persistent, 9 MFMA + 7 staging waves, double-buffered): %.1f us per launch; %.2f TB/s of the 53.2 MB = %.2f of 8 TB/s\n",
                us2, 2.0 * n * 4 / us2 / 1e6, 2.0 * n * 4 / us2 / 1e6 / 8.0);
+    }
+    {
+        float* dy3; hipMalloc(&dy3, n * 4); hipMemset(dy3, 0, n * 4);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_bf16x6_fwd_v3), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF * 2);
+        int ngrid = 512; if (const char* e = getenv("V3_GRID")) ngrid = atoi(e);
+        hipLaunchKernelGGL(conv2d_bf16x6_fwd_v3, dim3(ngrid), dim3(V3_THREADS), 2 * PBUF * 2, 0, dx, dtab, db, dy3, B, T, alpha);
+        hipError_t err = hipDeviceSynchronize();
+        std::vector<float> hy3(n);
+        hipMemcpy(hy3.data(), dy3, n * 4, hipMemcpyDeviceToHost);
+        double dmax = 0;
+        for (size_t k = 0; k < n; ++k) { const double d = std::fabs((double)hy3[k] - hy[k]); dmax = d > dmax ? d : dmax; }
+        printf("v3 kernel: %s, max |y_v3 - y| = %.3e\n", hipGetErrorString(err), dmax);
+        hipEventRecord(e0);
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(conv2d_bf16x6_fwd_v3, dim3(ngrid), dim3(V3_THREADS), 2 * PBUF * 2, 0, dx, dtab, db, dy3, B, T, alpha);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        const double us3 = ms * 1e3 / reps;
+        printf("v3 (persistent, 8 waves doing both jobs, loads two tiles ahead, grid %d): %.1f us per launch; %.2f TB/s = %.2f of 8 TB/s\n",
+               ngrid, us3, 2.0 * n * 4 / us3 / 1e6, 2.0 * n * 4 / us3 / 1e6 / 8.0);
     }
     return 0;
 }
