@@ -125,6 +125,39 @@ def np_adam_keras(p, g, m, v, t, lr, b1, b2, eps):
 # ------------------------------------------------------------------------------------------------
 # torch (CPU) primitives with Keras semantics; differentiable to any order
 # ------------------------------------------------------------------------------------------------
+def np_bf16_round(x):
+    """fp32 -> bfloat16 (round to nearest even), returned as fp32 values with 8 significant bits.  The rounding the split
+    pass of csrc/split.hip applies; restated on the bit pattern as IEEE defines it (no NaN/inf handling: finite inputs)."""
+    u = np.asarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = (u + 0x7FFF + ((u >> 16) & 1)) >> 16
+    return (r.astype(np.uint32) << 16).view(np.float32)
+
+
+def np_split3_bf16(x):
+    """The three-way bf16 split of an fp32 array: x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2) (subtractions in
+    fp32, exact).  x1 + x2 + x3 == x exactly for finite fp32 x (3 x 8 significant bits cover fp32's 24)."""
+    x = np.asarray(x, dtype=np.float32)
+    x1 = np_bf16_round(x)
+    r1 = (x - x1).astype(np.float32)
+    x2 = np_bf16_round(r1)
+    r2 = (r1 - x2).astype(np.float32)
+    x3 = np_bf16_round(r2)
+    return x1, x2, x3
+
+
+def np_conv1d_same_bf16x6(x, w, b=None):
+    """The context Conv1D forward as csrc/split.hip computes it: both fp32 operands split three ways, the six products
+    x1w1, x1w2, x2w1, x1w3, x2w2, x3w1 summed (here in fp64: the kernel accumulates in fp32, which the tests allow for)."""
+    xs = np_split3_bf16(x)
+    ws = np_split3_bf16(w)
+    out = 0.0
+    for i, j in ((0, 0), (0, 1), (1, 0), (0, 2), (1, 1), (2, 0)):
+        out = out + np_conv1d_same(xs[i].astype(np.float64), ws[j].astype(np.float64), None)
+    if b is not None:
+        out = out + np.asarray(b, dtype=np.float64)
+    return out
+
+
 def lrelu(x):
     return TF.leaky_relu(x, LRELU_ALPHA)
 

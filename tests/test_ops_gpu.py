@@ -344,6 +344,24 @@ def test_split3_planes_are_exact(ops):
     assert (ws[..., C:] == 0).all()
     # each plane is what rounding the running remainder to bf16 gives
     assert torch.equal(xp[0].permute(1, 2, 0, 3).reshape(B, T + pl + pr, Cp)[:, pl:pl + T, :C], x.to(torch.bfloat16))
+    # bit for bit the oracle's restatement of the split (oracle.np_split3_bf16), all three planes, both layouts
+    o1, o2, o3 = O.np_split3_bf16(x.cpu().numpy())
+    for plane, ref_ in zip(xp, (o1, o2, o3)):
+        got = plane.float().permute(1, 2, 0, 3).reshape(B, T + pl + pr, Cp)[:, pl:pl + T, :C].cpu().numpy()
+        assert (got == ref_).all()
+    q1, q2, q3 = O.np_split3_bf16(w.cpu().numpy())
+    for plane, ref_ in zip(wp, (q1, q2, q3)):
+        got = plane.float().permute(1, 2, 0, 3).reshape(N, KW, Cp)[..., :C].permute(1, 2, 0).cpu().numpy()
+        assert (got == ref_).all()
+    # frame-major planes of the weight-gradient kernel
+    Tp = T + pl + pr
+    Pp = ops._C1Split.plane_len(B, T, pl + pr + 1)
+    xt, Crows = ops._C1Split.transposed(x, B, T, C, pl, Tp, Pp)
+    for plane, ref_ in zip(xt, (o1, o2, o3)):
+        full = plane.float()[:C, :B * Tp].reshape(C, B, Tp).permute(1, 2, 0)
+        assert (full[:, pl:pl + T].cpu().numpy() == ref_).all()
+        assert (full[:, :pl] == 0).all() and (full[:, pl + T:] == 0).all()
+        assert (plane.float()[C:] == 0).all() and (plane.float()[:, B * Tp:] == 0).all()
 
 
 @pytest.mark.parametrize('case', [(2, 130, 37, 128, 5), (3, 129, 70, 256, 21), (1, 50, 33, 128, 3), (2, 300, 601, 256, 21)])
@@ -385,6 +403,9 @@ def test_conv1d_bf16x6_split_product(ops, case):
     e_split = ((y_split - yr).abs().max() / scale).item()
     assert e_split < 3e-5, (e_split, e_f32)                 # tolerance: fp32 rounding of a K <= 12 621 accumulation
     assert e_split < 4 * max(e_f32, 2e-6), (e_split, e_f32)
+    if Cin < 100:       # the oracle's own restatement of the six-product arithmetic (numpy loops: small cases only)
+        six = torch.from_numpy(O.np_conv1d_same_bf16x6(x32.numpy(), w32.numpy(), b32.numpy()))
+        assert ((y_split - six).abs().max() / scale).item() < 1e-5      # fp32 accumulation order only
     # weight gradient: a reduction over B*T frames
     gs = wr.grad.abs().mean()
     g_f32 = ((dw_f32 - wr.grad).abs().max() / gs).item()

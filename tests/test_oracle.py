@@ -133,3 +133,32 @@ def test_wls_weights():
     assert abs((1 - w_ls[1 + 32]) - 0.75 * 0.5) < 1e-12      # sigmoid centre
     assert 0 < ww < 0.75
     assert O.critic_runs(0) == 10 and O.critic_runs(25) == 5 and O.critic_runs(500) == 10
+
+
+def test_bf16_three_way_split_restatement():
+    """The oracle's restatement of the bf16x6 arithmetic of csrc/split.hip: the rounding agrees with torch's own
+    fp32 -> bfloat16 conversion (round to nearest even), the three planes add up to the fp32 operand EXACTLY, and the six
+    kept products reproduce an fp32 convolution to fp32 accuracy while three products do not."""
+    g = np.random.RandomState(5)
+    x = (g.randn(4096) * np.exp(6 * g.randn(4096))).astype(np.float32)
+    x[:4] = [0.0, -0.0, 1.0, -3.0]
+    # ties: a value exactly half way between two bf16 numbers must go to the even one
+    x[4:6] = np.array([0x3F808000, 0x3F818000], dtype=np.uint32).view(np.float32)
+    r = O.np_bf16_round(x)
+    assert np.array_equal(r, torch.from_numpy(x).to(torch.bfloat16).float().numpy())
+    x1, x2, x3 = O.np_split3_bf16(x)
+    assert np.array_equal((x1.astype(np.float64) + x2 + x3).astype(np.float32), x)
+    assert np.array_equal(x1.astype(np.float64) + x2.astype(np.float64) + x3.astype(np.float64), x.astype(np.float64))
+    for p in (x1, x2, x3):                       # each plane is a bf16 number
+        assert np.array_equal(O.np_bf16_round(p), p)
+    # a small 'same' Conv1D: six products vs the exact product of the fp32 operands
+    a = g.randn(2, 9, 7).astype(np.float32)
+    w = (g.randn(5, 7, 3) * 0.3).astype(np.float32)
+    b = g.randn(3).astype(np.float32)
+    exact = O.np_conv1d_same(a.astype(np.float64), w.astype(np.float64), b.astype(np.float64))
+    six = O.np_conv1d_same_bf16x6(a, w, b)
+    scale = np.abs(exact).mean()
+    assert np.abs(six - exact).max() / scale < 2e-7          # what is dropped: x2w3, x3w2, x3w3 ~ 2^-24 of a product
+    a1 = O.np_bf16_round(a); w1 = O.np_bf16_round(w)
+    plain = O.np_conv1d_same(a1.astype(np.float64), w1.astype(np.float64), b.astype(np.float64))
+    assert np.abs(plain - exact).max() / scale > 1e-3        # a plain bf16 product is 4 orders of magnitude worse
