@@ -156,7 +156,7 @@ def roofline_leg(opt, X, Y, args):
     avg = [(recs[0][i][0], recs[0][i][1], sum(r[i][2] for r in recs) / reps) for i in range(n)]
     M, N, K = B * T, opt.cfg.arch_hiddenwidth, opt.cfg.arch_ctx_winlen * X.shape[2]
     conv1d_fwd = [d for (nm, tag, d) in avg if nm == 'ptts_gemm' and tag == (M, N, K, 0, 0, 1)]
-    conv1d_bww = [d for (nm, tag, d) in avg if nm == 'ptts_gemm' and tag == (K, N, M, 1, 0, 1)]
+    conv1d_bww = [d for (nm, tag, d) in avg if (nm == 'ptts_gemm' and tag == (K, N, M, 1, 0, 1)) or nm in ('ptts_conv1d_wgrad_t', 'ptts_conv1d_wgrad_bf16x6')]
     conv1d_split = [d for (nm, tag, d) in avg if nm == 'ptts_conv1d_bf16x6']
     # the critic's conv2d stack: every conv2d call without a BatchNorm affine whose batch is B (G's convs carry scale/shift
     # or are 1->C without bias; separate them by running G first)

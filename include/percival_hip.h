@@ -171,6 +171,16 @@ int ptts_conv1d_wgrad_bf16x6(const void* xt1, const void* xt2, const void* xt3, 
                              const void* yt3, float* dw, int B, int T, int KW, int C, int N, int Crows, long long Pp,
                              void* stream);
 
+/* The same weight gradient in exact fp32 (v_mfma_f32_16x16x4_f32) over frame-major fp32 operands (conv1d_wgrad.hip):
+ *   ptts_transpose_frames  x [B][T][C] -> out [Crows][Pp], element (c, b Tp + pad_left + t), zero elsewhere;
+ *   ptts_conv1d_wgrad_t    dw (overwritten; and db[n] = sum_{b,t} dy[b][t][n] when db != NULL) from xt = the transposed
+ *                          padded frames and yt = the transposed gradient (Tp = T + KW - 1 for both).  KW in {3, 5, 21},
+ *                          N % 32 == 0, Crows % 64 == 0, Pp % 64 == 0, Pp >= 32 ceil(B (T + KW - 1) / 32) + 64. */
+int ptts_transpose_frames(const float* x, float* out, int B, int T, int C, int pad_left, int Tp, int Crows, long long Pp,
+                          void* stream);
+int ptts_conv1d_wgrad_t(const float* xt, const float* yt, float* dw, float* db, int B, int T, int KW, int C, int N, int Crows,
+                        long long Pp, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * channel-last reductions and elementwise passes
  * ------------------------------------------------------------------------------------- */

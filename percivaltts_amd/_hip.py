@@ -44,6 +44,8 @@ SIGNATURES = {
     'ptts_conv1d_bf16x6': (c_i, [c_p] * 8 + [c_i] * 5 + [c_p]),
     'ptts_split3_frames_t': (c_i, [c_p] * 4 + [c_i] * 6 + [c_ll, c_p]),
     'ptts_conv1d_wgrad_bf16x6': (c_i, [c_p] * 7 + [c_i] * 6 + [c_ll, c_p]),
+    'ptts_transpose_frames': (c_i, [c_p] * 2 + [c_i] * 6 + [c_ll, c_p]),
+    'ptts_conv1d_wgrad_t': (c_i, [c_p] * 4 + [c_i] * 6 + [c_ll, c_p]),
     'ptts_conv2d_bwd_partials': (c_i, [c_p] * 5 + [c_p, c_sz, c_p] + [c_i] * 10 + [c_f, c_p]),
     'ptts_conv2d_reduce_grouped': (c_i, [c_p, c_i, c_p]),
     'ptts_colstats_workspace_bytes': (c_sz, [c_ll, c_i]),

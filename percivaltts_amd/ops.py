@@ -646,6 +646,36 @@ class _C1Split(object):
         cls.w_planes = {}
 
 
+class _C1WgradT(object):
+    """Context-Conv1D weight gradient in exact fp32 over frame-major operands (csrc/conv1d_wgrad.hip): both operands are
+    transposed once so that the reduction index is contiguous, and the kernel forms every tap's operand in registers.
+    PTTS_WGRAD_T=0 switches back to the stream-K product of gemm.hip.  The transposed frames are kept for the tensor the
+    layer was called with (generator and critic convolve the same context input)."""
+    enabled = os.environ.get('PTTS_WGRAD_T', '1') == '1'
+    src = None
+    key = None
+    planes = None
+
+    @classmethod
+    def frames_t(cls, src, ap, KW):
+        B, Tp, C = ap.shape
+        Pp = _C1Split.plane_len(B, Tp - (KW - 1), KW)
+        Crows = (C + 63) // 64 * 64
+        key = None if src is None else (src._version, tuple(src.shape), KW, torch.cuda.current_stream().cuda_stream)
+        if src is not None and cls.src is src and cls.key == key:
+            return cls.planes
+        xt = torch.empty((Crows, Pp), dtype=torch.float32, device=ap.device)
+        call('ptts_transpose_frames', ptr(ap), ptr(xt), B, Tp, C, 0, Tp, Crows, Pp, stream(), tag=(B, Tp, C))
+        out = (xt, Crows, Pp)
+        if src is not None:
+            cls.src, cls.key, cls.planes = src, key, out
+        return out
+
+    @classmethod
+    def clear(cls):
+        cls.src = cls.key = cls.planes = None
+
+
 def conv1d_split(on):
     """Switch the bf16x6 split product of the context Conv1D forward on or off (see _C1Split)."""
     _C1Split.enabled = bool(on)
@@ -680,7 +710,7 @@ class Conv1dFn(torch.autograd.Function):
             if _C1Cache.capture:
                 _C1Cache.ap = ap
         ctx.save_for_backward(ap, w)
-        ctx.x_src = a if _C1Split.enabled else None
+        ctx.x_src = a
         ctx.has_b = b is not None
         ctx.dims = (B, T, Cin, KW, N, pl)
         return y
@@ -701,6 +731,17 @@ class Conv1dFn(torch.autograd.Function):
             dw = torch.empty_like(w)
             call('ptts_conv1d_wgrad_bf16x6', ptr(xt[0]), ptr(xt[1]), ptr(xt[2]), ptr(yt[0]), ptr(yt[1]), ptr(yt[2]), ptr(dw),
                  B, T, KW, Cin, N, Crows, Pp, stream(), tag=(B, T, KW, Cin, N))
+        elif ctx.needs_input_grad[1] and not _Flags.skip_param_grads and _C1WgradT.enabled and dy.is_cuda \
+                and _C1Split.eligible_wgrad(KW, N) and ap.numel() > 0 and B * T >= 4096:
+            # exact fp32 over frame-major operands (csrc/conv1d_wgrad.hip); the bias gradient comes with it
+            xt, Crows, Pp = _C1WgradT.frames_t(ctx.x_src, ap, KW)
+            yt = torch.empty((N, Pp), dtype=torch.float32, device=dy.device)
+            call('ptts_transpose_frames', ptr(dy), ptr(yt), B, T, N, 0, T + KW - 1, N, Pp, stream(), tag=(B, T, N))
+            dw = torch.empty_like(w)
+            if need_b:
+                db = torch.empty(N, dtype=torch.float32, device=dy.device)
+            call('ptts_conv1d_wgrad_t', ptr(xt), ptr(yt), ptr(dw), ptr(db), B, T, KW, Cin, N, Crows, Pp, stream(),
+                 tag=(B, T, KW, Cin, N))
         elif ctx.needs_input_grad[1] and not _Flags.skip_param_grads:
             dw = torch.empty_like(w)
             if need_b and N > 4:          # bias gradient taken from the B tiles of the weight-gradient product

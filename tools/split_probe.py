@@ -66,7 +66,20 @@ def split_yt():
 def bww6():
     call('ptts_conv1d_wgrad_bf16x6', ptr(xt[0]), ptr(xt[1]), ptr(xt[2]), ptr(yt[0]), ptr(yt[1]), ptr(yt[2]), ptr(dw6),
          B, T, KW, Cin, N, Crows, Pp, stream())
+dwt = torch.empty_like(w); dbt = torch.empty(N, device=dev)
+def tr_x():
+    global xtf, Crt
+    xtf, Crt, _ = ops._C1WgradT.frames_t(None, ap, KW)
+def tr_y():
+    global ytf
+    ytf = torch.empty((N, Pp), device=dev)
+    call('ptts_transpose_frames', ptr(dy), ptr(ytf), B, T, N, 0, Tp, N, Pp, stream())
+def bwwt():
+    call('ptts_conv1d_wgrad_t', ptr(xtf), ptr(ytf), ptr(dwt), ptr(dbt), B, T, KW, Cin, N, Crt, Pp, stream())
+tr_x(); tr_y(); bwwt()
 split_xt(); split_yt(); bww32(); bww6(); torch.cuda.synchronize()
+print('fp32 frame-major wgrad: dw vs stream-K fp32 everywhere %.3e (of mean |dw|), db rel err %.3e' % (
+    ((dwt - dw32).abs().max() / dw32.abs().mean()).item(), ((dbt - dy.sum((0, 1))).abs().max() / dy.sum((0, 1)).abs().mean()).item()))
 xts = xt.float().sum(0)[:Cin, :B * Tp].reshape(Cin, B, Tp).permute(1, 2, 0)
 print('planes(xt): max |sum - xp| = %.3e' % (xts - ap).abs().max().item(), ' slack zero:', bool((xt[:, :, B * Tp:] == 0).all() and (xt[:, Cin:] == 0).all()))
 js = [0, 1, 10, 19, 20]; cs = [0, 1, 300, 599, 600]
@@ -76,6 +89,7 @@ jj = torch.tensor(js, device=dev)[:, None]; cc = torch.tensor(cs, device=dev)[No
 print('dW max err / mean|ref|: fp32 MFMA %.3e   bf16x6 %.3e   (dw6 vs dw32 everywhere: %.3e)' % (
     ((dw32[jj, cc].double() - refw).abs().max() / scw).item(), ((dw6[jj, cc].double() - refw).abs().max() / scw).item(),
     ((dw6 - dw32).abs().max() / scw).item()))
+print('dW max err / mean|ref|: fp32 frame-major %.3e' % ((dwt[jj, cc].double() - refw).abs().max() / scw).item())
 
 def timeit(fn):
     fn(); torch.cuda.synchronize()
@@ -85,6 +99,6 @@ def timeit(fn):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 flop = 2.0 * B * T * N * KW * Cin
-for name, fn in (('fp32 mfma', f32), ('bf16x6', x6), ('split x', split_x), ('split w', split_w), ('bww fp32', bww32), ('bww x6', bww6), ('split xt', split_xt), ('split yt', split_yt)):
+for name, fn in (('fp32 mfma', f32), ('bf16x6', x6), ('split x', split_x), ('split w', split_w), ('bww fp32', bww32), ('bww x6', bww6), ('split xt', split_xt), ('split yt', split_yt), ('bww f32 T', bwwt), ('transp x', tr_x), ('transp y', tr_y)):
     ms = timeit(fn)
-    print('%-10s %.3f ms' % (name, ms) + ('  %.1f TF (algorithmic)' % (flop / ms / 1e9) if fn in (f32, x6, bww32, bww6) else ''))
+    print('%-10s %.3f ms' % (name, ms) + ('  %.1f TF (algorithmic)' % (flop / ms / 1e9) if fn in (f32, x6, bww32, bww6, bwwt) else ''))
