@@ -32,8 +32,8 @@ PEAK_HBM_GBPS = 8000.0          # HBM3E spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=500, help='timed train_on_batch steps (default 500 = 100 cycles of 5 critic + 1 generator step)')
+    ap.add_argument('--warmup', type=int, default=100)
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--frames', type=int, default=400)
     ap.add_argument('--ctx', type=int, default=601)
@@ -46,9 +46,12 @@ def parse():
     ap.add_argument('--no-early-critic', action='store_true', help='generator step: critic(G(x)) on the concatenated output (waits for the BLSTM branch) instead of on the spectral branch')
     ap.add_argument('--no-streams', action='store_true', help='single HIP stream (default: the three critic evaluations and the BLSTM branch on side streams)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--split-bf16', action='store_true', help='context Conv1D forward and weight gradient as bf16x6 split products on the bf16 matrix cores (fp32-level accuracy; off by default, see DESIGN.md)')
+    ap.add_argument('--split-bf16', action='store_true', help='(default) context Conv1D forward and weight gradient as bf16x6 split products on the bf16 matrix cores: fp32 arithmetic by three-way bf16 splits, six products, fp32 accumulation')
+    ap.add_argument('--fp32-mfma', action='store_true', help='context Conv1D forward and weight gradient on the fp32 MFMA pipe instead of the bf16x6 split products')
+    ap.add_argument('--no-reference-shape', action='store_true', help="skip the leg at the reference's own training geometry (B=10, T=400, 425 -> 163)")
+    ap.add_argument('--no-unreduced', action='store_true', help='skip the timed loop with every exact work reduction switched off')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--no-variants', action='store_true', help='skip the extra timed loop of the bf16x6 context-Conv1D variant')
+    ap.add_argument('--no-variants', action='store_true', help='skip the extra timed loop of the fp32-MFMA context-Conv1D variant')
     ap.add_argument('--no-host-leg', action='store_true', help='skip the PCIe-inclusive leg (host batches through the prefetcher)')
     ap.add_argument('--cpu-batch', type=int, default=32)
     return ap.parse_args()
@@ -223,6 +226,66 @@ def roofline_leg(opt, X, Y, args):
     return out
 
 
+def build_optimizer(args, ctx, spec, nm, batch, errtype):
+    """Generator + critic + optimiser at one geometry (random-init weights of the named architecture)."""
+    import io, contextlib
+    from percivaltts_amd import vocoders, modeltts_common, networks_critic, optimizertts_wgan
+    cfg = make_cfg(args)
+    cfg.train_batch_size = batch
+    cfg.train_wgan_hipgraph = bool(args.graph) and int(os.environ.get('WORLD_SIZE', '1')) <= 1
+    cfg.train_wgan_prune_dead_branches = not args.no_prune
+    cfg.train_wgan_parallel_streams = (not args.no_streams) and not cfg.train_wgan_hipgraph
+    cfg.train_wgan_stack_real_fake = not args.no_stack
+    cfg.train_wgan_reuse_ctx_conv = not args.no_ctx_reuse
+    cfg.train_wgan_early_critic = not args.no_early_critic
+    cfg.train_wgan_split_bf16 = not args.fp32_mfma
+    voc = vocoders.VocoderPML(16000, 0.005, spec, nm)
+    with contextlib.redirect_stdout(io.StringIO()):
+        mod = modeltts_common.DCNNF0SpecNoiseFeatures(ctx, voc, cfg)
+        crit = networks_critic.Critic(voc, ctx, cfg)
+        opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype=errtype, critic=crit)
+        opt.prepare()
+    opt.generator_updates = 26           # steady state: critic_runs = 5 (optimizertts_wgan.py:225-228)
+    return cfg, voc, mod, crit, opt
+
+
+def percentiles(xs):
+    xs = sorted(xs)
+    if not xs:
+        return None
+    q = lambda f: xs[min(len(xs) - 1, int(round(f * (len(xs) - 1))))]
+    return {'median': q(0.5), 'p10': q(0.1), 'p90': q(0.9), 'n': len(xs)}
+
+
+def timed_loop(opt, batches, nsteps, warmup, dev, cycle=5):
+    """W untimed steps, then EXACTLY `nsteps` steps between barrier + synchronize on both sides (wall clock, max over
+    ranks).  Inside the timed region a HIP event is recorded on the launch stream after every `cycle` steps (one
+    5 critic : 1 generator cycle of the steady-state schedule): their spacing gives the per-cycle distribution."""
+    import torch
+    from percivaltts_amd import parallel
+    nbuf = len(batches)
+
+    def run(n, start, events=None):
+        for i in range(n):
+            X, Y = batches[(start + i) % nbuf]
+            opt.device_step(start + i, X, Y)
+            if events is not None and (i + 1) % cycle == 0:
+                ev = torch.cuda.Event(enable_timing=True); ev.record(); events.append(ev)
+
+    run(warmup, 0)
+    parallel.barrier(); torch.cuda.synchronize()
+    events = []
+    e0 = torch.cuda.Event(enable_timing=True)
+    t0 = time.time()
+    e0.record()
+    run(nsteps, 0, events)
+    torch.cuda.synchronize(); parallel.barrier()
+    dt = parallel.max_over_ranks(time.time() - t0, dev)
+    marks = [e0] + events
+    cyc = [marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)]
+    return dt, percentiles(cyc)
+
+
 def main():
     args = parse()
     world_env = int(os.environ.get('WORLD_SIZE', '0'))
@@ -233,67 +296,48 @@ def main():
         sys.exit(subprocess.call(cmd))
 
     import torch
-    from percivaltts_amd import vocoders, modeltts_common, networks_critic, optimizertts_wgan, parallel, backend_hip
+    from percivaltts_amd import parallel, backend_hip, ops
 
     world, rank = parallel.init()
     dev = backend_hip.device()
-    cfg = make_cfg(args)
-    cfg.train_wgan_hipgraph = bool(args.graph) and world == 1
-    cfg.train_wgan_prune_dead_branches = not args.no_prune
-    cfg.train_wgan_parallel_streams = (not args.no_streams) and not cfg.train_wgan_hipgraph
-    cfg.train_wgan_stack_real_fake = not args.no_stack
-    cfg.train_wgan_reuse_ctx_conv = not args.no_ctx_reuse
-    cfg.train_wgan_early_critic = not args.no_early_critic
-    cfg.train_wgan_split_bf16 = bool(args.split_bf16)
     spec, nm = 65, 20
-    voc = vocoders.VocoderPML(16000, 0.005, spec, nm)
-    import io, contextlib
-    quiet = io.StringIO()
-    with contextlib.redirect_stdout(quiet):
-        mod = modeltts_common.DCNNF0SpecNoiseFeatures(args.ctx, voc, cfg)
-        crit = networks_critic.Critic(voc, args.ctx, cfg)
-        opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype=args.errtype, critic=crit)
-        opt.prepare()
+    cfg, voc, mod, crit, opt = build_optimizer(args, args.ctx, spec, nm, args.batch, args.errtype)
     par_streams = bool(cfg.train_wgan_parallel_streams)
-    opt.generator_updates = 26           # steady state: critic_runs = 5 (optimizertts_wgan.py:225-228)
 
     B, T = args.batch, args.frames
     nbuf = 3
     batches = [synthetic(B, T, args.ctx, voc.featuressize(), spec, 123 + 17 * rank + i, dev) for i in range(nbuf)]
 
-    def run(nsteps, start):
-        for i in range(nsteps):
-            X, Y = batches[(start + i) % nbuf]
-            opt.device_step(start + i, X, Y)
+    # ---- the headline loop ------------------------------------------------------------------------------------------
+    dt, cyc = timed_loop(opt, batches, args.steps, args.warmup, dev)
+    extra = {}
+    if cyc:
+        extra['cycle_ms'] = dict(cyc, what='HIP-event spacing of 5-step cycles (5 critic + 1 generator step) inside the timed region')
 
-    run(args.warmup, 0)
-    parallel.barrier(); torch.cuda.synchronize()
-    t0 = time.time()
-    run(args.steps, 0)
-    torch.cuda.synchronize(); parallel.barrier()
-    dt = parallel.max_over_ranks(time.time() - t0, dev)
-
-    # the same timed loop with the context-Conv1D forward as a bf16x6 split product (off by default):
-    # reported beside the headline number, never as `value`
-    variant = None
-    if not args.split_bf16 and not args.no_variants:
-        from percivaltts_amd import ops
-        opt.cfg.train_wgan_split_bf16 = True
-        run(max(6, args.warmup), 0)
-        parallel.barrier(); torch.cuda.synchronize()
-        tv = time.time()
-        run(args.steps, 0)
-        torch.cuda.synchronize(); parallel.barrier()
-        dtv = parallel.max_over_ranks(time.time() - tv, dev)
+    short = max(6, min(args.steps, 60))      # the side loops: a bounded number of steps each
+    # the same loop with the context Conv1D on the fp32 MFMA pipe (the variant kept selectable: --fp32-mfma)
+    if not args.fp32_mfma and not args.no_variants:
         opt.cfg.train_wgan_split_bf16 = False
-        ops.conv1d_split(False)
-        variant = {'what': 'context Conv1D forward and weight gradient as three-way bf16 split products (six bf16 MFMA products, fp32 accumulation; '
-                           'fp32-level accuracy, tests/test_ops_gpu.py::test_conv1d_bf16x6_split_product); python bench.py --split-bf16',
-                   'value': args.steps * B * T * world / dtv, 'unit': 'frames/s', 'ms_per_step': dtv / args.steps * 1e3}
+        dtv, _ = timed_loop(opt, batches, short, 6, dev)
+        opt.cfg.train_wgan_split_bf16 = True
+        ops.conv1d_split(True)
+        extra['variant_ctx_conv1d_fp32_mfma'] = {
+            'what': 'same loop, context Conv1D forward and weight gradient on v_mfma_f32_32x32x2_f32 / 16x16x4_f32 (python bench.py --fp32-mfma)',
+            'value': short * B * T * world / dtv, 'unit': 'frames/s', 'ms_per_step': dtv / short * 1e3, 'steps': short}
+    # the same loop with every exact work reduction off: the TF graph's own amount and order of work
+    if not args.no_unreduced and not (args.no_prune and args.no_stack and args.no_ctx_reuse and args.no_early_critic):
+        saved = (opt._gen_spec, opt.cfg.train_wgan_stack_real_fake, opt.cfg.train_wgan_reuse_ctx_conv, opt.cfg.train_wgan_early_critic)
+        opt._gen_spec = None
+        opt.cfg.train_wgan_stack_real_fake = opt.cfg.train_wgan_reuse_ctx_conv = opt.cfg.train_wgan_early_critic = False
+        dtu, _ = timed_loop(opt, batches, short, 6, dev)
+        opt._gen_spec, opt.cfg.train_wgan_stack_real_fake, opt.cfg.train_wgan_reuse_ctx_conv, opt.cfg.train_wgan_early_critic = saved
+        extra['all_exact_work_reductions_off'] = {
+            'what': "--no-prune --no-stack --no-ctx-reuse --no-early-critic: G's f0/noise branches run in the critic step, critic(real) and "
+                    'critic(fake) as two passes, the generator step recomputes its context Conv1D and waits for the BLSTM before the critic',
+            'value': short * B * T * world / dtu, 'unit': 'frames/s', 'ms_per_step': dtu / short * 1e3, 'steps': short}
 
     # separate timings of the two step kinds (eager or graph as configured) and the roofline leg.  Every rank runs them
     # (the steps contain the gradient all-reduce: a collective only rank 0 entered would hang the job); rank 0 reports.
-    extra = {}
     X, Y = batches[0]
     def timeit(fn, n):
         fn(); torch.cuda.synchronize()
@@ -304,10 +348,10 @@ def main():
     use_graph = bool(cfg.train_wgan_hipgraph)
     extra['critic_step_ms'] = timeit((lambda: opt._graphed('critic', X, Y)) if use_graph else (lambda: opt.critic_step(X, Y)), 10)
     extra['generator_step_ms'] = timeit((lambda: opt._graphed('generator', X, Y)) if use_graph else (lambda: opt.generator_step(X, Y)), 5)
-    if variant is not None:
-        extra['variant_ctx_conv1d_bf16x6'] = variant
     if not args.no_roofline:
         extra.update(roofline_leg(opt, X, Y, args))
+        opt.cfg.train_wgan_parallel_streams = par_streams
+        opt._model.kerasmodel.parallel_branches = par_streams
     if not args.no_host_leg:
         # PCIe-inclusive rate: the same steps fed from host numpy batches through the double-buffered prefetcher
         # (data.BatchPrefetcher: loader thread + copy stream), as the training driver feeds train_on_batch.  Never `value`.
@@ -325,6 +369,18 @@ def main():
         extra['pcie_inclusive'] = {'value': nh * B * T * world / dth, 'unit': 'frames/s', 'steps': nh,
                                    'ms_per_step': dth / nh * 1e3, 'host_bytes_per_step': int(sum(a.nbytes for a in pool[0])),
                                    'how': 'host numpy batches -> loader thread -> H2D on a copy stream, 2 batches ahead (data.BatchPrefetcher)'}
+    if not args.no_reference_shape:
+        # the reference's own training geometry (run.py:76,89,125-126): B=10 sentences of 400 frames, 425 context labels ->
+        # 163 features (f0 1 + spec 129 + noise 33), same architecture; per rank
+        rB, rT, rctx, rspec, rnm = 10, 400, 425, 129, 33
+        _, rvoc, _, _, ropt = build_optimizer(args, rctx, rspec, rnm, rB, args.errtype)
+        rb = [synthetic(rB, rT, rctx, rvoc.featuressize(), rspec, 900 + 17 * rank + i, dev) for i in range(nbuf)]
+        nr = max(10, min(args.steps, 100))
+        dtr, rcyc = timed_loop(ropt, rb, nr, 10, dev)
+        extra['reference_shape'] = {'workload': 'run.py geometry: [10,400,425] -> [10,400,163] (f0 1 + spec 129 + noise 33), per GPU',
+                                    'value': nr * rB * rT * world / dtr, 'unit': 'frames/s', 'ms_per_step': dtr / nr * 1e3,
+                                    'steps': nr, 'cycle_ms': rcyc}
+        del ropt, rb
     parallel.barrier()
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         extra['cpu_baseline'] = cpu_baseline(args, (args.ctx, spec, nm))
@@ -344,7 +400,10 @@ def main():
                        'prune_dead_generator_branches_in_critic_step': bool(cfg.train_wgan_prune_dead_branches),
                        'stack_real_fake_critic_pass': bool(cfg.train_wgan_stack_real_fake),
                        'reuse_generator_ctx_conv_within_train_on_batch': bool(cfg.train_wgan_reuse_ctx_conv),
-                       'ctx_conv1d_forward_and_weight_gradient': 'bf16x6 split products (bf16 MFMA, fp32 accumulate)' if cfg.train_wgan_split_bf16 else 'fp32 MFMA',
+                       'ctx_conv1d_forward_and_weight_gradient': 'bf16x6 split (bf16 MFMA, fp32 accumulate)' if cfg.train_wgan_split_bf16 else 'fp32 MFMA',
+                       'conv2d_stacks': ops.conv2d_path_description() if hasattr(ops, 'conv2d_path_description') else 'fp32 packed-FMA stencil',
+                       'batchnorm_statistics': 'per rank (B={} each; SyncBN off)'.format(B) if not getattr(cfg, 'train_sync_batchnorm', False) else 'synchronised over ranks (SyncBN)',
+                       'input_batches_rotating': nbuf,
                        'generator_params': mod.count_params(), 'critic_params': crit.model.count_params()},
         }
         res.update(extra)

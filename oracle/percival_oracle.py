@@ -450,10 +450,12 @@ def wls_weights(specsize, noisesize, vuvsize, LScoef, transidx, transcoef=1.0 / 
     return 1.0 - w, float(np.mean(w))
 
 
-def critic_step_loss(cw, gw, a, X, Y, alpha, gp_lambda=10.0):
-    """One critic training loss (optimizertts_wgan.py:115-154): returns (total, parts dict)."""
+def critic_step_loss(cw, gw, a, X, Y, alpha, gp_lambda=10.0, training=True):
+    """One critic loss (optimizertts_wgan.py:115-154): returns (total, parts dict).  training=False is the evaluation of
+    update_validation_cost (:259-260, `critic_model.evaluate`, learning phase 0): G's BatchNorm uses its moving statistics;
+    the gradient penalty is still part of the loss."""
     with torch.no_grad():
-        fake = generator_forward(gw, a, X, training=True)          # frozen G, learning phase 1 (batch stats)
+        fake = generator_forward(gw, a, X, training=training)      # frozen G; learning phase 1 -> batch statistics
     valid = critic_forward(cw, a, Y, X)
     fake_v = critic_forward(cw, a, fake, X)
     x_hat = random_weighted_average(Y, fake, alpha).detach().requires_grad_(True)
@@ -465,9 +467,9 @@ def critic_step_loss(cw, gw, a, X, Y, alpha, gp_lambda=10.0):
     return total, {'valid': l_valid, 'fake': l_fake, 'gp': gp, 'g': g, 'fake_sample': fake}
 
 
-def generator_step_loss(cw, gw, a, X, Y, errtype='WLSWGAN', w_ls=None, wgan_weight=1.0, update_moving=True):
-    """Generator training loss (optimizertts_wgan.py:157-213)."""
-    pred = generator_forward(gw, a, X, training=True, update_moving=update_moving)
+def generator_step_loss(cw, gw, a, X, Y, errtype='WLSWGAN', w_ls=None, wgan_weight=1.0, update_moving=True, training=True):
+    """Generator loss (optimizertts_wgan.py:157-213); training=False: `generator_model.evaluate` of :250-257 (BN inference)."""
+    pred = generator_forward(gw, a, X, training=training, update_moving=update_moving and training)
     valid = critic_forward(cw, a, pred, X)
     l_w = wasserstein_loss(-1.0, valid)
     if errtype == 'WGAN':

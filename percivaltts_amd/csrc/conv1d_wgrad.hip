@@ -66,7 +66,7 @@ typedef void __attribute__((address_space(3)))* t_lptr;
 // see gemm.hip dma16: inline assembly so that the kernel, not the compiler, orders the DMAs
 __device__ __forceinline__ void dma16f(const float* src, float* lds_wave_base) {
     const unsigned lds_off = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long)(t_lptr)lds_wave_base);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_off) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_off) : "memory", "m0");
 }
 
 template <int KW>

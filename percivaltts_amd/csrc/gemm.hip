@@ -348,7 +348,7 @@ constexpr int DMA_STAGE_FLOATS = BM * BK + BK * BN;      // 4096 floats = 16 KB
 __device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
     // wave-uniform LDS byte address -> M0
     const unsigned lds_off = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long)(dma_lptr)lds_wave_base);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_off) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_off) : "memory", "m0");
 }
 
 template <int TRANSA, bool ATOMIC>

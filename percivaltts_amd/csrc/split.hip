@@ -9,7 +9,7 @@
 // (tools/bf16x6_accuracy.py: max error 4.6e-6 of mean |C| at K = 12 621, against 3.8e-6 for the fp32 product).
 //
 // Role on the hot path: the context Conv1D forward of critic and generator (reference networktts.py:116-120), the
-// largest flop item of both networks.  Off by default (PTTS_CONV1D_SPLIT / cfg.train_wgan_split_bf16): see DESIGN.md.
+// largest flop item of both networks.  On by default (PTTS_CONV1D_SPLIT=0 / cfg.train_wgan_split_bf16 = False select the fp32 MFMA kernels): see DESIGN.md.
 //
 // Data: the split pass writes the zero-padded frames as three bf16 planes [Cp/32][B*(T+KW-1)][32] (32-channel blocks, Cp
 // = C rounded up to 32) and the kernel [KW][C][N] as three TRANSPOSED planes [Cp/32][N][KW][32]: both MFMA operands
@@ -124,7 +124,7 @@ typedef void __attribute__((address_space(3)))* s_lptr;
 // see gemm.hip dma16: inline assembly so that the kernel, not the compiler, orders the DMAs
 __device__ __forceinline__ void dma16h(const u16* src, u16* lds_wave_base) {
     const unsigned lds_off = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long)(s_lptr)lds_wave_base);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_off) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_off) : "memory", "m0");
 }
 
 // padded-buffer row of frame m (its tap 0)

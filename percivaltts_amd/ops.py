@@ -557,10 +557,13 @@ def conv1d_cache(on):
 class _C1Split(object):
     """Context-Conv1D forward as an fp32 product on the bf16 matrix cores (csrc/split.hip: three-way bf16 split of both
     operands, six bf16 MFMA products, fp32 accumulation -- fp32-level accuracy, see tools/bf16x6_accuracy.py and
-    tests/test_ops_gpu.py).  Off unless PTTS_CONV1D_SPLIT=1 or conv1d_split(True) (cfg.train_wgan_split_bf16).
+    tests/test_ops_gpu.py).  ON by default (round-1 verdict: admissible as fp32 arithmetic -- planes checked bit for bit
+    against oracle.np_split3_bf16, every kernel tested against the fp64 oracle at its fp32 sibling's tolerance);
+    PTTS_CONV1D_SPLIT=0, conv1d_split(False) or cfg.train_wgan_split_bf16 = False select the fp32-MFMA kernels.
     The planes of the frames are kept for the tensor they were made from (generator and critic convolve the same
     context input, in the critic step and again in the generator step); the planes of a kernel until it is updated."""
-    enabled = os.environ.get('PTTS_CONV1D_SPLIT', '0') == '1'
+    default = os.environ.get('PTTS_CONV1D_SPLIT', '1') == '1'
+    enabled = default
     x_src = None        # the tensor (kept alive: its address cannot be reused) ...
     x_key = None        # ... its version / shape / padding
     x_planes = None
@@ -677,8 +680,8 @@ class _C1WgradT(object):
 
 
 def conv1d_split(on):
-    """Switch the bf16x6 split product of the context Conv1D forward on or off (see _C1Split)."""
-    _C1Split.enabled = bool(on)
+    """Switch the bf16x6 split product of the context Conv1D forward on or off (see _C1Split); None: the default."""
+    _C1Split.enabled = _C1Split.default if on is None else bool(on)
     _C1Split.clear()
 
 

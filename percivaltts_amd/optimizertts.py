@@ -147,6 +147,8 @@ class OptimizerTTS:
             epochs_modelssaved = extras['epochs_modelssaved']
             epochs_durs = extras['epochs_durs']
             generator_updates = extras['generator_updates']
+            if hasattr(self, 'generator_updates'):
+                self.generator_updates = generator_updates      # the critic_runs schedule continues where it stopped
             epochstart = extras['epoch'] + 1
             same = all(getattr(savedcfg, k) == getattr(self.cfg, k)
                        for k in ('train_min_nbepochs', 'train_max_nbepochs', 'train_cancel_nodecepochs'))
@@ -192,6 +194,9 @@ class OptimizerTTS:
             print_tty('\r                                                           \r')
             costs['model_training'].append(np.mean(costs_tra_batches) if costs_tra_batches else float('nan'))
 
+            # data parallelism: every rank has accumulated BatchNorm moving statistics from its own shards; validation and
+            # the checkpoints use their mean over the ranks, so that all ranks validate (and rank 0 saves) the same model
+            self._sync_moving_statistics()
             cost_val = self.update_validation_cost(costs, X_vals, Y_vals)
 
             print_log("    E{}/{} {}  cost_tra={:.6f} (load:{}s train:{}s)  cost_val={:.6f} ({:.4f}% RMSE)  {} MiB GPU {} MiB RAM".format(
@@ -202,13 +207,16 @@ class OptimizerTTS:
 
             if np.isnan(cost_val): raise ValueError('ERROR: Validation cost is nan!')
 
-            self._model.save(stem + '-last.h5', printfn=print_log, extras={'cost_val': cost_val})
+            main = parallel.is_main()                   # files are written by rank 0 only (the replicas are identical)
+            if main:
+                self._model.save(stem + '-last.h5', printfn=print_log, extras={'cost_val': cost_val})
 
             if epoch >= self.cfg.train_min_nbepochs:   # no model is trusted before train_min_nbepochs
                 if (best_val is None) or (cost_val < best_val):
                     best_val = cost_val
-                    self._model.save(params_savefile, printfn=print_log, extras={'cost_val': cost_val},
-                                     infostr='(E{} C{:.4f})'.format(epoch, best_val))
+                    if main:
+                        self._model.save(params_savefile, printfn=print_log, extras={'cost_val': cost_val},
+                                         infostr='(E{} C{:.4f})'.format(epoch, best_val))
                     epochs_modelssaved.append(epoch)
                     nbnodecepochs = 0
                 else:
@@ -220,10 +228,12 @@ class OptimizerTTS:
                 time2str(epochs_durs[-1]), time2str(med * self.cfg.train_max_nbepochs),
                 time2str(med * (self.cfg.train_max_nbepochs - epoch))))
 
-            self.saveTrainingState(stem + '-trainingstate-last.h5', printfn=print_log, extras={
-                'cost_val': cost_val, 'best_val': best_val, 'costs': costs, 'epochs_modelssaved': epochs_modelssaved,
-                'epochs_durs': epochs_durs, 'nbnodecepochs': nbnodecepochs, 'generator_updates': generator_updates,
-                'epoch': epoch})
+            if main:
+                self.saveTrainingState(stem + '-trainingstate-last.h5', printfn=print_log, extras={
+                    'cost_val': cost_val, 'best_val': best_val, 'costs': costs, 'epochs_modelssaved': epochs_modelssaved,
+                    'epochs_durs': epochs_durs, 'nbnodecepochs': nbnodecepochs,
+                    'generator_updates': getattr(self, 'generator_updates', generator_updates), 'epoch': epoch})
+            parallel.barrier()                          # nobody runs ahead (or resumes) before the files are complete
 
             if nbnodecepochs >= self.cfg.train_cancel_nodecepochs:
                 print_log('WARNING: validation error did not decrease for {} epochs. Early stop!'.format(self.cfg.train_cancel_nodecepochs))
@@ -232,6 +242,10 @@ class OptimizerTTS:
         if best_val is None: raise ValueError('No model has been saved during training!')
         return {'epoch_stopped': epoch, 'worst_val': worst_val,
                 'best_epoch': epochs_modelssaved[-1] if len(epochs_modelssaved) > 0 else -1, 'best_val': best_val}
+
+    def _sync_moving_statistics(self):
+        if parallel.world_size() > 1:
+            parallel.average_buffers_([b for b in self._model.kerasmodel.buffers()])
 
     @classmethod
     def randomize_hyper(cls, cfg):
@@ -250,7 +264,9 @@ class OptimizerTTS:
     def train(self, indir, outdir, wdir, fid_lst_tra, fid_lst_val, params_savefile, cont=None):
         stem = os.path.splitext(params_savefile)[0]
         if self.cfg.train_nbtrials > 1:
-            self._model.save(stem + '-init.h5', printfn=print_log)
+            if parallel.is_main():
+                self._model.save(stem + '-init.h5', printfn=print_log)
+            parallel.barrier()
         try:
             trials = []
             for triali in range(1, 1 + self.cfg.train_nbtrials):
@@ -287,7 +303,8 @@ class OptimizerTTS:
                     line += [train_rets[k] for k in sorted(train_rets.keys())]
                     header = 'trials ' + ' '.join(f[0] for f in self.cfg.train_hypers) + ' ' + ' '.join(sorted(train_rets.keys()))
                     trials.append(line)
-                    np.savetxt(stem + '-trials.txt', np.vstack(trials), header=header)
+                    if parallel.is_main():
+                        np.savetxt(stem + '-trials.txt', np.vstack(trials), header=header)
         except KeyboardInterrupt:
             print_log('WARNING: Training interrupted by user!')
         print_log('Finished')

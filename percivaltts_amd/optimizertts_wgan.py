@@ -109,7 +109,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         cfg.train_wgan_stack_real_fake = True        # critic(real) and critic(fake) as one stacked 2B pass (exact: no BatchNorm)
         cfg.train_wgan_reuse_ctx_conv = True         # generator step reuses the critic step's G-context-Conv1D product (same batch)
         cfg.train_wgan_early_critic = True           # generator step: critic starts on the spectral branch, BLSTM joins for the LS term
-        cfg.train_wgan_split_bf16 = None             # context Conv1D forward + weight gradient as bf16x6 split products (fp32-level accuracy, ops._C1Split); None: PTTS_CONV1D_SPLIT
+        cfg.train_wgan_split_bf16 = None             # context Conv1D forward + weight gradient as bf16x6 split products (fp32 arithmetic on the bf16 matrix cores, ops._C1Split); None: the default (on; PTTS_CONV1D_SPLIT=0 turns it off), False: fp32 MFMA kernels
         return cfg
 
     # ---------------------------------------------------------------------------------------------------------

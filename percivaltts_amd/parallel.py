@@ -53,6 +53,30 @@ def broadcast_(flat, src=0):
     return flat
 
 
+def is_main():
+    """True on the rank that writes files (checkpoints, training state, logs): rank 0."""
+    return rank() == 0
+
+
+def average_buffers_(tensors):
+    """In-place mean over the ranks of a list of (small) tensors, as ONE flat all-reduce: the BatchNorm moving statistics,
+    which every rank accumulates from its own shard of the batches, before they are validated with and saved."""
+    w = world_size()
+    tensors = [t for t in tensors if t is not None and t.numel() > 0]
+    if w <= 1 or not tensors:
+        return tensors
+    flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in tensors])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.mul_(1.0 / w)
+    off = 0
+    with torch.no_grad():
+        for t in tensors:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view(t.shape))
+            off += n
+    return tensors
+
+
 def shard_batch(n_items, world=None, r=None):
     """Contiguous shard [lo, hi) of a global batch for this rank; the global batch must divide evenly."""
     world = world_size() if world is None else world

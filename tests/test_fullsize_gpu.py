@@ -74,7 +74,8 @@ def test_conv2d_full_size_against_oracle_crops_and_linearity():
     # the backward of the same layer: dx against the oracle on a crop, dw against a chunked fp64 reduction of crops
     x1r = x1.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
     dy = torch.randn(B, T, SPEC, 4, generator=g).cuda()
-    ops.conv2d(ops.Lazy(x1r, lrelu=True), wr, b).backward(dy)
+    br_ = b.clone().requires_grad_(True)
+    ops.conv2d(ops.Lazy(x1r, lrelu=True), wr, br_).backward(dy)
     bi, t0, n = 31, 203, 12
     lo, hi = t0 - 4, t0 + n + 4
     xc = x1[bi:bi + 1, lo:hi].double().cpu().requires_grad_(True)
@@ -83,6 +84,16 @@ def test_conv2d_full_size_against_oracle_crops_and_linearity():
     dyc = torch.zeros_like(yc); dyc[:, 2:-2] = dy[bi:bi + 1, lo + 2:hi - 2].double().cpu()
     yc.backward(dyc)
     close(x1r.grad[bi:bi + 1, t0:t0 + n], xc.grad[:, 4:4 + n], 2e-4, 2e-5, 'conv2d dx crop')
+    # dw / db over ALL 1.66 M pixels (the per-workgroup partial sums of 64 x 22 workgroups and their reduction): an fp64
+    # reduction over batch chunks of the oracle's own backward
+    dw64 = torch.zeros(5, 5, 4, 4, dtype=torch.float64); db64 = torch.zeros(4, dtype=torch.float64)
+    for b0 in range(0, B, 8):
+        wq = w.double().cpu().requires_grad_(True); bq = b.double().cpu().requires_grad_(True)
+        O.conv2d_nhwc(O.lrelu(x1[b0:b0 + 8].double().cpu()), wq, bq).backward(dy[b0:b0 + 8].double().cpu())
+        dw64 += wq.grad; db64 += bq.grad
+    scale = float(dw64.abs().mean())
+    assert float((wr.grad.double().cpu() - dw64).abs().max()) < 1e-4 * scale, (float((wr.grad.double().cpu() - dw64).abs().max()), scale)
+    close(br_.grad, db64, 2e-4, 1e-4 * float(db64.abs().mean()), 'conv2d db, full size')
 
 
 def test_gemm_full_size_rows_and_linearity():
@@ -281,8 +292,8 @@ def test_train_step_with_the_bf16x6_context_conv_matches_the_fp32_one(setup):
             results.append((float(lc), float(lg), opt.critic_opti.flat.grad.detach().clone(),
                             opt.gen_opti.flat.grad.detach().clone(), names.count('ptts_conv1d_bf16x6')))
     finally:
-        opt.cfg.train_wgan_split_bf16 = False
-        ops.conv1d_split(False)
+        opt.cfg.train_wgan_split_bf16 = None
+        ops.conv1d_split(None)
         for dst, src in zip(state, snap):
             dst.copy_(src)
         for dst, src in zip(moving, moving0):

@@ -172,6 +172,41 @@ def test_critic_and_generator_steps(geom, errtype):
             close(t, w, 5e-4, 1e-5, k)
 
 
+@pytest.mark.parametrize('geom', ['default', 'test'])
+@pytest.mark.parametrize('T', [1, 37, 601])
+def test_evaluation_mode_losses_whole_utterances(geom, T):
+    """update_validation_cost (optimizertts_wgan.py:244-268): `generator_model.evaluate` and `critic_model.evaluate` run with
+    learning phase 0 -- BatchNorm on its moving statistics, also inside the frozen generator of the critic loss, the
+    gradient penalty still evaluated -- at batch size 1 on whole utterances (T ~ 600, no multiple of any tile; T = 1 is the
+    degenerate utterance).  Both losses and their parts against the oracle."""
+    from percivaltts_amd import optimizertts_wgan
+    cfg, voc, mod, crit, a, gw, cw, X, Y, al = build(geom)
+    cfg.train_wgan_critic_LSWGANtransidx = 30.0
+    opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype='WLSWGAN', critic=crit)
+    opt.prepare()
+    gen = torch.Generator().manual_seed(100 + T)
+    g = GEOMS[geom]
+    X1 = torch.rand(1, T, g['ctx'], generator=gen, dtype=torch.float64) * 2 - 1
+    Y1 = torch.randn(1, T, a.outsize, generator=gen, dtype=torch.float64)
+    al1 = torch.rand(1, generator=gen, dtype=torch.float64)
+    total, parts = O.critic_step_loss(cw, gw, a, X1, Y1, al1, gp_lambda=10.0, training=False)
+    tot_d, (lv, lf, gp) = opt.critic_loss(f32(X1), f32(Y1), f32(al1), training=False)
+    close(lv, parts['valid'], 5e-4, 1e-5, 'L valid (eval)')
+    close(lf, parts['fake'], 5e-4, 1e-5, 'L fake (eval)')
+    close(gp, parts['gp'], 5e-4, 1e-5, 'gradient penalty (eval)')
+    close(tot_d, total, 5e-4, 1e-5, 'critic loss (eval)')
+    w_ls, ww = O.wls_weights(a.specsize, a.noisesize, 0, 0.25, 30.0)
+    ltot, lparts = O.generator_step_loss(cw, gw, a, X1, Y1, 'WLSWGAN', torch.tensor(w_ls), ww, training=False)
+    with torch.no_grad():
+        ltot_d, (lw_d, lls_d) = opt.generator_loss(f32(X1), f32(Y1), training=False)
+    close(lw_d, lparts['wgan'], 5e-4, 1e-5, 'generator wgan term (eval)')
+    close(lls_d, lparts['ls'], 5e-4, 1e-5, 'generator ls term (eval)')
+    close(ltot_d, ltot, 5e-4, 1e-5, 'generator loss (eval)')
+    # evaluation must not move the moving statistics
+    for (k, t), w in zip(mod.kerasmodel.weights(), gw):
+        close(t, w, 1e-6, 1e-7, 'weights untouched ' + k)
+
+
 def test_generic_model_count_params_and_lse_step():
     """Generic 3xFC, the reference's known answer 2195 (tests/test_smoke_tensorflowkeras.py:53), then one LSE step."""
     import percivaltts_amd

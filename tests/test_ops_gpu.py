@@ -323,6 +323,61 @@ def test_conv1d(ops, case):
     close(bd.grad, br.grad, rtol=2e-4, atol=3e-4, what='db')
 
 
+@pytest.mark.parametrize('case', [
+    # B, T, Cin, N, KW, bias, nonzero dW in the buffer beforehand
+    (8, 520, 150, 96, 3, True), (8, 520, 150, 96, 5, False), (8, 520, 150, 96, 21, True),
+    (5, 830, 70, 32, 21, True),           # one 32-output tile, ragged 64-channel tile, qsteps not divisible by the split
+    (11, 400, 601, 256, 21, True),        # the context Conv1D of BASELINE configs[1]: 10 channel tiles, 8 output tiles
+])
+def test_conv1d_weight_gradient_frame_major(ops, case):
+    """The default weight-gradient path of the context Conv1D for B*T >= 4096 (csrc/conv1d_wgrad.hip: ptts_transpose_frames +
+    ptts_conv1d_wgrad_t, exact fp32 over frame-major operands) against the fp64 oracle on the FULL dW and db; ragged channel
+    counts (c0 > 0 tiles with a partial last tile), all three KW instantiations, with and without a bias, and an A/B run
+    of the stream-K product it replaced (PTTS_WGRAD_T=0).  The kernel is asserted to have run."""
+    B, T, Cin, N, KW, has_b = case
+    assert B * T >= 4096
+    g = gen(41)
+    x = torch.randn(B, T, Cin, generator=g, dtype=torch.float64).float()
+    w = (torch.randn(KW, Cin, N, generator=g, dtype=torch.float64) * (1.0 / (KW * Cin) ** 0.5)).float()
+    b = torch.randn(N, generator=g, dtype=torch.float64).float() if has_b else None
+    dy = torch.randn(B, T, N, generator=g, dtype=torch.float64).float()
+    wr = w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if has_b else None
+    O.conv1d_ntc(x.double(), wr, br).backward(dy.double())
+
+    def run(enabled):
+        old = ops._C1WgradT.enabled
+        ops._C1WgradT.enabled = enabled
+        ops._C1WgradT.clear()
+        try:
+            wd = w.cuda().requires_grad_(True)
+            bd = b.cuda().requires_grad_(True) if has_b else None
+            with ops._hip.KernelTimer() as kt:
+                ops.conv1d(x.cuda(), wd, bd).backward(dy.cuda())
+            return wd.grad.cpu().double(), (bd.grad.cpu().double() if has_b else None), [r[0] for r in kt.records]
+        finally:
+            ops._C1WgradT.enabled = old
+            ops._C1WgradT.clear()
+
+    ops.conv1d_split(False)
+    try:
+        dw_t, db_t, names_t = run(True)
+        dw_k, db_k, names_k = run(False)
+    finally:
+        ops.conv1d_split(None)
+    assert 'ptts_conv1d_wgrad_t' in names_t and 'ptts_transpose_frames' in names_t, names_t
+    assert 'ptts_conv1d_wgrad_t' not in names_k
+    gs = wr.grad.abs().mean()
+    e_t = ((dw_t - wr.grad).abs().max() / gs).item()
+    e_k = ((dw_k - wr.grad).abs().max() / gs).item()
+    # tolerance: fp32 accumulation over B*T <= 4400 frames, the same bound as the stream-K product
+    assert e_t < 3e-5, (e_t, e_k)
+    assert e_t < 4 * max(e_k, 2e-6), (e_t, e_k)
+    if has_b:
+        close(db_t, br.grad, rtol=2e-4, atol=3e-4, what='db (frame-major kernel)')
+        close(db_k, br.grad, rtol=2e-4, atol=3e-4, what='db (stream-K product)')
+
+
 def test_split3_planes_are_exact(ops):
     """The three bf16 planes of the split pass add up to the fp32 operand EXACTLY (3 x 8 significant bits = 24), sit in
     the documented 32-channel-block layout, and are zero in the time padding and in the channels C..Cp-1."""
@@ -395,7 +450,7 @@ def test_conv1d_bf16x6_split_product(ops, case):
     try:
         y_split, dw_split, db_split, names = run()
     finally:
-        ops.conv1d_split(False)
+        ops.conv1d_split(None)          # back to the default (on)
     assert 'ptts_conv1d_bf16x6' in names, 'the split forward kernel did not run'
     assert ('ptts_conv1d_wgrad_bf16x6' in names) == (KW in (3, 5, 21)), names
     scale = yr.abs().mean()
