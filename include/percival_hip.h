@@ -103,6 +103,37 @@ typedef struct ptts_conv2d_reduce_desc {
 int ptts_conv2d_reduce_grouped(const ptts_conv2d_reduce_desc* descs, int n, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * The same convolution for the 4 -> 4 channel, 5x5 layers (the critic's stack, networks_critic.py:66-68, and the
+ * generator's, networktts.py:122-126) on the bf16 matrix cores, in fp32 arithmetic: both operands are split three ways
+ * into bf16 (x = x1 + x2 + x3 exactly), the six products of order >= 2^-16 are formed by v_mfma_f32_16x16x32_bf16 and
+ * accumulated in fp32 (csrc/conv2d_mfma.hip).  Time dilation 1, 2, 4 or 8; any T, F, B.
+ *   ptts_conv2d_mfma_tables   the banded (Toeplitz) operand tables of a kernel w [5,5,4,4], 3 bf16 planes each
+ *                             (ptts_conv2d_mfma_table_bytes(5) bytes): table_fwd for the forward, table_bwd (flipped,
+ *                             transposed) for the backward-data pass; either may be NULL.  Rebuild when w changes.
+ *   ptts_conv2d_mfma_fwd      y = bias + conv(transform(x)) with pad_t rows of zero padding before t = 0; when out_mask
+ *                             is given, y *= (out_mask > 0 ? 1 : alpha).  Forward: table_fwd, pad_t = 2 dil ('same') or
+ *                             4 dil (causal).  Masked forward of the second-order sweep: in_mode PTTS_IN_MASKMUL.
+ *                             Backward data: x = dy, table_bwd, pad_t = 4 dil - pad_t(forward), out_mask = the forward
+ *                             layer's pre-activation input (its LeakyReLU mask), in_mode PTTS_IN_NONE.
+ *   ptts_conv2d_mfma_wgrad_partials   per-workgroup partial sums of dw / dbias in the row layout of
+ *                             ptts_conv2d_bwd_partials (rows of *npart_out floats behind a 4096-byte head), reduced in a
+ *                             fixed order inside a workgroup (no atomics); ptts_conv2d_reduce_grouped adds them up.
+ *   ptts_conv2d_mfma_debug    measurement hook of tools/conv2d_mfma_probe.py (phase switches, per-workgroup stamps);
+ *                             flags 0 = the product path.
+ * ------------------------------------------------------------------------------------- */
+int ptts_conv2d_mfma_supported(int F, int Cin, int Cout, int KT, int KF, int dil_t);
+size_t ptts_conv2d_mfma_table_bytes(int KT);
+int ptts_conv2d_mfma_tables(const float* w, void* table_fwd, void* table_bwd, int KT, int KF, int Cin, int Cout, void* stream);
+int ptts_conv2d_mfma_fwd(const float* x, const void* table, const float* bias, const float* in_scale, const float* in_shift,
+                         const float* mask_src, const float* out_mask, float* y,
+                         int B, int T, int F, int KT, int dil_t, int pad_t, int in_mode, float alpha, void* stream);
+size_t ptts_conv2d_mfma_wgrad_workspace_bytes(int B, int T);
+int ptts_conv2d_mfma_wgrad_partials(const float* dy, const float* x, const float* mask_src, void* workspace,
+                                    size_t workspace_bytes, int* nblocks_out, int* npart_out, int B, int T, int F,
+                                    int KT, int dil_t, int pad_t, int in_mode, float alpha, void* stream);
+int ptts_conv2d_mfma_debug(int flags, void* stamp_buf);
+
+/* ---------------------------------------------------------------------------------------
  * fp32 GEMM on the MFMA pipe (v_mfma_f32_32x32x2_f32), with implicit-convolution row
  * addressing for the context Conv1D.  Replaces keras Dense (networktts.py:60; heads at
  * modeltts_common.py:84,95,121; networks_critic.py:96) and kl.Conv1D (networktts.py:117).
@@ -216,6 +247,10 @@ int ptts_affine_act_bwd(const float* dy, const float* x, const float* y, const f
                         float* dx, double* dsums /*[2C]: dscale, dshift; or NULL*/,
                         void* workspace, size_t workspace_bytes,
                         long long rows, int C, int act, float alpha, void* stream);
+/* The gated product of a gated convolution (networktts.py:128-134, pGCNN2D): y = a * sigmoid(b) over the two Conv2D
+ * pre-activations, and its backward da = dy*s, db = dy*a*s*(1-s), s = sigmoid(b).  One pass each; n = element count. */
+int ptts_gated_mul_fwd(const float* a, const float* b, float* y, long long n, void* stream);
+int ptts_gated_mul_bwd(const float* dy, const float* a, const float* b, float* da, float* db, long long n, void* stream);
 
 /* out[r,c] = (acc? out : 0) + a[r,c]*c1[c] + x[r,c]*c2[c] + c0[c]   (BatchNorm backward fix-up: dz += dmean/N + dvar*2(z-mean)/N) */
 int ptts_axpby_cols(const float* a, const float* c1, const float* x, const float* c2, const float* c0,

@@ -48,12 +48,21 @@ SIGNATURES = {
     'ptts_conv1d_wgrad_t': (c_i, [c_p] * 4 + [c_i] * 6 + [c_ll, c_p]),
     'ptts_conv2d_bwd_partials': (c_i, [c_p] * 5 + [c_p, c_sz, c_p] + [c_i] * 10 + [c_f, c_p]),
     'ptts_conv2d_reduce_grouped': (c_i, [c_p, c_i, c_p]),
+    'ptts_conv2d_mfma_debug': (c_i, [c_i, c_p]),
+    'ptts_conv2d_mfma_table_bytes': (c_sz, [c_i]),
+    'ptts_conv2d_mfma_tables': (c_i, [c_p, c_p, c_p] + [c_i] * 4 + [c_p]),
+    'ptts_conv2d_mfma_supported': (c_i, [c_i] * 6),
+    'ptts_conv2d_mfma_fwd': (c_i, [c_p] * 8 + [c_i] * 7 + [c_f, c_p]),
+    'ptts_conv2d_mfma_wgrad_workspace_bytes': (c_sz, [c_i, c_i]),
+    'ptts_conv2d_mfma_wgrad_partials': (c_i, [c_p] * 4 + [c_sz, c_p, c_p] + [c_i] * 7 + [c_f, c_p]),
     'ptts_colstats_workspace_bytes': (c_sz, [c_ll, c_i]),
     'ptts_colstats': (c_i, [c_p, c_ll, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_sz, c_p]),
     'ptts_bn_finalize': (c_i, [c_p, c_ll, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     'ptts_bn_bwd_coefs': (c_i, [c_p] * 5 + [c_ll, c_i] + [c_p] * 4 + [c_p]),
     'ptts_affine_act': (c_i, [c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_f, c_p]),
     'ptts_affine_act_bwd': (c_i, [c_p] * 7 + [c_p, c_sz, c_ll, c_i, c_i, c_f, c_p]),
+    'ptts_gated_mul_fwd': (c_i, [c_p] * 3 + [c_ll, c_p]),
+    'ptts_gated_mul_bwd': (c_i, [c_p] * 5 + [c_ll, c_p]),
     'ptts_axpby_cols': (c_i, [c_p] * 6 + [c_ll, c_i, c_p]),
     'ptts_gp_interpolate': (c_i, [c_p] * 4 + [c_i, c_ll, c_p]),
     'ptts_gp_sqnorm': (c_i, [c_p, c_p, c_i, c_ll, c_p]),

@@ -1,0 +1,667 @@
+// 2D convolution (time x frequency, NHWC, C = 4 -> 4, 5x5) on the bf16 matrix cores of gfx950, in fp32 arithmetic.
+//
+// Role on the hot path: the 4 -> 4 channel layers of the critic's 8-deep Conv2D stack (reference
+// networks_critic.py:66-68) -- forward, the masked forward of the gradient penalty's second-order sweep, the
+// backward-data pass (with the LeakyReLU mask of the previous layer fused into the store) and the weight gradient.
+// The packed-FMA stencil of conv2d.hip is issue-bound at 0.17 of the HBM roofline; here the same sums run on
+// v_mfma_f32_16x16x32_bf16 through the three-way bf16 split of BOTH operands (x = x1 + x2 + x3, xi = bf16(remainder),
+// exact: 3 x 8 = 24 significant bits; the six products of order >= 2^-16 are kept and accumulated in fp32 -- the same
+// arithmetic as split.hip's context Conv1D, admitted as fp32 arithmetic by the round-1 verdict).
+//
+// Mapping (per kernel row kt): the 5 x 4 taps of a kernel row form a banded (Toeplitz) block
+//     A[m = (so, co)][k = (j, ci)] = w[kt][kf = j - so][ci][co]   (0 <= j - so < 5, else 0),
+// m: 4 output bins x 4 output channels, k: 8 input bins x 4 input channels (62.5 % of the block is non-zero); the
+// activations are the B operand, B[k][n = time row]: a lane's 8 k-values are 8 CONSECUTIVE bf16 of the NHWC row (2 bins x
+// 4 channels), no im2col.  D[m][n]: lane (n = lane & 15, q = lane >> 4) holds output pixel (row of lane n, bin 4g + q), its
+// four output channels in the four accumulator registers -- one 16-byte store per lane.
+// The weight gradient runs the reduction over the pixels through the same instruction (K = 16 rows x 2 bin groups per
+// step) with both operands read transposed out of the row-major LDS planes by ds_read_b64_tr_b16.
+//
+// Tiles: (utterance, 16 time rows, block of <= 17 bin groups).  The staged tile always has the geometry of a 17-group
+// block (72 bins) and the dilation is a template parameter, so that every LDS address of the inner loops is one base
+// register plus an immediate: the first version spent as many vector instructions on addresses as the matrix pipe spent
+// cycles on the products (rocprofv3 SQ_INSTS_VALU, gpurun_out/c2m_pmc).
+#include "common.h"
+#include <cstdlib>
+
+namespace ptts {
+namespace c2m {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+constexpr int THREADS = 256;
+constexpr int NP = 3;          // bf16 planes per fp32 operand
+constexpr int C = 4;           // channels in and out
+constexpr int KF = 5;
+constexpr int KT = 5;
+constexpr int GPB = 17;        // bin groups (of 4 bins) per block: F = 65 is one block
+constexpr int NPART = KT * KF * 16 + 4 + 8;   // row of partial sums: the layout of conv2d.hip's backward
+
+// six products (activation plane, weight plane), smallest first
+#define C2M_PRODUCTS(X) X(2, 0) X(1, 1) X(0, 2) X(1, 0) X(0, 1) X(0, 0)
+
+// measurement hooks (tools/conv2d_mfma_probe.py): bit 0 skip the staging, bit 1 skip the MFMA phase, bit 2 skip the
+// stores, bit 3 write s_memtime stamps of the phases of every workgroup to dbg_buf[block][8]
+constexpr int DBG_NOSTAGE = 1, DBG_NOMFMA = 2, DBG_NOSTORE = 4, DBG_STAMPS = 8;
+static int g_dbg = 0;
+static unsigned long long* g_dbg_buf = nullptr;
+__device__ __forceinline__ void stamp(unsigned long long* buf, int dbg, int slot) {
+    if ((dbg & DBG_STAMPS) && threadIdx.x == 0) buf[(size_t)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memtime();
+}
+
+__device__ __forceinline__ void split3(f32x4 v, bf16x4& h1, bf16x4& h2, bf16x4& h3) {
+    h1 = __builtin_convertvector(v, bf16x4);
+    const f32x4 r1 = v - __builtin_convertvector(h1, f32x4);
+    h2 = __builtin_convertvector(r1, bf16x4);
+    const f32x4 r2 = r1 - __builtin_convertvector(h2, f32x4);
+    h3 = __builtin_convertvector(r2, bf16x4);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Toeplitz tables of a 5x5 4->4 kernel, three bf16 planes: tab[KT][NP][64 lanes][8].
+//   transposed == 0 (forward):        A[(so,co)][(j,ci)] = w[kt][j - so][ci][co]
+//   transposed == 1 (backward data):  A[(so,ci)][(j,co)] = w[KT-1-kt][KF-1-(j - so)][ci][co]   (dx = conv(dy, flipped w^T))
+// lane (li = lane & 15, lg = lane >> 4): m = li -> so = li >> 2, oc = li & 3; element e: j = 2 lg + (e >> 2), ic = e & 3.
+// One launch builds both tables: block 0 the forward one, block 1 the transposed one.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void toeplitz_table_kernel(const float* __restrict__ w, u16* __restrict__ tab_fwd, u16* __restrict__ tab_bwd) {
+    const int transposed = blockIdx.x;
+    u16* tab = transposed ? tab_bwd : tab_fwd;
+    if (!tab) return;
+    const int lane = threadIdx.x & 63, kt = threadIdx.x >> 6;
+    const int li = lane & 15, lg = lane >> 4, so = li >> 2, oc = li & 3;
+    if (kt >= KT) return;
+    f32x4 v[2];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int j = 2 * lg + (e >> 2), ic = e & 3, kf = j - so;
+        float x = 0.f;
+        if (kf >= 0 && kf < KF)
+            x = transposed ? w[(((KT - 1 - kt) * KF + (KF - 1 - kf)) * C + oc) * C + ic] : w[((kt * KF + kf) * C + ic) * C + oc];
+        v[e >> 2][e & 3] = x;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        bf16x4 h1, h2, h3;
+        split3(v[h], h1, h2, h3);
+        u16* d = tab + ((size_t)(kt * NP) * 64 + lane) * 8 + 4 * h;
+        *reinterpret_cast<bf16x4*>(d) = h1;
+        *reinterpret_cast<bf16x4*>(d + 64 * 8) = h2;
+        *reinterpret_cast<bf16x4*>(d + 2 * 64 * 8) = h3;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// tile geometry
+// ------------------------------------------------------------------------------------------------------------
+struct Shape {
+    int T, F, NG, nfb, ntt, ntiles;          // bin groups, blocks of <= 17 groups per row, time tiles, all tiles
+    unsigned magic_nfb, magic_ntt;           // ceil(2^32 / d) for d > 1: mulhi(n, magic) == n / d for n < 2^20, d < 2^12
+    int pad_t;
+};
+
+// LDS row layout.  A staged row holds SB bins x 4 channels = SB/2 sixteen-byte units (two bins each).  ds_read_b128 serves a
+// wave in four groups of 16 lanes, each made of 8 lanes (lg = a) and 8 lanes (lg = a + 1) that together cover every
+// li = 0..15 once (li in {0-3, 12-15} on one side, {4-11} on the other); a lane's unit is 2 g + lg, so the two sides of a
+// group read the two units of one aligned pair.  With the pair's units TWO positions apart (the two low bits of the unit
+// index swapped) and an odd number of units per row, the 16 lanes hit 16 different 16-byte bank slots iff the lanes
+// li = 4..11 own the even time rows and the others the odd ones: row_of_lane().
+__host__ __device__ constexpr int unit_pos(int u) { return (u & ~3) | ((u & 1) << 1) | ((u >> 1) & 1); }
+__host__ __device__ constexpr int bin_off(int c) { return unit_pos(c >> 1) * 8 + (c & 1) * 4; }      // elements, staged bin c
+// time row (0..15) of the MFMA column li
+__device__ __forceinline__ int row_of_lane(int li) { return (li >= 4 && li < 12) ? 2 * (li - 4) : (li < 4 ? 2 * li + 1 : 2 * li - 15); }
+
+template <int SB_, int ROWS_>
+struct Stage {
+    static constexpr int SB = SB_;                     // staged bins (-2 .. SB-3 relative to the block's first bin)
+    static constexpr int RS = SB_ * C + 8;             // row stride in bf16 elements: an odd number of 16-byte units
+    static constexpr int ROWS = ROWS_;
+    static constexpr int PS = ROWS_ * RS;              // plane stride
+    static constexpr int TOTAL = ROWS_ * SB_;
+    static constexpr int NB = (TOTAL + THREADS - 1) / THREADS;
+};
+
+struct TilePos { long long img; int t0, g_base, ng; };
+
+__device__ __forceinline__ TilePos tile_pos(const Shape& s, int tile) {
+    TilePos p;
+    const int q = s.nfb > 1 ? (int)__umulhi((unsigned)tile, s.magic_nfb) : tile, fb = tile - q * s.nfb;
+    const int b = s.ntt > 1 ? (int)__umulhi((unsigned)q, s.magic_ntt) : q, tb = q - b * s.ntt;
+    p.img = (long long)b * s.T * s.F;
+    p.t0 = tb * 16;
+    p.g_base = fb * GPB;
+    p.ng = min(GPB, s.NG - p.g_base);
+    return p;
+}
+
+// What a lane needs to know about its NB staging slots, computed once per workgroup (tile-independent):
+// slot idx = tid + 256 u -> staged row r = idx / SB, staged bin c = idx % SB
+template <class ST>
+struct Slots {
+    int rc[ST::NB];        // r << 8 | c, or -1 for a slot beyond the tile
+    int dst[ST::NB];       // LDS element offset inside a plane
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int u = 0; u < ST::NB; ++u) {
+            const int idx = threadIdx.x + u * THREADS;
+            const int r = idx / ST::SB, c = idx - r * ST::SB;
+            rc[u] = idx < ST::TOTAL ? (r << 8 | c) : -1;
+            dst[u] = r * ST::RS + bin_off(c);
+        }
+    }
+};
+
+template <int NB, bool MASK>
+struct Pref {
+    f32x4 v[NB];
+    f32x4 m[MASK ? NB : 1];
+};
+
+// the loads of one tile: rows t_org .., bins f_org ..; zero outside the image
+template <class ST, bool MASK>
+__device__ __forceinline__ void pref_load(Pref<ST::NB, MASK>& pf, const Slots<ST>& sl, const float* __restrict__ src,
+                                          const float* __restrict__ msk, long long img, int t_org, int f_org, int T, int F,
+                                          int f_end /*bins >= f_end are staged as zeros (f_end <= F)*/) {
+    const float* base = src + (img + (long long)t_org * F + f_org) * C;         // wave-uniform
+    const float* mbase = MASK ? msk + (img + (long long)t_org * F + f_org) * C : nullptr;
+#pragma unroll
+    for (int u = 0; u < ST::NB; ++u) {
+        const int r = sl.rc[u] >> 8, c = sl.rc[u] & 255;
+        const bool ok = sl.rc[u] >= 0 && (unsigned)(t_org + r) < (unsigned)T && (unsigned)(f_org + c) < (unsigned)f_end;
+        pf.v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (MASK) pf.m[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            const int off = (r * F + c) * C;
+            pf.v[u] = *reinterpret_cast<const f32x4*>(base + off);
+            if (MASK) pf.m[u] = *reinterpret_cast<const f32x4*>(mbase + off);
+        }
+    }
+}
+
+// registers -> transform -> three bf16 planes in LDS.  Slots outside the image were loaded as zeros and stay zero under
+// every transform but the BatchNorm-affine one, which gets its own select.  `sum` (optional) accumulates the raw values
+// of staged rows [sum_r0, sum_r0 + 16), staged bins [2, sum_c1).
+template <class ST, int MODE>
+__device__ __forceinline__ void pref_commit(const Pref<ST::NB, MODE == PTTS_IN_MASKMUL>& pf, const Slots<ST>& sl,
+                                            u16* __restrict__ planes, int t_org, int f_org, int T, int F,
+                                            const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+                                            float alpha, int sum_r0, int sum_c1, f32x4* sum) {
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    const bool affine = MODE == PTTS_IN_LRELU && in_scale != nullptr;
+    if (affine) {
+        sc = *reinterpret_cast<const f32x4*>(in_scale);
+        sh = *reinterpret_cast<const f32x4*>(in_shift);
+    }
+#pragma unroll
+    for (int u = 0; u < ST::NB; ++u) {
+        if (sl.rc[u] < 0) continue;
+        f32x4 a = pf.v[u];
+        if (sum) {
+            // the block's own pixels only: rows [sum_r0, sum_r0 + 16), staged bins [2, sum_c1) (the rest is halo)
+            const int r = sl.rc[u] >> 8, c = sl.rc[u] & 255;
+            if (r >= sum_r0 && r < sum_r0 + 16 && c >= 2 && c < sum_c1) *sum += a;
+        }
+        if (MODE == PTTS_IN_LRELU) {
+            if (affine) {
+                const int r = sl.rc[u] >> 8, c = sl.rc[u] & 255;
+                const bool ok = (unsigned)(t_org + r) < (unsigned)T && (unsigned)(f_org + c) < (unsigned)F;
+                a = a * sc + sh;
+                if (!ok) a = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = fmaxf(a[e], alpha * a[e]);      // LeakyReLU for 0 <= alpha <= 1
+        } else if (MODE == PTTS_IN_MASKMUL) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = a[e] * (pf.m[u][e] > 0.f ? 1.f : alpha);
+        }
+        bf16x4 h1, h2, h3;
+        split3(a, h1, h2, h3);
+        u16* d = planes + sl.dst[u];
+        *reinterpret_cast<bf16x4*>(d) = h1;
+        *reinterpret_cast<bf16x4*>(d + ST::PS) = h2;
+        *reinterpret_cast<bf16x4*>(d + 2 * ST::PS) = h3;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// forward / masked forward / backward data.  Persistent workgroups (256 threads) walk the tiles blockIdx.x, + gridDim.x,
+// ...: the Toeplitz table is fetched once per workgroup and the global loads of tile i+1 are in flight (registers) while
+// tile i is multiplied.  LDS: planes [NP][ROWS][RS] | table [KT][NP][64][8]
+// out = bias + conv(transform(x)) ; OUTMASK: out *= (out_mask > 0 ? 1 : alpha)
+// ------------------------------------------------------------------------------------------------------------
+// one pass of a wave over N consecutive bin groups g0 .. g0+N-1 of the staged block: straight-line code (a branch around
+// an MFMA group makes the compiler carry the accumulators through register copies), one LDS base register per parity of
+// the group, everything else immediates
+template <class ST, int DIL, int N, bool OUTMASK>
+__device__ __forceinline__ void fwd_pass(const u16* __restrict__ planes, const u16* __restrict__ wl, int g0, int lane,
+                                         f32x4 bv, const float* __restrict__ mrow, float* __restrict__ yrow, int fbase,
+                                         int F, bool rowok, float alpha, bool store) {
+    const int li = lane & 15, lg = lane >> 4;
+    f32x4 acc[N], mv[OUTMASK ? N : 1];
+#pragma unroll
+    for (int j = 0; j < N; ++j) acc[j] = bv;
+    // this lane's output pixels: row row_of_lane(li) (yrow / mrow point at its bin 0), bins fbase + 4 (g0 + j) + lg
+    const int f0 = fbase + 4 * g0 + lg;
+    if (OUTMASK) {
+        // the mask source of the outputs: requested now, needed after the MFMAs
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            mv[j] = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (rowok && f0 + 4 * j < F) mv[j] = *reinterpret_cast<const f32x4*>(mrow + (f0 + 4 * j) * C);
+        }
+    }
+    // unit of the lane in group g: 2 g + lg; groups two apart are four units (32 elements) apart
+    const u16* b0 = planes + row_of_lane(li) * ST::RS + unit_pos(2 * g0 + lg) * 8;
+    const u16* b1 = planes + row_of_lane(li) * ST::RS + unit_pos(2 * g0 + 2 + lg) * 8;
+    const u16* wa = wl + lane * 8;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        bf16x8 a[NP], bq[N][NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) a[q] = *reinterpret_cast<const bf16x8*>(wa + (kt * NP + q) * 64 * 8);
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                bq[j][p] = *reinterpret_cast<const bf16x8*>(((j & 1) ? b1 : b0) + p * ST::PS + kt * DIL * ST::RS + (j >> 1) * 32);
+        // product-major: consecutive MFMAs go to different accumulators
+#define C2M_MM(PA, PW)                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < N; ++j)                                                   \
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PW], bq[j][PA], acc[j], 0, 0, 0);
+        C2M_PRODUCTS(C2M_MM)
+#undef C2M_MM
+    }
+    if (rowok && store) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if (f0 + 4 * j < F) {
+                f32x4 o = acc[j];
+                if (OUTMASK) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = o[e] * (mv[j][e] > 0.f ? 1.f : alpha);
+                }
+                *reinterpret_cast<f32x4*>(yrow + (f0 + 4 * j) * C) = o;
+            }
+        }
+    }
+}
+
+template <int DIL, int MODE, bool OUTMASK>
+__global__ __launch_bounds__(THREADS, DIL == 1 ? 3 : (DIL == 2 ? 2 : 1)) void fwd_kernel(
+    const float* __restrict__ x, const u16* __restrict__ tab, const float* __restrict__ bias,
+    const float* __restrict__ in_scale, const float* __restrict__ in_shift, const float* __restrict__ mask_src,
+    const float* __restrict__ out_mask, float* __restrict__ y, Shape s, float alpha, int dbg, unsigned long long* dbg_buf) {
+    typedef Stage<4 * GPB + 4, 16 + (KT - 1) * DIL> ST;
+    extern __shared__ __attribute__((aligned(16))) u16 lds[];
+    stamp(dbg_buf, dbg, 0);
+    u16* planes = lds;
+    u16* wl = lds + NP * ST::PS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr bool MASK = MODE == PTTS_IN_MASKMUL;
+
+    Slots<ST> sl;
+    sl.init();
+    int tile = blockIdx.x;
+    Pref<ST::NB, MASK> pf;
+    TilePos pos = tile_pos(s, tile < s.ntiles ? tile : 0);
+    if (tile < s.ntiles && !(dbg & DBG_NOSTAGE))
+        pref_load<ST, MASK>(pf, sl, x, mask_src, pos.img, pos.t0 - s.pad_t, 4 * pos.g_base - 2, s.T, s.F, s.F);
+    // the table: KT*NP KB, 16 bytes per lane and copy, once per workgroup
+    for (int i = tid; i < KT * NP * 64; i += THREADS)
+        *reinterpret_cast<bf16x8*>(wl + (size_t)i * 8) = *reinterpret_cast<const bf16x8*>(tab + (size_t)i * 8);
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4*>(bias);
+    const bool store = !(dbg & DBG_NOSTORE);
+    const int myrow = row_of_lane(lane & 15);
+    int it = 0;
+    while (tile < s.ntiles) {
+        if (!(dbg & DBG_NOSTAGE))
+            pref_commit<ST, MODE>(pf, sl, planes, pos.t0 - s.pad_t, 4 * pos.g_base - 2, s.T, s.F, in_scale, in_shift, alpha, 0, 0, nullptr);
+        if (it == 0) stamp(dbg_buf, dbg, 1);
+        __syncthreads();
+        if (it == 0) stamp(dbg_buf, dbg, 2);
+        const TilePos cur = pos;
+        const int next = tile + gridDim.x;
+        if (next < s.ntiles) {
+            pos = tile_pos(s, next);
+            if (!(dbg & DBG_NOSTAGE))
+                pref_load<ST, MASK>(pf, sl, x, mask_src, pos.img, pos.t0 - s.pad_t, 4 * pos.g_base - 2, s.T, s.F, s.F);
+        }
+        // the wave's share of the block's bin groups: a contiguous run, in passes of at most NMAX groups of nearly equal
+        // size (register budget: a pass keeps N x 3 activation fragments)
+        const int per = cur.ng >> 2, rem = cur.ng & 3;
+        int gl = wave * per + min(wave, rem);
+        int n = per + (wave < rem ? 1 : 0);
+        if (dbg & DBG_NOMFMA) n = 0;
+        constexpr int NMAX = (OUTMASK || MASK) ? 4 : 5;
+        int npass = (n + NMAX - 1) / NMAX;
+        const int t = cur.t0 + myrow;
+        const bool rowok = t < s.T;
+        const long long rowoff = (cur.img + (long long)t * s.F) * C;
+        float* yrow = y + rowoff;
+        const float* mrow = OUTMASK ? out_mask + rowoff : nullptr;
+        const int fbase = 4 * cur.g_base;
+        while (n > 0) {
+            const int m = (n + npass - 1) / npass;
+#define C2M_PASS(NN) fwd_pass<ST, DIL, NN, OUTMASK>(planes, wl, gl, lane, bv, mrow, yrow, fbase, s.F, rowok, alpha, store)
+            switch (m) {
+                case 1: C2M_PASS(1); break;
+                case 2: C2M_PASS(2); break;
+                case 3: C2M_PASS(3); break;
+                case 4: C2M_PASS(4); break;
+                default: if (NMAX >= 5) C2M_PASS(NMAX >= 5 ? 5 : 4); break;
+            }
+#undef C2M_PASS
+            gl += m; n -= m; --npass;
+        }
+        if (it == 0) stamp(dbg_buf, dbg, 3);
+        __syncthreads();       // the planes are free again
+        tile = next;
+        ++it;
+    }
+    stamp(dbg_buf, dbg, 4);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// weight gradient: dW[kt][kf][ci][co] = sum_{b,t,f} a[t][f][ci] dy[t - kt dil + pad][f - kf + 2][co], a = transform(x);
+// dbias[co] = sum dy.  Persistent workgroups walk the tiles; a wave keeps its ten accumulators over all its tiles and the
+// workgroup reduces ONCE, in a fixed order (no atomics): partials[workgroup][NPART] (the row layout of conv2d.hip's
+// backward, so that ptts_conv2d_reduce_grouped serves both).
+// LDS: dy planes [NP][16 + (KT-1) dil][RS] (halo) | a planes [NP][16][RS]; reduction scratch over them at the end.
+// Blocks are 18 bin groups wide here (9 pairs; 17 used).  K step = 16 rows x 2 adjacent bin groups; per kernel row kt and
+// half hb of the 8 dy bins a lane's accumulator holds
+//   Ck[(fi,ci)][(fo,co)] with kf = fi + 4 - 4 hb - fo   (rows m = 4 (lane >> 4) + r -> fi = lane >> 4, ci = r; n = lane & 15)
+// ------------------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef s16x4 __attribute__((address_space(3)))* lds_s16x4_ptr;
+__device__ __forceinline__ bf16x4 tr_read(const u16* p) {
+    // ds_read_b64_tr_b16: lane i of a 16-lane group receives column i of the 4 rows x 16 columns block whose row q,
+    // columns 4p..4p+3 lane 4q+p of the group points at (EXEC must be full: every caller is wave-uniform)
+    return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p)));
+}
+__device__ __forceinline__ bf16x8 cat(bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+
+template <int DIL, int MODE>
+__global__ __launch_bounds__(THREADS, DIL <= 2 ? 2 : 1) void wgrad_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mask_src,
+    float* __restrict__ partials, Shape s, float alpha, int dbg, unsigned long long* dbg_buf) {
+    typedef Stage<4 * (GPB + 1) + 4, 16 + (KT - 1) * DIL> SD;      // dy tile with its time halo
+    typedef Stage<4 * (GPB + 1) + 4, 16> SA;                       // activation tile
+    static_assert(SD::RS == SA::RS, "one row stride");
+    extern __shared__ __attribute__((aligned(16))) u16 lds[];
+    stamp(dbg_buf, dbg, 0);
+    u16* dpl = lds;
+    u16* apl = lds + NP * SD::PS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int lo = (KT - 1) * DIL - s.pad_t;      // staged dy row r <-> t = t0 - lo + r
+    constexpr bool MASK = MODE == PTTS_IN_MASKMUL;
+
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[KT][2];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) { acc[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    // transposed-read address of this lane inside a 4 rows x 16 columns block: row li >> 2, bin li & 3 of the block's four.
+    // bin_off(8 gp + c) = 32 gp + bin_off(c): the pair index is an immediate-free add, everything else immediates
+    const int trow = 4 * lg + (li >> 2);
+    const u16* abase0 = apl + trow * SA::RS + bin_off(2 + (li & 3));
+    const u16* abase1 = apl + trow * SA::RS + bin_off(6 + (li & 3));
+    const u16* dbase0 = dpl + trow * SD::RS + bin_off(0 + (li & 3));
+    const u16* dbase1 = dpl + trow * SD::RS + bin_off(4 + (li & 3));
+    const u16* dbase2 = dpl + trow * SD::RS + bin_off(8 + (li & 3));
+
+    Slots<SD> sd; sd.init();
+    Slots<SA> sa; sa.init();
+    int tile = blockIdx.x;
+    Pref<SD::NB, false> pd;
+    Pref<SA::NB, MASK> pa;
+    TilePos pos = tile_pos(s, tile < s.ntiles ? tile : 0);
+    if (tile < s.ntiles && !(dbg & DBG_NOSTAGE)) {
+        pref_load<SD, false>(pd, sd, dy, nullptr, pos.img, pos.t0 - lo, 4 * pos.g_base - 2, s.T, s.F, s.F);
+        pref_load<SA, MASK>(pa, sa, x, mask_src, pos.img, pos.t0, 4 * pos.g_base - 2, s.T, s.F, min(s.F, 4 * (pos.g_base + pos.ng)));
+    }
+    int it = 0;
+    while (tile < s.ntiles) {
+        if (!(dbg & DBG_NOSTAGE)) {
+            pref_commit<SD, PTTS_IN_NONE>(pd, sd, dpl, pos.t0 - lo, 4 * pos.g_base - 2, s.T, s.F, nullptr, nullptr, alpha, lo, 2 + 4 * pos.ng, &bsum);
+            pref_commit<SA, MODE>(pa, sa, apl, pos.t0, 4 * pos.g_base - 2, s.T, s.F, nullptr, nullptr, alpha, 0, 0, nullptr);
+        }
+        if (it == 0) stamp(dbg_buf, dbg, 1);
+        __syncthreads();
+        if (it == 0) stamp(dbg_buf, dbg, 2);
+        const int ng2 = (pos.ng + 1) >> 1;
+        const int next = tile + gridDim.x;
+        if (next < s.ntiles) {
+            pos = tile_pos(s, next);
+            if (!(dbg & DBG_NOSTAGE)) {
+                pref_load<SD, false>(pd, sd, dy, nullptr, pos.img, pos.t0 - lo, 4 * pos.g_base - 2, s.T, s.F, s.F);
+                pref_load<SA, MASK>(pa, sa, x, mask_src, pos.img, pos.t0, 4 * pos.g_base - 2, s.T, s.F, min(s.F, 4 * (pos.g_base + pos.ng)));
+            }
+        }
+        for (int gp = wave; gp < ng2 && !(dbg & DBG_NOMFMA); gp += 4) {
+            // A operand: a[row 4 lg + e&3][group 2 gp + (e >> 2)][(fi, ci) = li]  -- staged bin of group g, fi: 4 g + 2 + fi
+            bf16x8 af[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) af[p] = cat(tr_read(abase0 + 32 * gp + p * SA::PS), tr_read(abase1 + 32 * gp + p * SA::PS));
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                // B operand: dy[staged row 4 lg + e&3 + (KT-1-kt) dil][staged bin 4 (g + hb) + fo][co], (fo, co) = li;
+                // the upper half of hb = 0 is the lower half of hb = 1
+                bf16x4 d0[NP], d1[NP], d2[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const int off = 32 * gp + p * SD::PS + (KT - 1 - kt) * DIL * SD::RS;
+                    d0[p] = tr_read(dbase0 + off);
+                    d1[p] = tr_read(dbase1 + off);
+                    d2[p] = tr_read(dbase2 + off);
+                }
+#define C2M_MM(PA, PW)                                                                                                   \
+                acc[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA], cat(d0[PW], d1[PW]), acc[kt][0], 0, 0, 0);   \
+                acc[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA], cat(d1[PW], d2[PW]), acc[kt][1], 0, 0, 0);
+                C2M_PRODUCTS(C2M_MM)
+#undef C2M_MM
+            }
+        }
+        if (it == 0) stamp(dbg_buf, dbg, 3);
+        __syncthreads();       // planes free (and, after the last tile, dead: the LDS becomes the reduction scratch)
+        tile = next;
+        ++it;
+    }
+    // ---- one reduction per workgroup, fixed order.  red[wave][kt][hb][r][lane] | bs[256][4]
+    float* red = reinterpret_cast<float*>(lds);
+    float* bs = red + 4 * KT * 2 * 4 * 64;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(((wave * KT + kt) * 2 + hb) * 4 + r) * 64 + lane] = acc[kt][hb][r];
+    *reinterpret_cast<f32x4*>(bs + tid * 4) = bsum;
+    __syncthreads();
+    float* out = partials + (size_t)blockIdx.x * NPART;
+    for (int i = tid; i < KT * KF * 16; i += THREADS) {
+        // dW[kt][kf][ci][co]: lane (li = 4 fo + co, lg = fi), register r = ci of acc[kt][hb], kf = fi + 4 - 4 hb - fo
+        const int co = i & 3, ci = (i >> 2) & 3, kf = (i >> 4) % KF, kt = (i >> 4) / KF;
+        float sum = 0.f;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) {
+                const int fo = fi + 4 - 4 * hb - kf;
+                if (fo >= 0 && fo < 4) {
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) sum += red[(((w * KT + kt) * 2 + hb) * 4 + ci) * 64 + 16 * fi + 4 * fo + co];
+                }
+            }
+        out[i] = sum;
+    }
+    if (tid < 64) {
+        // dbias: 256 lane sums x 4 channels -> 64 lanes take 16 values each, then a butterfly over the lanes of a channel
+        const int ch = tid & 3, j0 = tid >> 2;
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v += bs[(j0 * 16 + j) * 4 + ch];
+        v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+        if (tid < 4) out[KT * KF * 16 + tid] = v;
+    }
+    stamp(dbg_buf, dbg, 4);
+}
+
+}  // namespace c2m
+}  // namespace ptts
+
+using namespace ptts;
+using namespace ptts::c2m;
+
+// measurement hook: phase switches / per-workgroup stamps (buffer of gridDim.x * 8 uint64, or NULL); 0 restores the product path
+extern "C" int ptts_conv2d_mfma_debug(int flags, void* stamp_buf) {
+    g_dbg = flags;
+    g_dbg_buf = (unsigned long long*)stamp_buf;
+    if ((flags & DBG_STAMPS) && !stamp_buf) g_dbg &= ~DBG_STAMPS;
+    return PTTS_OK;
+}
+
+extern "C" size_t ptts_conv2d_mfma_table_bytes(int KT_) { return (size_t)KT_ * NP * 64 * 8 * sizeof(u16); }
+
+extern "C" int ptts_conv2d_mfma_tables(const float* w, void* table_fwd, void* table_bwd, int KT_, int KF_, int Cin, int Cout,
+                                       void* stream) {
+    PTTS_REQUIRE(w && (table_fwd || table_bwd), "conv2d_mfma_tables: null pointer");
+    PTTS_REQUIRE(KT_ == 5 && KF_ == 5 && Cin == 4 && Cout == 4, "conv2d_mfma_tables: only 5x5, 4 -> 4 channels (got %dx%d, %d -> %d)", KT_, KF_, Cin, Cout);
+    hipLaunchKernelGGL(toeplitz_table_kernel, dim3(2), dim3(64 * KT), 0, (hipStream_t)stream, w, (u16*)table_fwd, (u16*)table_bwd);
+    return check_launch("conv2d_mfma_tables");
+}
+
+namespace {
+constexpr size_t LDS_MAX = 160 * 1024;
+constexpr int NCU = 256;
+
+unsigned magic32(int d) { return (unsigned)(((1ULL << 32) + (unsigned)d - 1) / (unsigned)d); }
+
+Shape make_shape(int B, int T, int F, int pad_t) {
+    Shape s;
+    s.T = T; s.F = F; s.NG = (F + 3) / 4;
+    s.nfb = (s.NG + GPB - 1) / GPB;
+    s.ntt = (T + 15) / 16;
+    s.ntiles = B * s.ntt * s.nfb;
+    s.magic_nfb = s.nfb > 1 ? magic32(s.nfb) : 0u;
+    s.magic_ntt = s.ntt > 1 ? magic32(s.ntt) : 0u;
+    s.pad_t = pad_t;
+    return s;
+}
+bool shape_ok(const Shape& s) { return s.ntiles > 0 && s.ntiles < (1 << 20) && s.nfb < 4096 && s.ntt < 4096; }
+
+template <int DIL> constexpr size_t lds_fwd() { return ((size_t)NP * Stage<4 * GPB + 4, 16 + (KT - 1) * DIL>::PS + (size_t)KT * NP * 64 * 8) * sizeof(u16); }
+template <int DIL> constexpr size_t lds_wgrad() {
+    const size_t planes = (size_t)NP * (Stage<4 * (GPB + 1) + 4, 16 + (KT - 1) * DIL>::PS + Stage<4 * (GPB + 1) + 4, 16>::PS) * sizeof(u16);
+    const size_t red = (size_t)(4 * KT * 2 * 4 * 64 + THREADS * 4) * sizeof(float);
+    return planes > red ? planes : red;
+}
+int grid_for(int ntiles, size_t lds, int max_per_cu) {
+    int per_cu = (int)(LDS_MAX / lds);
+    if (per_cu > max_per_cu) per_cu = max_per_cu;
+    if (per_cu < 1) per_cu = 1;
+    return ntiles < NCU * per_cu ? ntiles : NCU * per_cu;
+}
+}  // namespace
+
+// 1 when the shape has a matrix-core kernel, else 0: 5x5, 4 -> 4 channels, time dilation 1, 2, 4 or 8
+extern "C" int ptts_conv2d_mfma_supported(int F, int Cin, int Cout, int KT_, int KF_, int dil_t) {
+    if (!(Cin == 4 && Cout == 4 && KT_ == 5 && KF_ == 5 && F >= 1)) return 0;
+    return (dil_t == 1 || dil_t == 2 || dil_t == 4 || dil_t == 8) ? 1 : 0;
+}
+
+// y = bias + conv(transform(x), w) through the forward table; with out_mask: y *= (out_mask > 0 ? 1 : alpha)
+// (the backward-data pass: x = dy, table = the transposed table, pad_t = (KT-1) dil - pad_t(forward), out_mask = the
+// forward layer's pre-activation input).
+extern "C" int ptts_conv2d_mfma_fwd(const float* x, const void* table, const float* bias, const float* in_scale,
+                                    const float* in_shift, const float* mask_src, const float* out_mask, float* y,
+                                    int B, int T, int F, int KT_, int dil_t, int pad_t, int in_mode, float alpha,
+                                    void* stream) {
+    PTTS_REQUIRE(x && table && y, "conv2d_mfma_fwd: null tensor");
+    PTTS_REQUIRE(B > 0 && T > 0 && F > 0 && KT_ == 5, "conv2d_mfma_fwd: bad dims B=%d T=%d F=%d KT=%d", B, T, F, KT_);
+    PTTS_REQUIRE(dil_t == 1 || dil_t == 2 || dil_t == 4 || dil_t == 8, "conv2d_mfma_fwd: time dilation %d has no kernel (1, 2, 4, 8)", dil_t);
+    PTTS_REQUIRE(in_mode >= 0 && in_mode <= 2, "conv2d_mfma_fwd: bad in_mode %d", in_mode);
+    PTTS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_mfma_fwd: scale/shift must come together");
+    PTTS_REQUIRE(in_mode != PTTS_IN_MASKMUL || mask_src, "conv2d_mfma_fwd: MASKMUL needs mask_src");
+    PTTS_REQUIRE(in_mode == PTTS_IN_LRELU || !in_scale, "conv2d_mfma_fwd: scale/shift need PTTS_IN_LRELU");
+    PTTS_REQUIRE(pad_t >= 0 && pad_t <= (KT - 1) * dil_t, "conv2d_mfma_fwd: bad pad_t %d", pad_t);
+    PTTS_REQUIRE(alpha >= 0.f && alpha <= 1.f, "conv2d_mfma_fwd: LeakyReLU slope %g outside [0, 1]", alpha);
+    PTTS_REQUIRE((long long)(T + 64) * F * C < (1LL << 31), "conv2d_mfma_fwd: utterance too large for 32-bit tile offsets");
+    const Shape s = make_shape(B, T, F, pad_t);
+    PTTS_REQUIRE(shape_ok(s), "conv2d_mfma_fwd: too many tiles");
+    hipStream_t st = (hipStream_t)stream;
+    const bool om = out_mask != nullptr;
+#define C2M_L(DIL, MODE, OM)                                                                                             \
+    do {                                                                                                                 \
+        constexpr size_t lds = lds_fwd<DIL>();                                                                           \
+        static_assert(lds <= LDS_MAX, "tile does not fit the LDS");                                                      \
+        static bool attr = false;                                                                                        \
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_kernel<DIL, MODE, OM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX); attr = true; } \
+        const int grid = grid_for(s.ntiles, lds, DIL == 1 ? 3 : (DIL == 2 ? 2 : 1));                                     \
+        hipLaunchKernelGGL((fwd_kernel<DIL, MODE, OM>), dim3(grid), dim3(THREADS), lds, st, x, (const u16*)table, bias,  \
+                           in_scale, in_shift, mask_src, out_mask, y, s, alpha, g_dbg, g_dbg_buf);                       \
+    } while (0)
+#define C2M_M(DIL)                                                                                                       \
+    do {                                                                                                                 \
+        if (in_mode == PTTS_IN_LRELU) { if (om) C2M_L(DIL, PTTS_IN_LRELU, true); else C2M_L(DIL, PTTS_IN_LRELU, false); } \
+        else if (in_mode == PTTS_IN_MASKMUL) { PTTS_REQUIRE(!om, "conv2d_mfma_fwd: MASKMUL with an output mask has no kernel"); C2M_L(DIL, PTTS_IN_MASKMUL, false); } \
+        else { if (om) C2M_L(DIL, PTTS_IN_NONE, true); else C2M_L(DIL, PTTS_IN_NONE, false); }                           \
+    } while (0)
+    if (dil_t == 1) C2M_M(1); else if (dil_t == 2) C2M_M(2); else if (dil_t == 4) C2M_M(4); else C2M_M(8);
+#undef C2M_M
+#undef C2M_L
+    return check_launch("conv2d_mfma_fwd");
+}
+
+extern "C" size_t ptts_conv2d_mfma_wgrad_workspace_bytes(int B, int T) {
+    (void)B; (void)T;
+    return 4096 + (size_t)NCU * 3 * NPART * sizeof(float);
+}
+
+// per-workgroup partial sums of dW / dbias as rows [nblocks][npart] behind a 4096-byte head of `workspace` (the layout of
+// ptts_conv2d_bwd_partials: ptts_conv2d_reduce_grouped adds them into the gradient buffers)
+extern "C" int ptts_conv2d_mfma_wgrad_partials(const float* dy, const float* x, const float* mask_src, void* workspace,
+                                               size_t workspace_bytes, int* nblocks_out, int* npart_out, int B, int T, int F,
+                                               int KT_, int dil_t, int pad_t, int in_mode, float alpha, void* stream) {
+    PTTS_REQUIRE(dy && x && workspace && nblocks_out && npart_out, "conv2d_mfma_wgrad: null pointer");
+    PTTS_REQUIRE(B > 0 && T > 0 && F > 0 && KT_ == 5, "conv2d_mfma_wgrad: bad dims");
+    PTTS_REQUIRE(dil_t == 1 || dil_t == 2 || dil_t == 4 || dil_t == 8, "conv2d_mfma_wgrad: time dilation %d has no kernel (1, 2, 4, 8)", dil_t);
+    PTTS_REQUIRE(in_mode >= 0 && in_mode <= 2, "conv2d_mfma_wgrad: bad in_mode %d", in_mode);
+    PTTS_REQUIRE(in_mode != PTTS_IN_MASKMUL || mask_src, "conv2d_mfma_wgrad: MASKMUL needs mask_src");
+    PTTS_REQUIRE(pad_t >= 0 && pad_t <= (KT - 1) * dil_t, "conv2d_mfma_wgrad: bad pad_t %d", pad_t);
+    PTTS_REQUIRE(alpha >= 0.f && alpha <= 1.f, "conv2d_mfma_wgrad: LeakyReLU slope %g outside [0, 1]", alpha);
+    PTTS_REQUIRE((long long)(T + 64) * F * C < (1LL << 31), "conv2d_mfma_wgrad: utterance too large for 32-bit tile offsets");
+    const Shape s = make_shape(B, T, F, pad_t);
+    PTTS_REQUIRE(shape_ok(s), "conv2d_mfma_wgrad: too many tiles");
+    const size_t need = ptts_conv2d_mfma_wgrad_workspace_bytes(B, T);
+    if (workspace_bytes < need) { set_error("conv2d_mfma_wgrad: workspace %zu < %zu", workspace_bytes, need); return PTTS_EWORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    float* parts = reinterpret_cast<float*>((char*)workspace + 4096);
+    int grid = 0;
+#define C2M_L(DIL, MODE)                                                                                                 \
+    do {                                                                                                                 \
+        constexpr size_t lds = lds_wgrad<DIL>();                                                                         \
+        static_assert(lds <= LDS_MAX, "tile does not fit the LDS");                                                      \
+        static bool attr = false;                                                                                        \
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<DIL, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX); attr = true; } \
+        grid = grid_for(s.ntiles, lds, DIL <= 2 ? 2 : 1);                                                                \
+        hipLaunchKernelGGL((wgrad_kernel<DIL, MODE>), dim3(grid), dim3(THREADS), lds, st, x, dy, mask_src, parts, s, alpha, g_dbg, g_dbg_buf); \
+    } while (0)
+#define C2M_M(DIL)                                                                                                       \
+    do {                                                                                                                 \
+        if (in_mode == PTTS_IN_LRELU) C2M_L(DIL, PTTS_IN_LRELU);                                                         \
+        else if (in_mode == PTTS_IN_MASKMUL) C2M_L(DIL, PTTS_IN_MASKMUL);                                                \
+        else C2M_L(DIL, PTTS_IN_NONE);                                                                                   \
+    } while (0)
+    if (dil_t == 1) C2M_M(1); else if (dil_t == 2) C2M_M(2); else if (dil_t == 4) C2M_M(4); else C2M_M(8);
+#undef C2M_M
+#undef C2M_L
+    *nblocks_out = grid;
+    *npart_out = NPART;
+    return check_launch("conv2d_mfma_wgrad");
+}

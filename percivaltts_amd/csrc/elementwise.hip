@@ -619,6 +619,66 @@ extern "C" int ptts_affine_act(const float* x, const float* scale, const float* 
     return check_launch("affine_act");
 }
 
+// ---- gated product of a gated convolution: y = a * sigmoid(b) (reference networktts.py:128-134, pGCNN2D: the second
+// Conv2D carries activation=sigmoid and kl.Multiply joins the two).  Both pre-activations are read once; neither the
+// sigmoid nor the product's operands are written.  HBM-bound: 12 B per element forward, 20 B backward.
+__global__ __launch_bounds__(EW_THREADS) void gated_mul_fwd_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                                 float4* __restrict__ y, long long n4, const float* __restrict__ at,
+                                                                 const float* __restrict__ bt, float* __restrict__ yt, int tail) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 av = a[i], bv = b[i];
+        float4 o;
+        o.x = av.x / (1.f + __expf(-bv.x)); o.y = av.y / (1.f + __expf(-bv.y));
+        o.z = av.z / (1.f + __expf(-bv.z)); o.w = av.w / (1.f + __expf(-bv.w));
+        y[i] = o;
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail) yt[threadIdx.x] = at[threadIdx.x] / (1.f + __expf(-bt[threadIdx.x]));
+}
+
+__device__ __forceinline__ void gated_bwd1(float dy, float a, float b, float& da, float& db) {
+    const float s = 1.f / (1.f + __expf(-b));
+    da = dy * s;
+    db = dy * a * s * (1.f - s);
+}
+
+__global__ __launch_bounds__(EW_THREADS) void gated_mul_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ a,
+                                                                 const float4* __restrict__ b, float4* __restrict__ da,
+                                                                 float4* __restrict__ db, long long n4,
+                                                                 const float* __restrict__ dyt, const float* __restrict__ at,
+                                                                 const float* __restrict__ bt, float* __restrict__ dat,
+                                                                 float* __restrict__ dbt, int tail) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 g = dy[i], av = a[i], bv = b[i];
+        float4 oa, ob;
+        gated_bwd1(g.x, av.x, bv.x, oa.x, ob.x); gated_bwd1(g.y, av.y, bv.y, oa.y, ob.y);
+        gated_bwd1(g.z, av.z, bv.z, oa.z, ob.z); gated_bwd1(g.w, av.w, bv.w, oa.w, ob.w);
+        da[i] = oa; db[i] = ob;
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail) gated_bwd1(dyt[threadIdx.x], at[threadIdx.x], bt[threadIdx.x], dat[threadIdx.x], dbt[threadIdx.x]);
+}
+
+extern "C" int ptts_gated_mul_fwd(const float* a, const float* b, float* y, long long n, void* stream) {
+    PTTS_REQUIRE(a && b && y && n > 0, "gated_mul_fwd: bad args");
+    PTTS_REQUIRE(al16(a) && al16(b) && al16(y), "gated_mul_fwd: tensors must be 16-byte aligned");
+    const long long n4 = n / 4;
+    const int tail = (int)(n - 4 * n4);
+    hipLaunchKernelGGL(gated_mul_fwd_kernel, dim3(ew_blocks(n4 > 0 ? n4 : 1, 2)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       (const float4*)a, (const float4*)b, (float4*)y, n4, a + 4 * n4, b + 4 * n4, y + 4 * n4, tail);
+    return check_launch("gated_mul_fwd");
+}
+
+extern "C" int ptts_gated_mul_bwd(const float* dy, const float* a, const float* b, float* da, float* db, long long n,
+                                  void* stream) {
+    PTTS_REQUIRE(dy && a && b && da && db && n > 0, "gated_mul_bwd: bad args");
+    PTTS_REQUIRE(al16(dy) && al16(a) && al16(b) && al16(da) && al16(db), "gated_mul_bwd: tensors must be 16-byte aligned");
+    const long long n4 = n / 4;
+    const int tail = (int)(n - 4 * n4);
+    hipLaunchKernelGGL(gated_mul_bwd_kernel, dim3(ew_blocks(n4 > 0 ? n4 : 1, 2)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       (const float4*)dy, (const float4*)a, (const float4*)b, (float4*)da, (float4*)db, n4, dy + 4 * n4,
+                       a + 4 * n4, b + 4 * n4, da + 4 * n4, db + 4 * n4, tail);
+    return check_launch("gated_mul_bwd");
+}
+
 extern "C" int ptts_affine_act_bwd(const float* dy, const float* x, const float* y, const float* scale,
                                    const float* shift, float* dx, double* dsums, void* workspace,
                                    size_t workspace_bytes, long long rows, int C, int act, float alpha,

@@ -209,6 +209,78 @@ def _workspace(nbytes, device):
 # ----------------------------------------------------------------------------------------------
 # raw kernel wrappers (no autograd)
 # ----------------------------------------------------------------------------------------------
+class _C2M(object):
+    """The 4 -> 4 channel 5x5 Conv2D layers on the bf16 matrix cores (csrc/conv2d_mfma.hip): fp32 arithmetic by the
+    three-way bf16 split of both operands (six products, fp32 accumulation), like the context Conv1D's split kernels.
+    PTTS_CONV2D_MFMA=0 or conv2d_mfma(False) select the packed-FMA stencil of csrc/conv2d.hip.  The Toeplitz tables of a
+    kernel (forward and transposed, 15 KB each) are rebuilt when the kernel changes (tensor version / flat-buffer epoch)."""
+    default = os.environ.get('PTTS_CONV2D_MFMA', '1') == '1'
+    enabled = default
+    tables = {}         # (id(w), stream) -> (w, version, epoch, fwd table, bwd table)
+
+    @staticmethod
+    def eligible(x, w, dil_t):
+        KT, KF, Cin, Cout = w.shape
+        return x.is_cuda and Cin == 4 and Cout == 4 and KT == 5 and KF == 5 and dil_t in (1, 2, 4, 8)
+
+    @classmethod
+    def table(cls, w, transposed):
+        flat = getattr(w, '_ptts_flat', None)
+        epoch = None if flat is None else flat.epoch
+        sid = torch.cuda.current_stream().cuda_stream
+        key = (id(w), sid)         # one copy per stream: the build is ordered with its consumers by the stream itself
+        ent = cls.tables.get(key)
+        if ent is None or ent[0] is not w or ent[1] != w._version or ent[2] != epoch or flat is None:
+            nb = _hip.lib().ptts_conv2d_mfma_table_bytes(5)
+            reuse = ent is not None and ent[0] is w
+            tf = ent[3] if reuse else torch.empty(nb, dtype=torch.uint8, device=w.device)
+            tb = ent[4] if reuse else torch.empty(nb, dtype=torch.uint8, device=w.device)
+            call('ptts_conv2d_mfma_tables', ptr(w), ptr(tf), ptr(tb), 5, 5, 4, 4, stream(), tag=(5, 5))
+            ent = (w, w._version, epoch, tf, tb)
+            if len(cls.tables) > 512:
+                cls.tables = {}
+            cls.tables[key] = ent
+        return ent[4] if transposed else ent[3]
+
+    @staticmethod
+    def pad_t(dil_t, pad_mode):
+        return 4 * dil_t if pad_mode == PAD_CAUSAL else 2 * dil_t
+
+    @classmethod
+    def clear(cls):
+        cls.tables = {}
+
+
+def conv2d_mfma(on):
+    """Switch the matrix-core Conv2D kernels on or off (None: the default)."""
+    _C2M.enabled = _C2M.default if on is None else bool(on)
+    _C2M.clear()
+
+
+def conv2d_path_description():
+    return ('4->4 5x5 layers: bf16x6 split on the bf16 matrix cores (fp32 accumulate); 1->4 / 4->1 layers: fp32 packed-FMA stencil'
+            if _C2M.enabled else 'fp32 packed-FMA stencil')
+
+
+def _conv2d_mfma_fwd(x, w, table, b, scale, shift, mask_src, out_mask, mode, alpha, dil_t, pad_t):
+    B, T, F, _ = x.shape
+    y = torch.empty((B, T, F, 4), dtype=torch.float32, device=x.device)
+    call('ptts_conv2d_mfma_fwd', ptr(x), ptr(table), ptr(b), ptr(scale), ptr(shift), ptr(mask_src), ptr(out_mask), ptr(y),
+         B, T, F, 5, dil_t, pad_t, mode, alpha, stream(), tag=(B, T, F, 4, 4, mode, int(out_mask is not None)))
+    return y
+
+
+def _conv2d_mfma_wgrad(dy, x, mask_src, mode, alpha, dil_t, pad_t):
+    """Partial sums of dW / dbias: (buffer, nblocks, npart); the rows start 4096 bytes into the buffer."""
+    B, T, F, _ = x.shape
+    nws = _hip.lib().ptts_conv2d_mfma_wgrad_workspace_bytes(B, T)
+    buf = torch.empty(int(nws), dtype=torch.uint8, device=x.device)
+    nblocks, npart = ctypes.c_int(0), ctypes.c_int(0)
+    call('ptts_conv2d_mfma_wgrad_partials', ptr(dy), ptr(x), ptr(mask_src), ptr(buf), buf.numel(), ctypes.byref(nblocks),
+         ctypes.byref(npart), B, T, F, 5, dil_t, pad_t, mode, alpha, stream(), tag=(B, T, F, 4, 4, mode))
+    return buf, nblocks.value, npart.value
+
+
 def _conv2d_fwd_raw(x, w, b, scale, shift, mask_src, mode, alpha, dil_t, pad_mode):
     f32c(x, 'conv2d.x'); f32c(w, 'conv2d.w'); f32c(b, 'conv2d.b'); f32c(scale); f32c(shift); f32c(mask_src)
     B, T, F, Cin = x.shape
@@ -217,6 +289,9 @@ def _conv2d_fwd_raw(x, w, b, scale, shift, mask_src, mode, alpha, dil_t, pad_mod
     assert b is None or b.numel() == Cout
     assert scale is None or (scale.numel() == Cin and shift.numel() == Cin)
     assert mask_src is None or mask_src.shape == x.shape
+    if _C2M.enabled and _C2M.eligible(x, w, dil_t) and 0.0 <= alpha <= 1.0:
+        return _conv2d_mfma_fwd(x, w, _C2M.table(w, False), b, scale, shift, mask_src, None, mode, alpha, dil_t,
+                                _C2M.pad_t(dil_t, pad_mode))
     y = torch.empty((B, T, F, Cout), dtype=torch.float32, device=x.device)
     call('ptts_conv2d_fwd', ptr(x), ptr(w), ptr(b), ptr(scale), ptr(shift), ptr(mask_src), ptr(y),
          B, T, F, Cin, Cout, KT, KF, dil_t, pad_mode, mode, alpha, stream(), tag=(B, T, F, Cin, Cout, mode))
@@ -231,6 +306,26 @@ def _conv2d_bwd_raw(dy, x, w, scale, shift, mask_src, mode, alpha, dil_t, pad_mo
     assert dy.shape == (B, T, F, Cout), 'conv2d_bwd: dy shape {} vs {}'.format(tuple(dy.shape), (B, T, F, Cout))
     assert mask_src is None or mask_src.shape == x.shape
     dev = x.device
+    if _C2M.enabled and _C2M.eligible(x, w, dil_t) and scale is None and not want_affine and 0.0 <= alpha <= 1.0:
+        # matrix-core kernels: backward data = forward through the transposed table with the layer input's LeakyReLU mask
+        # in the store; weight gradient = per-workgroup partial sums + the grouped reduction
+        pad_t = _C2M.pad_t(dil_t, pad_mode)
+        dx = dw = db = None
+        if want_dx:
+            assert mode != IN_MASKMUL, 'conv2d_bwd: dx is not defined for MASKMUL (weight-only sweep)'
+            dx = _conv2d_mfma_fwd(dy, w, _C2M.table(w, True), None, None, None, None, x if mode == IN_LRELU else None,
+                                  IN_NONE, alpha, dil_t, 4 * dil_t - pad_t)
+        if want_dw or want_db:
+            buf, nblocks, npart = _conv2d_mfma_wgrad(dy, x, mask_src, mode, alpha, dil_t, pad_t)
+            dw = torch.zeros_like(w) if want_dw else None
+            db = torch.zeros(Cout, dtype=torch.float32, device=dev) if want_db else None
+            desc = (_hip.Conv2dReduceDesc * 1)()
+            desc[0].partials = buf.data_ptr() + 4096
+            desc[0].nblocks, desc[0].npart, desc[0].nw, desc[0].cout = nblocks, npart, KT * KF * Cin * Cout, Cout
+            desc[0].dw = dw.data_ptr() if dw is not None else None
+            desc[0].dbias = db.data_ptr() if db is not None else None
+            call('ptts_conv2d_reduce_grouped', ctypes.cast(desc, ctypes.c_void_p), 1, stream(), tag=(1,))
+        return dx, dw, db, None, None
     dx = torch.empty_like(x) if want_dx else None
     dw = torch.empty_like(w) if (want_dw or want_db) else None
     db = torch.empty(Cout, dtype=torch.float32, device=dev) if want_db else None
@@ -251,6 +346,18 @@ def _conv2d_bwd_deferred(dy, x, w, mask_src, mode, alpha, dil_t, pad_mode, want_
     this shape has no tiled kernel."""
     B, T, F, Cin = x.shape
     KT, KF, _, Cout = w.shape
+    if _C2M.enabled and _C2M.eligible(x, w, dil_t) and 0.0 <= alpha <= 1.0:
+        pad_t = _C2M.pad_t(dil_t, pad_mode)
+        dx = None
+        if want_dx:
+            dx = _conv2d_mfma_fwd(dy, w, _C2M.table(w, True), None, None, None, None, x if mode == IN_LRELU else None,
+                                  IN_NONE, alpha, dil_t, 4 * dil_t - pad_t)
+        buf, nblocks, npart = _conv2d_mfma_wgrad(dy, x, mask_src, mode, alpha, dil_t, pad_t)
+        cur = torch.cuda.current_stream()
+        if all(cur.cuda_stream != st.cuda_stream for st in _Deferred.streams):
+            _Deferred.streams.append(cur)
+        _Deferred.conv_items.append((buf, nblocks, npart, KT * KF * Cin * Cout, Cout, gw, gb))
+        return dx
     nws = _hip.lib().ptts_conv2d_bwd_workspace_bytes(B, T, F, Cin, Cout, KT, KF, dil_t)
     if nws <= 16:
         return False

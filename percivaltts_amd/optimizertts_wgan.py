@@ -311,6 +311,9 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         if kind == 'critic':
             sA.uniform_(0.0, 1.0)
         g.replay()
+        # the replayed Adam / clip kernels changed the weights behind every weight-keyed cache (bf16 planes, Toeplitz
+        # tables): the Python-side epoch bump of KerasAdam.step() is not part of the graph
+        (self.critic_opti if kind == 'critic' else self.gen_opti).flat.epoch += 1
         return out
 
     def device_step(self, batchid, X, Y):

@@ -107,6 +107,98 @@ def test_conv2d_forward_backward(ops, case, mode):
         close(shd.grad, shr.grad, rtol=2e-4, atol=1e-4, what='dshift')
 
 
+def test_conv2d_mfma_tables_are_the_split_of_the_toeplitz_blocks(ops):
+    """csrc/conv2d_mfma.hip: the operand tables of a 5x5 4->4 kernel -- per kernel row the banded block
+    A[(so,co)][(j,ci)] = w[kt][j-so][ci][co] (forward) resp. w[4-kt][4-(j-so)][ci][co] with the channel roles swapped
+    (backward data) -- hold the three bf16 planes of oracle.np_split3_bf16, bit for bit, in the lane layout
+    [kt][plane][lane = 16 lg + li][e]: m = li -> (so, oc), k = 8 lg + e -> (j = 2 lg + e // 4, ic = e % 4).  The same device
+    function (split3) splits the activations on their way into the LDS, where they cannot be read back."""
+    from percivaltts_amd.ops import call, ptr, stream
+    g = gen(51)
+    w = (torch.randn(5, 5, 4, 4, generator=g) * torch.exp(2 * torch.randn(5, 5, 4, 4, generator=g))).float()
+    nb = ops._hip.lib().ptts_conv2d_mfma_table_bytes(5)
+    assert nb == 5 * 3 * 64 * 8 * 2
+    tf = torch.zeros(nb, dtype=torch.uint8, device='cuda'); tb = torch.zeros(nb, dtype=torch.uint8, device='cuda')
+    call('ptts_conv2d_mfma_tables', ptr(w.cuda()), ptr(tf), ptr(tb), 5, 5, 4, 4, stream())
+    wn = w.numpy()
+    for tab, transposed in ((tf, False), (tb, True)):
+        got = tab.view(torch.bfloat16).float().cpu().numpy().reshape(5, 3, 64, 8)
+        want = O.np.zeros((5, 64, 8), dtype=O.np.float32)
+        for kt in range(5):
+            for lane in range(64):
+                li, lg = lane & 15, lane >> 4
+                so, oc = li >> 2, li & 3
+                for e in range(8):
+                    j, ic = 2 * lg + e // 4, e % 4
+                    kf = j - so
+                    if 0 <= kf < 5:
+                        want[kt, lane, e] = wn[4 - kt, 4 - kf, oc, ic] if transposed else wn[kt, kf, ic, oc]
+        planes = O.np_split3_bf16(want)
+        for p in range(3):
+            assert (got[:, p] == planes[p]).all(), 'plane {} of the {} table'.format(p, 'transposed' if transposed else 'forward')
+        assert (got.sum(1) == want).all()
+
+
+@pytest.mark.parametrize('case', [
+    # B, T, F, dil, causal
+    (3, 100, 65, 1, False),        # the critic's layer: one block of 17 bin groups, several time tiles, a ragged last tile
+    (2, 16, 65, 1, False),         # exactly one tile per utterance
+    (1, 1, 65, 1, False),          # a single frame
+    (2, 37, 130, 1, False),        # two blocks of bin groups, F not a multiple of 4
+    (1, 50, 129, 1, True),         # reference-shaped F, causal
+    (2, 40, 7, 2, False), (2, 70, 65, 4, True), (1, 90, 33, 8, False),     # every dilation instance
+])
+def test_conv2d_mfma_against_the_oracle_and_the_fp32_stencil(ops, case):
+    """The matrix-core kernels of the 4->4 5x5 layers (bf16x6 split, csrc/conv2d_mfma.hip) in every role -- forward with
+    LeakyReLU on load, with a BatchNorm affine, backward data + weight/bias gradient, and the masked (second-order)
+    sweeps -- against the fp64 oracle at the tolerance of the fp32 stencil they replace (rtol 1e-4 / atol 1e-5; 2e-4 /
+    1e-4 for the reductions), and A/B against that stencil (PTTS_CONV2D_MFMA=0).  The kernels are asserted to have run."""
+    B, T, F, dil, causal = case
+    g = gen(52)
+    x = torch.randn(B, T, F, 4, generator=g, dtype=torch.float64)
+    w = torch.randn(5, 5, 4, 4, generator=g, dtype=torch.float64) * 0.3
+    b = torch.randn(4, generator=g, dtype=torch.float64)
+    sc = torch.rand(4, generator=g, dtype=torch.float64) + 0.5
+    sh = torch.randn(4, generator=g, dtype=torch.float64) * 0.3
+    dy = torch.randn(B, T, F, 4, generator=g, dtype=torch.float64)
+    msk = torch.randn(B, T, F, 4, generator=g, dtype=torch.float64)
+    pm = ops.PAD_CAUSAL if causal else ops.PAD_SAME
+
+    xr, wr, br = ref(x, True), ref(w, True), ref(b, True)
+    yr = O.conv2d_nhwc(O.lrelu(xr), wr, br, dil_t=dil, causal=causal)
+    yr.backward(dy)
+    ya = O.conv2d_nhwc(O.lrelu(ref(x) * ref(sc) + ref(sh)), ref(w), ref(b), dil_t=dil, causal=causal)
+    dmask = torch.where(ref(msk) > 0, 1.0, 0.3)
+    ym = O.conv2d_nhwc(ref(x) * dmask, ref(w), None, dil_t=dil, causal=causal)
+    wm = ref(w, True)
+    O.conv2d_nhwc(ref(x) * dmask, wm, None, dil_t=dil, causal=causal).backward(dy)
+
+    def run(on):
+        ops.conv2d_mfma(on)
+        try:
+            with ops._hip.KernelTimer() as kt:
+                xd, wd, bd = dev(x, True), dev(w, True), dev(b, True)
+                yd = ops.conv2d(ops.Lazy(xd, lrelu=True), wd, bd, dil_t=dil, pad_mode=pm)
+                yd.backward(dev(dy))
+                yad = ops.conv2d(ops.Lazy(dev(x), dev(sc), dev(sh), lrelu=True), dev(w), dev(b), dil_t=dil, pad_mode=pm)
+                ymd = ops._conv2d_fwd_raw(dev(x), dev(w), None, None, None, dev(msk), ops.IN_MASKMUL, 0.3, dil, pm)
+                _, dwm, _, _, _ = ops._conv2d_bwd_raw(dev(dy), dev(x), dev(w), None, None, dev(msk), ops.IN_MASKMUL, 0.3, dil, pm,
+                                                      False, True, False, False)
+            return (yd, xd.grad, wd.grad, bd.grad, yad, ymd, dwm), [r[0] for r in kt.records]
+        finally:
+            ops.conv2d_mfma(None)
+
+    res_m, names_m = run(True)
+    res_s, names_s = run(False)
+    assert names_m.count('ptts_conv2d_mfma_fwd') == 4 and names_m.count('ptts_conv2d_mfma_wgrad_partials') == 2, names_m
+    assert 'ptts_conv2d_fwd' not in names_m and not any(n.startswith('ptts_conv2d_mfma') for n in names_s)
+    wants = (yr, xr.grad, wr.grad, br.grad, ya, ym, wm.grad)
+    tols = ((RT, AT), (RT, AT), (2e-4, 1e-4), (2e-4, 1e-4), (RT, AT), (RT, AT), (2e-4, 1e-4))
+    for nm, got_m, got_s, want, (rt, at) in zip(('y', 'dx', 'dw', 'db', 'y (affine)', 'y (maskmul)', 'dw (maskmul)'), res_m, res_s, wants, tols):
+        close(got_m, want, rtol=rt, atol=at, what=nm + ' [matrix cores]')
+        close(got_s, want, rtol=rt, atol=at, what=nm + ' [fp32 stencil]')
+
+
 @pytest.mark.parametrize('case', [(2, 12, 9, 2, 3, 3), (2, 40, 65, 4, 5, 5)])
 def test_conv2d_stack_second_order(ops, case):
     """The gradient-penalty pattern: differentiate ||d(sum v)/dx||^2 w.r.t. the kernels of a
