@@ -50,6 +50,8 @@ def parse():
     ap.add_argument('--fp32-mfma', action='store_true', help='context Conv1D forward and weight gradient on the fp32 MFMA pipe instead of the bf16x6 split products')
     ap.add_argument('--no-reference-shape', action='store_true', help="skip the leg at the reference's own training geometry (B=10, T=400, 425 -> 163)")
     ap.add_argument('--no-unreduced', action='store_true', help='skip the timed loop with every exact work reduction switched off')
+    ap.add_argument('--no-gated-leg', action='store_true', help='skip the BASELINE configs[4] leg (gated dilated-causal generator, T=2000)')
+    ap.add_argument('--gated-batch', type=int, default=64)
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-variants', action='store_true', help='skip the extra timed loop of the fp32-MFMA context-Conv1D variant')
     ap.add_argument('--no-host-leg', action='store_true', help='skip the PCIe-inclusive leg (host batches through the prefetcher)')
@@ -226,12 +228,14 @@ def roofline_leg(opt, X, Y, args):
     return out
 
 
-def build_optimizer(args, ctx, spec, nm, batch, errtype):
+def build_optimizer(args, ctx, spec, nm, batch, errtype, gated=False):
     """Generator + critic + optimiser at one geometry (random-init weights of the named architecture)."""
     import io, contextlib
     from percivaltts_amd import vocoders, modeltts_common, networks_critic, optimizertts_wgan
     cfg = make_cfg(args)
     cfg.train_batch_size = batch
+    if gated:       # BASELINE configs[4]: pGCNN2D spectral branch, time dilations 1,2,4,8,1,2,4,8, causal padding
+        cfg.arch_gen_gated = True; cfg.arch_gen_dilations = [1, 2, 4, 8]; cfg.arch_gen_causal = True
     cfg.train_wgan_hipgraph = bool(args.graph) and int(os.environ.get('WORLD_SIZE', '1')) <= 1
     cfg.train_wgan_prune_dead_branches = not args.no_prune
     cfg.train_wgan_parallel_streams = (not args.no_streams) and not cfg.train_wgan_hipgraph
@@ -381,6 +385,20 @@ def main():
                                     'value': nr * rB * rT * world / dtr, 'unit': 'frames/s', 'ms_per_step': dtr / nr * 1e3,
                                     'steps': nr, 'cycle_ms': rcyc}
         del ropt, rb
+    if not args.no_gated_leg:
+        # BASELINE configs[4]: generator spectral branch from gated convolutions (networktts.py:128-134) with time dilations
+        # 1,2,4,8,1,2,4,8 and causal padding, long context T = 2000; fp32, per GPU
+        gB, gT = args.gated_batch, 2000
+        _, gvoc, _, _, gopt = build_optimizer(args, args.ctx, spec, nm, gB, args.errtype, gated=True)
+        gb = [synthetic(gB, gT, args.ctx, gvoc.featuressize(), spec, 500 + 17 * rank + i, dev) for i in range(2)]
+        ng = 10
+        dtg, gcyc = timed_loop(gopt, gb, ng, 5, dev)
+        extra['config4_gated_dilated_causal_T2000'] = {
+            'workload': 'BASELINE configs[4] shape per GPU: synthetic [{b},{t},{c}]->[{b},{t},{o}], generator spectral branch = 8 gated '
+                        'Conv2D layers (dilations 1,2,4,8,1,2,4,8 in time, causal), 2D-conv critic, fp32'.format(b=gB, t=gT, c=args.ctx, o=gvoc.featuressize()),
+            'value': ng * gB * gT * world / dtg, 'unit': 'frames/s', 'ms_per_step': dtg / ng * 1e3, 'steps': ng, 'cycle_ms': gcyc}
+        del gopt, gb
+        torch.cuda.empty_cache()
     parallel.barrier()
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         extra['cpu_baseline'] = cpu_baseline(args, (args.ctx, spec, nm))

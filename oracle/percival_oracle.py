@@ -186,6 +186,12 @@ def dense(x, w, b=None):
     return y if b is None else y + b
 
 
+def pgcnn2d_product(x, wa, wb, dil_t=1, causal=False, ba=None, bb=None):
+    """The gated product of pGCNN2D (networktts.py:128-134): Conv2D(x) * Conv2D(x, activation=sigmoid), before its
+    BatchNormalization / LeakyReLU."""
+    return conv2d_nhwc(x, wa, ba, dil_t=dil_t, causal=causal) * torch.sigmoid(conv2d_nhwc(x, wb, bb, dil_t=dil_t, causal=causal))
+
+
 class BN(object):
     """gamma, beta, moving_mean, moving_var (the Keras weight order)."""
     def __init__(self, gamma, beta, mm, mv):
@@ -240,10 +246,15 @@ def blstm(x, W, U, b):
 # ------------------------------------------------------------------------------------------------
 class Arch(object):
     def __init__(self, ctxsize, specsize, noisesize, hiddenwidth=256, ctx_nbcnnlayers=1, ctx_winlen=21,
-                 gen_nbcnnlayers=8, gen_nbfilters=4, gen_winlen=5, spec_freqlen=5, vuvsize=0):
+                 gen_nbcnnlayers=8, gen_nbfilters=4, gen_winlen=5, spec_freqlen=5, vuvsize=0,
+                 gen_gated=False, gen_dilations=None, gen_causal=False):
         self.ctxsize, self.specsize, self.noisesize, self.vuvsize = ctxsize, specsize, noisesize, vuvsize
         self.H, self.nctx, self.kctx = hiddenwidth, ctx_nbcnnlayers, ctx_winlen
         self.L, self.C, self.kt, self.kf = gen_nbcnnlayers, gen_nbfilters, gen_winlen, spec_freqlen
+        # generator spectral branch built from pGCNN2D (networktts.py:128-134, the commented alternative at
+        # modeltts_common.py:99); time dilations / causal padding are build extensions (BASELINE configs[4]) that reduce
+        # to the reference's layer at dilation 1, symmetric padding
+        self.gated, self.dilations, self.causal = bool(gen_gated), gen_dilations, bool(gen_causal)
 
     @property
     def outsize(self):
@@ -311,7 +322,7 @@ def generator_weight_shapes(a):
     s += [(a.H, a.specsize), (a.specsize,)]                        # spec projection
     cin = 1
     for _ in range(a.L):
-        s += [(a.kt, a.kf, cin, a.C)] + bn(a.C)
+        s += [(a.kt, a.kf, cin, a.C)] * (2 if getattr(a, 'gated', False) else 1) + bn(a.C)     # pGCNN2D: two kernels
         cin = a.C
     s += [(a.kt, a.kf, cin, 1), (1,)]                              # final Conv2D, bias, linear
     cin = a.H
@@ -393,10 +404,15 @@ def generator_forward(weights, a, ctx, training, update_moving=False):
     f0 = dense(f0, w, b)
     w, b = take(2)
     s = dense(h, w, b).reshape(B, T, a.specsize, 1)
-    for _ in range(a.L):
-        s = bnl(conv2d_nhwc(s, take()), fused4d=True)
+    for li in range(a.L):
+        if getattr(a, 'gated', False):
+            dil = a.dilations[li % len(a.dilations)] if a.dilations else 1
+            wa, wb = take(2)
+            s = bnl(pgcnn2d_product(s, wa, wb, dil, a.causal), fused4d=True)
+        else:
+            s = bnl(conv2d_nhwc(s, take()), fused4d=True)
     w, b = take(2)
-    s = conv2d_nhwc(s, w, b).reshape(B, T, a.specsize)
+    s = conv2d_nhwc(s, w, b, causal=bool(getattr(a, 'gated', False) and a.causal)).reshape(B, T, a.specsize)
     n = h
     for _ in range(a.L // 2):
         n = bnl(dense(n, take()))

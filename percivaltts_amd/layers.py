@@ -383,6 +383,13 @@ class Multiply(Layer):
         return to_tensor(vals[0]) * to_tensor(vals[1])
 
 
+class GatedMultiply(Layer):
+    """kl.Multiply()([conv_a(x), Conv2D(..., activation=sigmoid)(x)]) of the reference's gated convolution
+    (networktts.py:128-134) with the sigmoid folded in: takes the two PRE-activations, one HIP pass (ptts_gated_mul_fwd)."""
+    def compute(self, vals, training, memo):
+        return ops.gated_mul(to_tensor(vals[0]), to_tensor(vals[1]))
+
+
 class Activation(Layer):
     def __init__(self, activation, name=None):
         super(Activation, self).__init__(name)

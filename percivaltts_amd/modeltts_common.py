@@ -52,7 +52,9 @@ class DCNNF0SpecNoiseFeatures(modeltts.ModelTTS):
                 l_spec = networktts.pGCNN2D(l_spec, cfgarch.arch_gen_nbfilters, cfgarch.arch_gen_winlen, cfgarch.arch_spec_freqlen, **kw)
             else:
                 l_spec = networktts.pCNN2D(l_spec, cfgarch.arch_gen_nbfilters, cfgarch.arch_gen_winlen, cfgarch.arch_spec_freqlen)
-        l_spec = kl.Conv2D(1, [cfgarch.arch_gen_winlen, cfgarch.arch_spec_freqlen], use_bias=True, activation=None)(l_spec)
+        # (the causal variant keeps its output layer causal too, so that the whole spectral stack looks only backwards)
+        l_spec = kl.Conv2D(1, [cfgarch.arch_gen_winlen, cfgarch.arch_spec_freqlen], use_bias=True, activation=None,
+                           causal=gated and bool(getattr(cfgarch, 'arch_gen_causal', False)))(l_spec)
         l_spec = kl.Reshape([l_spec.shape[-2]])(l_spec)
 
         # NM

@@ -74,8 +74,8 @@ def pGCNN2D(input, nbfilters, winlen, freqlen, bn=True, **kwargs):
     """Gated conv: conv_a(x) * sigmoid(conv_b(x)) -> BN -> LeakyReLU (networktts.py:128-134).
     kwargs dil_t / causal are build extensions (BASELINE config 5); the defaults are the reference's layer."""
     output = kl.Conv2D(nbfilters, [winlen, freqlen], use_bias=not bn, **kwargs)(input)
-    gate = kl.Conv2D(nbfilters, [winlen, freqlen], use_bias=not bn, activation='sigmoid', **kwargs)(input)
-    output = kl.Multiply()([output, gate])
+    gate = kl.Conv2D(nbfilters, [winlen, freqlen], use_bias=not bn, **kwargs)(input)      # its sigmoid lives in the product
+    output = kl.GatedMultiply()([output, gate])
     if bn: output = kl.BatchNormalization()(output)
     return kl.LeakyReLU(alpha=0.3)(output)
 

@@ -980,6 +980,34 @@ def affine_act(x, scale=None, shift=None, act=None, alpha=0.3):
 
 
 # ----------------------------------------------------------------------------------------------
+# gated product of a gated convolution (networktts.py:128-134: Conv2D(...) * Conv2D(..., activation=sigmoid))
+# ----------------------------------------------------------------------------------------------
+class GatedMulFn(torch.autograd.Function):
+    """y = a * sigmoid(b) on the two pre-activations (one pass; neither the gate nor the product's operands are stored)."""
+    @staticmethod
+    def forward(ctx, a, b):
+        f32c(a, 'gated_mul.a'); f32c(b, 'gated_mul.b')
+        assert a.shape == b.shape
+        y = torch.empty_like(a)
+        call('ptts_gated_mul_fwd', ptr(a), ptr(b), ptr(y), a.numel(), stream(), tag=(a.numel(),))
+        ctx.save_for_backward(a, b)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        a, b = ctx.saved_tensors
+        dy = dy.contiguous()
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        call('ptts_gated_mul_bwd', ptr(dy), ptr(a), ptr(b), ptr(da), ptr(db), a.numel(), stream(), tag=(a.numel(),))
+        return da, db
+
+
+def gated_mul(a, b):
+    return GatedMulFn.apply(as_tensor(a).contiguous(), as_tensor(b).contiguous())
+
+
+# ----------------------------------------------------------------------------------------------
 # LSTM / Bidirectional LSTM (networktts.py:72-96)
 # ----------------------------------------------------------------------------------------------
 class LSTMFn(torch.autograd.Function):

@@ -304,3 +304,62 @@ def test_train_step_with_the_bf16x6_context_conv_matches_the_fp32_one(setup):
     assert abs(lc1 - lc0) <= 1e-4 * max(1.0, abs(lc0)) and abs(lg1 - lg0) <= 1e-4 * max(1.0, abs(lg0)), (lc1, lc0, lg1, lg0)
     assert rel_l2(gc1, gc0) < 3e-4, rel_l2(gc1, gc0)
     assert rel_l2(gg1, gg0) < 1e-3, rel_l2(gg1, gg0)
+
+
+def test_gated_dilated_causal_generator_at_T2000():
+    """BASELINE configs[4] at its real length: the generator's spectral branch from gated convolutions (pGCNN2D,
+    networktts.py:128-134) with time dilations 1,2,4,8,1,2,4,8 and causal padding (build extensions), T = 2000.
+      * a gated layer at every dilation against the fp64 oracle on crops with their causal halo;
+      * causality of the spectral branch in inference mode: frames before t0 - 10 (the context Conv1D looks 10 frames
+        ahead) do not depend on the labels from t0 on;
+      * one critic step and one generator step run and give finite losses and gradients."""
+    import bench
+    from percivaltts_amd import vocoders, modeltts_common, networks_critic, optimizertts_wgan, backend_hip, ops, layers as kl
+    Bq, Tq = 8, 2000
+
+    class A: batch = Bq; frames = Tq; ctx = CTX
+    cfg = bench.make_cfg(A)
+    cfg.arch_gen_gated = True; cfg.arch_gen_dilations = [1, 2, 4, 8]; cfg.arch_gen_causal = True
+    dev = backend_hip.device()
+    voc = vocoders.VocoderPML(16000, 0.005, SPEC, NM)
+    with contextlib.redirect_stdout(io.StringIO()):
+        mod = modeltts_common.DCNNF0SpecNoiseFeatures(CTX, voc, cfg)
+        crit = networks_critic.Critic(voc, CTX, cfg)
+        opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype='WLSWGAN', critic=crit)
+        opt.prepare()
+    assert sum(isinstance(l, kl.GatedMultiply) for l in mod.kerasmodel.layers_list) == 8
+    X, Y = bench.synthetic(Bq, Tq, CTX, voc.featuressize(), SPEC, 77, dev)
+
+    # ---- a gated layer at each dilation, crops against the oracle
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, Tq, SPEC, 4, generator=g).cuda()
+    wa = (torch.randn(5, 5, 4, 4, generator=g) * 0.2).cuda(); wb = (torch.randn(5, 5, 4, 4, generator=g) * 0.2).cuda()
+    for dil in (1, 2, 4, 8):
+        ya = ops.conv2d(ops.Lazy(x, lrelu=True), wa, None, dil_t=dil, pad_mode=ops.PAD_CAUSAL)
+        yb = ops.conv2d(ops.Lazy(x, lrelu=True), wb, None, dil_t=dil, pad_mode=ops.PAD_CAUSAL)
+        y = ops.gated_mul(ya, yb)
+        for (bi, t0, n) in ((0, 0, 20), (1, 1000, 40), (1, Tq - 16, 16)):
+            lo = max(0, t0 - 4 * dil)
+            xc = O.lrelu(x[bi:bi + 1, lo:t0 + n].double().cpu())
+            ref = O.pgcnn2d_product(xc, wa.double().cpu(), wb.double().cpu(), dil, True)
+            if lo > 0:       # the crop's own zero padding is wrong for its first 4 dil rows: they are the halo
+                ref = ref[:, t0 - lo:]
+            close(y[bi:bi + 1, t0:t0 + n], ref, 2e-4, 2e-5, 'gated layer dil={} crop t0={}'.format(dil, t0))
+
+    # ---- causality of the spectral branch (BatchNorm on its moving statistics)
+    spec_model = kl.Model(inputs=mod.kerasmodel.inputs[0], outputs=mod.node_spec)
+    t0 = 1200
+    X2 = X.clone(); X2[:, t0:] = torch.rand_like(X2[:, t0:]) * 2 - 1
+    with torch.no_grad():
+        s1 = spec_model(X, training=False); s2 = spec_model(X2, training=False)
+    # (the context Conv1D's split product combines partial tiles with fp32 atomics: equal to the last bits, not bit for bit)
+    assert rel_l2(s2[:, :t0 - 10], s1[:, :t0 - 10]) < 1e-5, 'frames before t0 - 10 changed'
+    assert rel_l2(s2[:, t0:], s1[:, t0:]) > 1e-2
+
+    # ---- one critic step and one generator step at T = 2000
+    lc = opt.critic_step(X, Y)
+    lg = opt.generator_step(X, Y)
+    torch.cuda.synchronize()
+    assert torch.isfinite(lc) and torch.isfinite(lg), (float(lc), float(lg))
+    assert torch.isfinite(opt.critic_opti.flat.grad).all() and torch.isfinite(opt.gen_opti.flat.grad).all()
+    assert float(opt.gen_opti.flat.grad.abs().max()) > 0 and float(opt.critic_opti.flat.grad.abs().max()) > 0

@@ -43,6 +43,12 @@ GEOMS = {
     # 4160 frames: large enough for the paths the small geometries never reach -- LDS-DMA GEMM tiles (interior and edge),
     # split-K weight gradients, the grouped (deferred) weight-gradient launch, multi-tile conv2d, the packed LSTM kernels
     'mid': dict(ctx=61, spec=65, nm=20, H=64, nctx=1, kctx=21, L=2, C=4, kt=5, kf=5, B=8, T=520),
+    # the generator's spectral branch built from pGCNN2D (networktts.py:128-134; the alternative commented at
+    # modeltts_common.py:99) exactly as the reference defines it: dilation 1, symmetric padding
+    'gated': dict(ctx=31, spec=65, nm=20, H=16, nctx=1, kctx=5, L=3, C=4, kt=5, kf=5, B=2, T=40, gated=True),
+    # BASELINE configs[4]: gated, time dilations 1,2,4,8 and causal padding (build extensions)
+    'gated_dilated': dict(ctx=31, spec=65, nm=20, H=16, nctx=1, kctx=5, L=4, C=4, kt=5, kf=5, B=2, T=70, gated=True,
+                          dils=[1, 2, 4, 8], causal=True),
 }
 
 
@@ -54,10 +60,13 @@ def build(geom):
     cfg.arch_hiddenwidth = g['H']; cfg.arch_ctx_nbcnnlayers = g['nctx']; cfg.arch_ctx_winlen = g['kctx']
     cfg.arch_gen_nbcnnlayers = g['L']; cfg.arch_gen_nbfilters = g['C']; cfg.arch_gen_winlen = g['kt']
     cfg.arch_spec_freqlen = g['kf']; cfg.train_batch_size = g['B']
+    if g.get('gated'):
+        cfg.arch_gen_gated = True; cfg.arch_gen_dilations = g.get('dils'); cfg.arch_gen_causal = bool(g.get('causal', False))
     voc = vocoders.VocoderPML(16000, 0.005, g['spec'], g['nm'])
     mod = modeltts_common.DCNNF0SpecNoiseFeatures(g['ctx'], voc, cfg)
     crit = networks_critic.Critic(voc, g['ctx'], cfg)
-    a = O.Arch(g['ctx'], g['spec'], g['nm'], g['H'], g['nctx'], g['kctx'], g['L'], g['C'], g['kt'], g['kf'])
+    a = O.Arch(g['ctx'], g['spec'], g['nm'], g['H'], g['nctx'], g['kctx'], g['L'], g['C'], g['kt'], g['kf'],
+               gen_gated=bool(g.get('gated')), gen_dilations=g.get('dils'), gen_causal=bool(g.get('causal', False)))
     gw = O.random_weights(O.generator_weight_shapes(a), seed=11)
     cw = O.random_weights(O.critic_weight_shapes(a), seed=12)
     assert mod.count_params() == O.count_params(O.generator_weight_shapes(a))
@@ -76,7 +85,7 @@ def f32(t):
     return t.to(torch.float32).cuda().contiguous()
 
 
-@pytest.mark.parametrize('geom', ['test', 'default', 'nocnn'])
+@pytest.mark.parametrize('geom', ['test', 'default', 'nocnn', 'gated', 'gated_dilated'])
 def test_predict_and_critic_forward(geom):
     cfg, voc, mod, crit, a, gw, cw, X, Y, al = build(geom)
     want = O.generator_forward(gw, a, X, training=False)
@@ -94,7 +103,7 @@ def test_predict_and_critic_forward(geom):
         close(t, w, 1e-6, 1e-7, 'weights untouched ' + k)
 
 
-@pytest.mark.parametrize('geom,errtype', [(g, e) for g in ('test', 'default', 'nocnn') for e in ('WLSWGAN', 'WGAN')] + [('mid', 'WLSWGAN')])
+@pytest.mark.parametrize('geom,errtype', [(g, e) for g in ('test', 'default', 'nocnn') for e in ('WLSWGAN', 'WGAN')] + [('mid', 'WLSWGAN'), ('gated', 'WLSWGAN'), ('gated_dilated', 'WLSWGAN')])
 def test_critic_and_generator_steps(geom, errtype):
     from percivaltts_amd import optimizertts_wgan, ops
     import contextlib
@@ -104,6 +113,9 @@ def test_critic_and_generator_steps(geom, errtype):
     cfg.train_wgan_critic_LSWGANtransidx = 30.0 if geom != 'nocnn' else 4.0
     opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype=errtype, critic=crit)
     opt.prepare()
+    if geom.startswith('gated'):
+        from percivaltts_amd import layers as _kl
+        assert sum(isinstance(l, _kl.GatedMultiply) for l in mod.kerasmodel.layers_list) == GEOMS[geom]['L']
     Xd, Yd, ald = f32(X), f32(Y), f32(al)
 
     # ---- critic: loss parts, every weight gradient, Keras-Adam update --------------------------------------

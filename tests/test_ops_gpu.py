@@ -562,6 +562,25 @@ def test_conv1d_bf16x6_split_product(ops, case):
     close(db_split, br.grad, rtol=2e-4, atol=3e-4, what='db')
 
 
+@pytest.mark.parametrize('shape', [(2, 12, 9, 4), (3, 50, 65, 4), (1, 7, 5, 3)])
+def test_gated_product(ops, shape):
+    """y = a * sigmoid(b) and its backward (ptts_gated_mul_fwd/bwd: the Multiply + sigmoid of the reference's gated
+    convolution, networktts.py:128-134) against torch fp64; the last shape has an element count that is no multiple of 4."""
+    g = gen(61)
+    a = torch.randn(*shape, generator=g, dtype=torch.float64) * 2
+    b = torch.randn(*shape, generator=g, dtype=torch.float64) * 3
+    dy = torch.randn(*shape, generator=g, dtype=torch.float64)
+    ar, br = ref(a, True), ref(b, True)
+    yr = ar * torch.sigmoid(br)
+    yr.backward(dy)
+    ad, bd = dev(a, True), dev(b, True)
+    yd = ops.gated_mul(ad, bd)
+    close(yd, yr, what='y')
+    yd.backward(dev(dy))
+    close(ad.grad, ar.grad, what='da')
+    close(bd.grad, br.grad, what='db')
+
+
 @pytest.mark.parametrize('shape', [(4, 6, 3), (2, 50, 256), (2, 10, 9, 4), (3, 7, 300)])
 def test_batchnorm_train_and_infer(ops, shape):
     g = gen(8)
