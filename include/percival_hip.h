@@ -57,6 +57,10 @@ extern "C" {
 const char* ptts_version(void);
 const char* ptts_device_arch(void);     /* "gfx950" : the only code object in the library */
 const char* ptts_last_error(void);      /* thread-local message of the last failure */
+/* Deterministic mode: reductions over workgroups in a fixed order only (no fp32 atomics: stream-K GEMM tiles, the
+ * thin weight-gradient kernel and the loss scalars take their single-pass forms).  Returns the previous setting. */
+int ptts_set_deterministic(int on);
+int ptts_get_deterministic(void);
 
 /* ---------------------------------------------------------------------------------------
  * 2D convolution over (time x frequency), NHWC, stride 1.

@@ -34,6 +34,8 @@ SIGNATURES = {
     'ptts_version': (ctypes.c_char_p, []),
     'ptts_device_arch': (ctypes.c_char_p, []),
     'ptts_last_error': (ctypes.c_char_p, []),
+    'ptts_set_deterministic': (c_i, [c_i]),
+    'ptts_get_deterministic': (c_i, []),
     'ptts_conv2d_fwd': (c_i, [c_p] * 7 + [c_i] * 10 + [c_f, c_p]),
     'ptts_conv2d_bwd_workspace_bytes': (c_sz, [c_i] * 8),
     'ptts_conv2d_bwd': (c_i, [c_p] * 11 + [c_p, c_sz] + [c_i] * 10 + [c_f, c_p]),
@@ -99,6 +101,8 @@ def lib():
             fn = getattr(l, name)   # AttributeError if the symbol is missing -> loud
             fn.restype = res
             fn.argtypes = args
+        if os.environ.get('PTTS_DETERMINISTIC', '0') == '1':
+            l.ptts_set_deterministic(1)
         _lib = l
     return _lib
 

@@ -8,6 +8,8 @@
 namespace ptts {
 
 void set_error(const char* fmt, ...);
+// ptts_set_deterministic(): fixed-order reductions only (no fp32 atomics between workgroups), at a price in speed
+bool deterministic();
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();

@@ -742,6 +742,7 @@ extern "C" int ptts_mean_scaled(const float* v, long long n, float sign, float* 
     if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) { set_error("mean_scaled: memset"); return PTTS_ELAUNCH; }
     int nb = (int)((n + 4095) / 4096);
     if (nb > 256) nb = 256;
+    if (deterministic()) nb = 1;      // one workgroup: one float add into the zeroed scalar
     hipLaunchKernelGGL(mean_scaled_kernel, dim3(nb), dim3(256), 0, st, v, n, sign / (float)n, out);
     return check_launch("mean_scaled");
 }
@@ -754,6 +755,7 @@ extern "C" int ptts_wlse_fwd(const float* y, const float* yhat, const float* w, 
     const long long n = rows * D;
     int nb = (int)((n + 4095) / 4096);
     if (nb > 512) nb = 512;
+    if (deterministic()) nb = 1;
     hipLaunchKernelGGL(wlse_fwd_kernel, dim3(nb), dim3(256), 0, st, y, yhat, w, n, D, 1.f / (float)n, out);
     return check_launch("wlse_fwd");
 }

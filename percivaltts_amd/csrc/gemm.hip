@@ -984,8 +984,9 @@ extern "C" int ptts_gemm(const float* A, const float* Bm, const float* bias, flo
     const long long slots = gemm_slots();
     const double eff_dp = (double)tiles / (double)(((tiles + slots - 1) / slots) * slots);
     long long workers;
-    // (atomic combination makes the last bits order-dependent: it is kept for the deep products only, K >= 4096)
-    if (g.ksteps >= 256 && eff_dp < 0.9) {
+    // (atomic combination makes the last bits order-dependent: it is kept for the deep products only, K >= 2048 -- the
+    // reference's own batch, 10 x 400 frames, is a reduction over K = 4000 and ran at 3.5 TF on 14 tiles without it)
+    if (g.ksteps >= 128 && eff_dp < 0.9 && !deterministic()) {
         workers = slots;
         if (workers > g.iters_total / 8) workers = g.iters_total / 8;
         if (workers < 1) workers = 1;

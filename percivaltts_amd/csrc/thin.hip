@@ -242,7 +242,7 @@ int thin_gemm_dispatch(const float* A, const float* Bm, const float* bias, float
         int rc = check_launch("thin_k");
         return rc ? rc : 1;
     }
-    if (transA == 1 && transB == 0 && N <= 2 && K >= 1024 && !bias && !out_mask && rows_per_seg >= K) {
+    if (transA == 1 && transB == 0 && N <= 2 && K >= 1024 && !bias && !out_mask && rows_per_seg >= K && !deterministic()) {
         if (!accumulate) {
             hipError_t e;
             if (ldc == N) e = hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), st);

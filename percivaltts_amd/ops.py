@@ -79,6 +79,19 @@ def _prep(v):
 # ----------------------------------------------------------------------------------------------
 class _Flags(object):
     skip_param_grads = False
+    deterministic = os.environ.get('PTTS_DETERMINISTIC', '0') == '1'
+
+
+def deterministic(on=None):
+    """Deterministic mode (PTTS_DETERMINISTIC=1): every reduction over workgroups runs in a fixed order -- no fp32 atomics.
+    The stream-K GEMM tiles, the grouped / frame-major / bf16x6 weight-gradient kernels, the split context Conv1D and the
+    grouped conv2d reduction (all of which combine partial sums with atomics) give way to their single-pass forms; two runs
+    of the same step then agree bit for bit, at a price in speed (tests/test_fullsize_gpu.py, the resume-parity test).
+    Returns the setting; `on=None` only reads it."""
+    if on is not None:
+        _Flags.deterministic = bool(on)
+    _hip.lib().ptts_set_deterministic(1 if _Flags.deterministic else 0)
+    return _Flags.deterministic
 
 
 @contextlib.contextmanager
@@ -475,7 +488,7 @@ class Conv2dFn(torch.autograd.Function):
 
 
 def _conv2d_can_defer(ctx, need_w, need_b):
-    return _Deferred.active and (not need_w or ctx.gw is not None) and (not need_b or ctx.gb is not None)
+    return _Deferred.active and not _Flags.deterministic and (not need_w or ctx.gw is not None) and (not need_b or ctx.gb is not None)
 
 
 class Conv2dBwdDataFn(torch.autograd.Function):
@@ -500,7 +513,7 @@ class Conv2dBwdDataFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             cot_dy = _conv2d_fwd_raw(u, w, None, None, None, msk, m2, alpha, dil_t, pad_mode)
         if ctx.needs_input_grad[2]:
-            if _Deferred.active and ctx.gw is not None and \
+            if _Deferred.active and not _Flags.deterministic and ctx.gw is not None and \
                     _conv2d_bwd_deferred(dy, u, w, msk, m2, alpha, dil_t, pad_mode, False, ctx.gw, None) is not False:
                 return cot_dy, None, None, None, None, None, None, None
             _, cot_w, _, _, _ = _conv2d_bwd_raw(dy, u, w, None, None, msk, m2, alpha, dil_t, pad_mode,
@@ -576,8 +589,8 @@ class DenseFn(torch.autograd.Function):
                 dx = dx2.view(x.shape)
             elif need_aff:
                 _, dscale, dshift = _dense_bwd_data(dy2, x2, w, mode, scale, shift, alpha, True)
-            if need_w and _Deferred.active and ctx.gw is not None and N > 4 and (not need_b or ctx.gb is not None) \
-                    and M >= 4096 and (scale is None or mode == IN_LRELU):
+            if need_w and _Deferred.active and not _Flags.deterministic and ctx.gw is not None and N > 4 and (not need_b or ctx.gb is not None) \
+                    and M >= 2048 and (scale is None or mode == IN_LRELU):
                 # queued for the grouped launch, which adds into the .grad buffers itself (no dw / db for autograd)
                 _defer_wgrad(x2, dy2, ctx.gw, ctx.gb if need_b else None, K, N, M, mode, scale, shift, None, alpha)
                 need_w = need_b = False
@@ -620,7 +633,7 @@ class DenseBwdDataFn(torch.autograd.Function):
             gemm_raw(u2, w, cot_dy, M, N, K, mode=m2, mask_src=msk, alpha=alpha)
             cot_dy = cot_dy.view(dy.shape)
         if ctx.needs_input_grad[2]:
-            if _Deferred.active and ctx.gw is not None and N > 4 and M >= 4096:
+            if _Deferred.active and not _Flags.deterministic and ctx.gw is not None and N > 4 and M >= 2048:
                 _defer_wgrad(u2, dy.view(M, N), ctx.gw, None, K, N, M, m2, None, None, msk, alpha)
             else:
                 cot_w = torch.empty_like(w)
@@ -806,7 +819,7 @@ class Conv1dFn(torch.autograd.Function):
             ap, y = pre
         else:
             y = torch.empty((B, T, N), dtype=torch.float32, device=a.device)
-            if _C1Split.enabled and _C1Split.eligible(a, w):
+            if _C1Split.enabled and not _Flags.deterministic and _C1Split.eligible(a, w):
                 xp, Cp = _C1Split.frames(a, pl, KW - 1 - pl)
                 wp = _C1Split.kernel(w)
                 call('ptts_conv1d_bf16x6', ptr(xp[0]), ptr(xp[1]), ptr(xp[2]), ptr(wp[0]), ptr(wp[1]), ptr(wp[2]), ptr(b), ptr(y),
@@ -833,7 +846,7 @@ class Conv1dFn(torch.autograd.Function):
         dy = dy.contiguous()
         da = dw = db = None
         need_b = ctx.has_b and ctx.needs_input_grad[2] and not _Flags.skip_param_grads
-        if ctx.needs_input_grad[1] and not _Flags.skip_param_grads and _C1Split.enabled and dy.is_cuda \
+        if ctx.needs_input_grad[1] and not _Flags.skip_param_grads and _C1Split.enabled and not _Flags.deterministic and dy.is_cuda \
                 and _C1Split.eligible_wgrad(KW, N) and ap.numel() > 0:
             # the weight gradient as a bf16x6 split product over frame-major planes (csrc/split.hip)
             xt, Crows, Pp = _C1Split.frames_t(ctx.x_src, ap, KW)
@@ -841,8 +854,8 @@ class Conv1dFn(torch.autograd.Function):
             dw = torch.empty_like(w)
             call('ptts_conv1d_wgrad_bf16x6', ptr(xt[0]), ptr(xt[1]), ptr(xt[2]), ptr(yt[0]), ptr(yt[1]), ptr(yt[2]), ptr(dw),
                  B, T, KW, Cin, N, Crows, Pp, stream(), tag=(B, T, KW, Cin, N))
-        elif ctx.needs_input_grad[1] and not _Flags.skip_param_grads and _C1WgradT.enabled and dy.is_cuda \
-                and _C1Split.eligible_wgrad(KW, N) and ap.numel() > 0 and B * T >= 4096:
+        elif ctx.needs_input_grad[1] and not _Flags.skip_param_grads and _C1WgradT.enabled and not _Flags.deterministic and dy.is_cuda \
+                and _C1Split.eligible_wgrad(KW, N) and ap.numel() > 0 and B * T >= 2048:
             # exact fp32 over frame-major operands (csrc/conv1d_wgrad.hip); the bias gradient comes with it
             xt, Crows, Pp = _C1WgradT.frames_t(ctx.x_src, ap, KW)
             yt = torch.empty((N, Pp), dtype=torch.float32, device=dy.device)

@@ -72,6 +72,12 @@ class OptimizerTTS:
         printfn('    saving training state in {} ...'.format(fstate), end='')
         sys.stdout.flush()
         self.saveTrainingStateLossSpecific(fstate)
+        # beyond the reference's numpy state: torch's generators (the interpolation weights of the gradient penalty are
+        # drawn on the device), so that a resumed run continues the SAME random sequence
+        extras = dict(extras)
+        extras['torch_rng_cpu'] = torch.get_rng_state().numpy()
+        if torch.cuda.is_available():
+            extras['torch_rng_cuda'] = torch.cuda.get_rng_state().cpu().numpy()
         with open(fstate + '.model.cfgextras.pkl', 'wb') as f:
             pickle.dump([self.cfg, extras, np.random.get_state()], f)
         print(' done')
@@ -143,6 +149,10 @@ class OptimizerTTS:
             print('    reloading previous training state ...')
             savedcfg, extras, rngstate = self.loadTrainingState(stem + '-trainingstate-last.h5')
             np.random.set_state(rngstate)
+            if 'torch_rng_cpu' in extras:
+                torch.set_rng_state(torch.as_tensor(extras['torch_rng_cpu'], dtype=torch.uint8))
+            if 'torch_rng_cuda' in extras and torch.cuda.is_available():
+                torch.cuda.set_rng_state(torch.as_tensor(extras['torch_rng_cuda'], dtype=torch.uint8))
             costs = extras['costs']
             epochs_modelssaved = extras['epochs_modelssaved']
             epochs_durs = extras['epochs_durs']

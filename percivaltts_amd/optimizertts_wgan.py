@@ -393,3 +393,6 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         if os.path.exists(fstate + '.critic.weights.npz'):
             with np.load(fstate + '.critic.weights.npz') as z:
                 self.critic_net.set_weights([z['arr_{}'.format(i)] for i in range(len(z.files))])
+        # the weights changed behind every weight-keyed cache (bf16 planes, Toeplitz tables)
+        self.gen_opti.flat.epoch += 1
+        self.critic_opti.flat.epoch += 1

@@ -306,6 +306,63 @@ def test_train_step_with_the_bf16x6_context_conv_matches_the_fp32_one(setup):
     assert rel_l2(gg1, gg0) < 1e-3, rel_l2(gg1, gg0)
 
 
+def test_deterministic_mode_is_bit_reproducible_at_full_size(setup):
+    """ops.deterministic(True) (PTTS_DETERMINISTIC=1): no reduction over workgroups uses fp32 atomics -- stream-K tiles, the
+    grouped / frame-major / bf16x6 weight gradients, the split context Conv1D and the grouped conv2d reduction give way to
+    fixed-order forms.  Two runs of the same critic step and of the same generator step at BASELINE configs[1] size then
+    agree BIT FOR BIT (losses and every gradient), and they agree with the default (atomic) paths to 1e-4 relative L2 --
+    the spread the atomics' summation order leaves, now measured against a fixed reference instead of against itself."""
+    from percivaltts_amd import ops
+    cfg, opt, crit, X, Y = setup
+    g = torch.Generator().manual_seed(8)
+    alpha = torch.rand(B, generator=g).cuda()
+    with torch.no_grad():
+        fake = opt._fake_sample(X, True).detach()
+
+    def gen_grads():
+        cps = opt.critic_opti.flat.params
+        for p in cps: p.requires_grad_(False)
+        try:
+            opt.gen_opti.zero_grad()
+            with ops.deferred_weight_grads():
+                tot, _ = opt.generator_loss(X, Y, training=True)
+                tot.backward()
+            torch.cuda.synchronize()
+            return tot.detach().clone(), opt.gen_opti.flat.grad.detach().clone()
+        finally:
+            for p in cps: p.requires_grad_(True)
+
+    moving = [t for k, t in opt._model.kerasmodel.weights() if 'moving' in k]
+    moving0 = [t.detach().clone() for t in moving]
+    def restore():
+        for dst, src in zip(moving, moving0): dst.copy_(src)
+
+    def critic_grads():
+        opt.critic_opti.zero_grad()
+        with ops.deferred_weight_grads():
+            total, _ = opt.critic_loss(X, Y, alpha, training=True, fake=fake)
+            total.backward()
+        torch.cuda.synchronize()
+        return total.detach().clone(), opt.critic_opti.flat.grad.detach().clone()
+
+    try:
+        t_def, g_def = critic_grads()
+        restore(); lg_def, gg_def = gen_grads()
+        ops.deterministic(True)
+        t1, g1 = critic_grads(); t2, g2 = critic_grads()
+        restore(); lg1, gg1 = gen_grads()
+        restore(); lg2, gg2 = gen_grads()
+    finally:
+        ops.deterministic(False)
+        restore()
+    assert torch.equal(t1, t2) and torch.equal(g1, g2), 'critic step not reproducible: rel L2 {:.3e}'.format(rel_l2(g2, g1))
+    assert torch.equal(lg1, lg2) and torch.equal(gg1, gg2), 'generator step not reproducible: rel L2 {:.3e}'.format(rel_l2(gg2, gg1))
+    close(t_def, t1, 1e-5, 1e-6, 'critic loss, default vs deterministic paths')
+    close(lg_def, lg1, 1e-5, 1e-6, 'generator loss, default vs deterministic paths')
+    assert rel_l2(g_def, g1) < 1e-4, rel_l2(g_def, g1)
+    assert rel_l2(gg_def, gg1) < 5e-4, rel_l2(gg_def, gg1)
+
+
 def test_gated_dilated_causal_generator_at_T2000():
     """BASELINE configs[4] at its real length: the generator's spectral branch from gated convolutions (pGCNN2D,
     networktts.py:128-134) with time dilations 1,2,4,8,1,2,4,8 and causal padding (build extensions), T = 2000.

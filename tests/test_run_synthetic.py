@@ -48,6 +48,54 @@ def test_run_training_continue_generate(tmp_path, monkeypatch):
     assert (y[:, 130:] > 0).all() and (y[:, 130:] < 1).all()     # sigmoid noise-mask head
 
 
+def test_resumed_run_reproduces_the_uninterrupted_one(tmp_path, monkeypatch):
+    """--continue (reference optimizertts.py:197-211): 4 epochs straight against 2 epochs + a resumed run of 2 more, in
+    deterministic mode (ops.deterministic: fixed-order reductions).  Generator and critic weights, both Adam states, the
+    BatchNorm moving statistics, the per-epoch costs and the generator-update counter must agree -- the training state
+    carries the critic's weights, the device RNG and `generator_updates` beyond what the reference saves."""
+    import importlib, pickle
+    from percivaltts_amd import ops
+    monkeypatch.setenv('PERCIVAL_CORPUS', str(tmp_path / 'corpus'))
+    import percivaltts_amd.run as run
+    ops.deterministic(True)
+    try:
+        states = {}
+        for name, plan in (('straight', [(4, False)]), ('resumed', [(2, False), (4, True)])):
+            wd = tmp_path / name
+            wd.mkdir()
+            monkeypatch.chdir(wd)
+            run = importlib.reload(run)
+            run.cfg.id_valid_start = 8; run.cfg.id_valid_nb = 1; run.cfg.id_test_nb = 1
+            run.cfg.train_min_nbepochs = 1; run.cfg.train_cancel_nodecepochs = 10
+            run.cfg.train_nbepochs_scalewdata = False
+            run.cfg.train_batch_size = 2; run.cfg.arch_hiddenwidth = 8; run.cfg.arch_gen_nbcnnlayers = 2
+            run.cfg.train_batch_lengthmax = 60
+            if not os.path.exists(run.cfg.fileids):
+                run.synthesize_corpus(nfiles=10, minlen=90, maxlen=140)
+            for (nep, cont) in plan:
+                np.random.seed(123); __import__('torch').manual_seed(123)
+                if cont:
+                    np.random.seed(999); __import__('torch').manual_seed(999)      # a resumed run must not depend on the fresh seeds
+                run.cfg.train_max_nbepochs = nep
+                run.training(cont=cont)
+            st = 'model-trainingstate-last.h5'
+            with open(st + '.model.cfgextras.pkl', 'rb') as f:
+                _, extras, _ = pickle.load(f)
+            states[name] = {k: dict(np.load(st + k)) for k in ('.model.weights.npz', '.critic.weights.npz', '.generator.optimizer.npz', '.critic.optimizer.npz')}
+            states[name]['extras'] = extras
+    finally:
+        ops.deterministic(False)
+    a, b = states['straight'], states['resumed']
+    assert a['extras']['epoch'] == b['extras']['epoch'] == 4
+    assert a['extras']['generator_updates'] == b['extras']['generator_updates'] > 0
+    for k in ('model_training', 'critic_training', 'critic_validation', 'model_validation', 'model_rmse_validation'):
+        np.testing.assert_allclose(b['extras']['costs'][k], a['extras']['costs'][k], rtol=1e-6, atol=1e-7, err_msg=k)
+    for part in ('.model.weights.npz', '.critic.weights.npz', '.generator.optimizer.npz', '.critic.optimizer.npz'):
+        assert sorted(a[part]) == sorted(b[part])
+        for k in a[part]:
+            np.testing.assert_allclose(b[part][k], a[part][k], rtol=1e-6, atol=1e-8, err_msg=part + ':' + k)
+
+
 @pytest.mark.gpu
 def test_batch_prefetcher_device_mode():
     """data.BatchPrefetcher on the GPU: pinned slots are reused only after their copy completed (more batches than
