@@ -50,6 +50,7 @@ def parse():
     ap.add_argument('--fp32-mfma', action='store_true', help='context Conv1D forward and weight gradient on the fp32 MFMA pipe instead of the bf16x6 split products')
     ap.add_argument('--no-reference-shape', action='store_true', help="skip the leg at the reference's own training geometry (B=10, T=400, 425 -> 163)")
     ap.add_argument('--no-unreduced', action='store_true', help='skip the timed loop with every exact work reduction switched off')
+    ap.add_argument('--sync-bn', action='store_true', help='data parallelism: BatchNorm statistics all-reduced over the ranks (default: per rank)')
     ap.add_argument('--no-gated-leg', action='store_true', help='skip the BASELINE configs[4] leg (gated dilated-causal generator, T=2000)')
     ap.add_argument('--gated-batch', type=int, default=64)
     ap.add_argument('--no-roofline', action='store_true')
@@ -243,6 +244,7 @@ def build_optimizer(args, ctx, spec, nm, batch, errtype, gated=False):
     cfg.train_wgan_reuse_ctx_conv = not args.no_ctx_reuse
     cfg.train_wgan_early_critic = not args.no_early_critic
     cfg.train_wgan_split_bf16 = not args.fp32_mfma
+    cfg.train_sync_batchnorm = bool(getattr(args, 'sync_bn', False))
     voc = vocoders.VocoderPML(16000, 0.005, spec, nm)
     with contextlib.redirect_stdout(io.StringIO()):
         mod = modeltts_common.DCNNF0SpecNoiseFeatures(ctx, voc, cfg)

@@ -21,6 +21,11 @@
 // block (72 bins) and the dilation is a template parameter, so that every LDS address of the inner loops is one base
 // register plus an immediate: the first version spent as many vector instructions on addresses as the matrix pipe spent
 // cycles on the products (rocprofv3 SQ_INSTS_VALU, gpurun_out/c2m_pmc).
+//
+// bf16 storage (BASELINE configs[2]): the same kernels with NPL = 1 plane per operand -- activations / gradients may lie in
+// HBM as bf16 (8 bytes per pixel) or fp32, are rounded to bf16 once on their way into the LDS, the kernel's bf16 copy of
+// the weights is the single table plane, ONE product per MFMA position instead of six, fp32 accumulation, and the result is
+// stored as bf16 or fp32 as the caller asks.  Weight gradients stay fp32.
 #include "common.h"
 #include <cstdlib>
 
@@ -40,8 +45,12 @@ constexpr int KT = 5;
 constexpr int GPB = 17;        // bin groups (of 4 bins) per block: F = 65 is one block
 constexpr int NPART = KT * KF * 16 + 4 + 8;   // row of partial sums: the layout of conv2d.hip's backward
 
-// six products (activation plane, weight plane), smallest first
+// six products (activation plane, weight plane), smallest first; with one plane per operand (bf16 arithmetic) the last one only
 #define C2M_PRODUCTS(X) X(2, 0) X(1, 1) X(0, 2) X(1, 0) X(0, 1) X(0, 0)
+#define C2M_PRODUCTS_NPL(NPL, X) do { if (NPL == 3) { X(2, 0) X(1, 1) X(0, 2) X(1, 0) X(0, 1) } X(0, 0) } while (0)
+
+// dtype flags of the entry points (bit set = that tensor is bf16 in HBM)
+constexpr int DT_IN = 1, DT_OUT = 2, DT_DY = 4;
 
 // measurement hooks (tools/conv2d_mfma_probe.py): bit 0 skip the staging, bit 1 skip the MFMA phase, bit 2 skip the
 // stores, bit 3 write s_memtime stamps of the phases of every workgroup to dbg_buf[block][8]
@@ -67,7 +76,7 @@ __device__ __forceinline__ void split3(f32x4 v, bf16x4& h1, bf16x4& h2, bf16x4& 
 // lane (li = lane & 15, lg = lane >> 4): m = li -> so = li >> 2, oc = li & 3; element e: j = 2 lg + (e >> 2), ic = e & 3.
 // One launch builds both tables: block 0 the forward one, block 1 the transposed one.
 // ------------------------------------------------------------------------------------------------------------
-__global__ void toeplitz_table_kernel(const float* __restrict__ w, u16* __restrict__ tab_fwd, u16* __restrict__ tab_bwd) {
+__global__ void toeplitz_table_kernel(const float* __restrict__ w, u16* __restrict__ tab_fwd, u16* __restrict__ tab_bwd, int npl) {
     const int transposed = blockIdx.x;
     u16* tab = transposed ? tab_bwd : tab_fwd;
     if (!tab) return;
@@ -87,10 +96,12 @@ __global__ void toeplitz_table_kernel(const float* __restrict__ w, u16* __restri
     for (int h = 0; h < 2; ++h) {
         bf16x4 h1, h2, h3;
         split3(v[h], h1, h2, h3);
-        u16* d = tab + ((size_t)(kt * NP) * 64 + lane) * 8 + 4 * h;
+        u16* d = tab + ((size_t)(kt * npl) * 64 + lane) * 8 + 4 * h;
         *reinterpret_cast<bf16x4*>(d) = h1;
-        *reinterpret_cast<bf16x4*>(d + 64 * 8) = h2;
-        *reinterpret_cast<bf16x4*>(d + 2 * 64 * 8) = h3;
+        if (npl == 3) {
+            *reinterpret_cast<bf16x4*>(d + 64 * 8) = h2;
+            *reinterpret_cast<bf16x4*>(d + 2 * 64 * 8) = h3;
+        }
     }
 }
 
@@ -161,12 +172,24 @@ struct Pref {
 };
 
 // the loads of one tile: rows t_org .., bins f_org ..; zero outside the image
+__device__ __forceinline__ f32x4 load_px(const void* base, int off /*elements*/, bool bf16) {
+    if (bf16) return __builtin_convertvector(*reinterpret_cast<const bf16x4*>(reinterpret_cast<const u16*>(base) + off), f32x4);
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + off);
+}
+__device__ __forceinline__ void store_px(void* base, long long off /*elements*/, f32x4 v, bool bf16) {
+    if (bf16) *reinterpret_cast<bf16x4*>(reinterpret_cast<u16*>(base) + off) = __builtin_convertvector(v, bf16x4);
+    else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + off) = v;
+}
+__device__ __forceinline__ const void* ptr_at(const void* p, long long off /*elements*/, bool bf16) {
+    return bf16 ? (const void*)(reinterpret_cast<const u16*>(p) + off) : (const void*)(reinterpret_cast<const float*>(p) + off);
+}
+
 template <class ST, bool MASK>
-__device__ __forceinline__ void pref_load(Pref<ST::NB, MASK>& pf, const Slots<ST>& sl, const float* __restrict__ src,
-                                          const float* __restrict__ msk, long long img, int t_org, int f_org, int T, int F,
+__device__ __forceinline__ void pref_load(Pref<ST::NB, MASK>& pf, const Slots<ST>& sl, const void* __restrict__ src,
+                                          const void* __restrict__ msk, bool bf16, long long img, int t_org, int f_org, int T, int F,
                                           int f_end /*bins >= f_end are staged as zeros (f_end <= F)*/) {
-    const float* base = src + (img + (long long)t_org * F + f_org) * C;         // wave-uniform
-    const float* mbase = MASK ? msk + (img + (long long)t_org * F + f_org) * C : nullptr;
+    const void* base = ptr_at(src, (img + (long long)t_org * F + f_org) * C, bf16);         // wave-uniform
+    const void* mbase = MASK ? ptr_at(msk, (img + (long long)t_org * F + f_org) * C, bf16) : nullptr;
 #pragma unroll
     for (int u = 0; u < ST::NB; ++u) {
         const int r = sl.rc[u] >> 8, c = sl.rc[u] & 255;
@@ -175,8 +198,8 @@ __device__ __forceinline__ void pref_load(Pref<ST::NB, MASK>& pf, const Slots<ST
         if (MASK) pf.m[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (ok) {
             const int off = (r * F + c) * C;
-            pf.v[u] = *reinterpret_cast<const f32x4*>(base + off);
-            if (MASK) pf.m[u] = *reinterpret_cast<const f32x4*>(mbase + off);
+            pf.v[u] = load_px(base, off, bf16);
+            if (MASK) pf.m[u] = load_px(mbase, off, bf16);
         }
     }
 }
@@ -184,7 +207,7 @@ __device__ __forceinline__ void pref_load(Pref<ST::NB, MASK>& pf, const Slots<ST
 // registers -> transform -> three bf16 planes in LDS.  Slots outside the image were loaded as zeros and stay zero under
 // every transform but the BatchNorm-affine one, which gets its own select.  `sum` (optional) accumulates the raw values
 // of staged rows [sum_r0, sum_r0 + 16), staged bins [2, sum_c1).
-template <class ST, int MODE>
+template <class ST, int MODE, int NPL>
 __device__ __forceinline__ void pref_commit(const Pref<ST::NB, MODE == PTTS_IN_MASKMUL>& pf, const Slots<ST>& sl,
                                             u16* __restrict__ planes, int t_org, int f_org, int T, int F,
                                             const float* __restrict__ in_scale, const float* __restrict__ in_shift,
@@ -217,12 +240,16 @@ __device__ __forceinline__ void pref_commit(const Pref<ST::NB, MODE == PTTS_IN_M
 #pragma unroll
             for (int e = 0; e < 4; ++e) a[e] = a[e] * (pf.m[u][e] > 0.f ? 1.f : alpha);
         }
-        bf16x4 h1, h2, h3;
-        split3(a, h1, h2, h3);
         u16* d = planes + sl.dst[u];
-        *reinterpret_cast<bf16x4*>(d) = h1;
-        *reinterpret_cast<bf16x4*>(d + ST::PS) = h2;
-        *reinterpret_cast<bf16x4*>(d + 2 * ST::PS) = h3;
+        if (NPL == 3) {
+            bf16x4 h1, h2, h3;
+            split3(a, h1, h2, h3);
+            *reinterpret_cast<bf16x4*>(d) = h1;
+            *reinterpret_cast<bf16x4*>(d + ST::PS) = h2;
+            *reinterpret_cast<bf16x4*>(d + 2 * ST::PS) = h3;
+        } else {
+            *reinterpret_cast<bf16x4*>(d) = __builtin_convertvector(a, bf16x4);       // the one rounding of bf16 arithmetic
+        }
     }
 }
 
@@ -235,10 +262,10 @@ __device__ __forceinline__ void pref_commit(const Pref<ST::NB, MODE == PTTS_IN_M
 // one pass of a wave over N consecutive bin groups g0 .. g0+N-1 of the staged block: straight-line code (a branch around
 // an MFMA group makes the compiler carry the accumulators through register copies), one LDS base register per parity of
 // the group, everything else immediates
-template <class ST, int DIL, int N, bool OUTMASK>
+template <class ST, int DIL, int N, bool OUTMASK, int NPL>
 __device__ __forceinline__ void fwd_pass(const u16* __restrict__ planes, const u16* __restrict__ wl, int g0, int lane,
-                                         f32x4 bv, const float* __restrict__ mrow, float* __restrict__ yrow, int fbase,
-                                         int F, bool rowok, float alpha, bool store) {
+                                         f32x4 bv, const void* __restrict__ mrow, void* __restrict__ yrow, bool out_bf16,
+                                         int fbase, int F, bool rowok, float alpha, bool store) {
     const int li = lane & 15, lg = lane >> 4;
     f32x4 acc[N], mv[OUTMASK ? N : 1];
 #pragma unroll
@@ -250,7 +277,7 @@ __device__ __forceinline__ void fwd_pass(const u16* __restrict__ planes, const u
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             mv[j] = f32x4{1.f, 1.f, 1.f, 1.f};
-            if (rowok && f0 + 4 * j < F) mv[j] = *reinterpret_cast<const f32x4*>(mrow + (f0 + 4 * j) * C);
+            if (rowok && f0 + 4 * j < F) mv[j] = load_px(mrow, (f0 + 4 * j) * C, out_bf16);
         }
     }
     // unit of the lane in group g: 2 g + lg; groups two apart are four units (32 elements) apart
@@ -259,19 +286,19 @@ __device__ __forceinline__ void fwd_pass(const u16* __restrict__ planes, const u
     const u16* wa = wl + lane * 8;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
-        bf16x8 a[NP], bq[N][NP];
+        bf16x8 a[NPL], bq[N][NPL];
 #pragma unroll
-        for (int q = 0; q < NP; ++q) a[q] = *reinterpret_cast<const bf16x8*>(wa + (kt * NP + q) * 64 * 8);
+        for (int q = 0; q < NPL; ++q) a[q] = *reinterpret_cast<const bf16x8*>(wa + (kt * NPL + q) * 64 * 8);
 #pragma unroll
         for (int j = 0; j < N; ++j)
 #pragma unroll
-            for (int p = 0; p < NP; ++p)
+            for (int p = 0; p < NPL; ++p)
                 bq[j][p] = *reinterpret_cast<const bf16x8*>(((j & 1) ? b1 : b0) + p * ST::PS + kt * DIL * ST::RS + (j >> 1) * 32);
         // product-major: consecutive MFMAs go to different accumulators
 #define C2M_MM(PA, PW)                                                                                  \
         _Pragma("unroll") for (int j = 0; j < N; ++j)                                                   \
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PW], bq[j][PA], acc[j], 0, 0, 0);
-        C2M_PRODUCTS(C2M_MM)
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PW < NPL ? PW : 0], bq[j][PA < NPL ? PA : 0], acc[j], 0, 0, 0);
+        C2M_PRODUCTS_NPL(NPL, C2M_MM);
 #undef C2M_MM
     }
     if (rowok && store) {
@@ -283,22 +310,23 @@ __device__ __forceinline__ void fwd_pass(const u16* __restrict__ planes, const u
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = o[e] * (mv[j][e] > 0.f ? 1.f : alpha);
                 }
-                *reinterpret_cast<f32x4*>(yrow + (f0 + 4 * j) * C) = o;
+                store_px(yrow, (f0 + 4 * j) * C, o, out_bf16);
             }
         }
     }
 }
 
-template <int DIL, int MODE, bool OUTMASK>
+template <int DIL, int MODE, bool OUTMASK, int NPL>
 __global__ __launch_bounds__(THREADS, DIL == 1 ? 3 : (DIL == 2 ? 2 : 1)) void fwd_kernel(
-    const float* __restrict__ x, const u16* __restrict__ tab, const float* __restrict__ bias,
-    const float* __restrict__ in_scale, const float* __restrict__ in_shift, const float* __restrict__ mask_src,
-    const float* __restrict__ out_mask, float* __restrict__ y, Shape s, float alpha, int dbg, unsigned long long* dbg_buf) {
+    const void* __restrict__ x, const u16* __restrict__ tab, const float* __restrict__ bias,
+    const float* __restrict__ in_scale, const float* __restrict__ in_shift, const void* __restrict__ mask_src,
+    const void* __restrict__ out_mask, void* __restrict__ y, int dt, Shape s, float alpha, int dbg, unsigned long long* dbg_buf) {
     typedef Stage<4 * GPB + 4, 16 + (KT - 1) * DIL> ST;
     extern __shared__ __attribute__((aligned(16))) u16 lds[];
     stamp(dbg_buf, dbg, 0);
     u16* planes = lds;
-    u16* wl = lds + NP * ST::PS;
+    u16* wl = lds + NPL * ST::PS;
+    const bool in_bf16 = (dt & DT_IN) != 0, out_bf16 = (dt & DT_OUT) != 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr bool MASK = MODE == PTTS_IN_MASKMUL;
@@ -309,9 +337,9 @@ __global__ __launch_bounds__(THREADS, DIL == 1 ? 3 : (DIL == 2 ? 2 : 1)) void fw
     Pref<ST::NB, MASK> pf;
     TilePos pos = tile_pos(s, tile < s.ntiles ? tile : 0);
     if (tile < s.ntiles && !(dbg & DBG_NOSTAGE))
-        pref_load<ST, MASK>(pf, sl, x, mask_src, pos.img, pos.t0 - s.pad_t, 4 * pos.g_base - 2, s.T, s.F, s.F);
-    // the table: KT*NP KB, 16 bytes per lane and copy, once per workgroup
-    for (int i = tid; i < KT * NP * 64; i += THREADS)
+        pref_load<ST, MASK>(pf, sl, x, mask_src, in_bf16, pos.img, pos.t0 - s.pad_t, 4 * pos.g_base - 2, s.T, s.F, s.F);
+    // the table: KT*NPL KB, 16 bytes per lane and copy, once per workgroup
+    for (int i = tid; i < KT * NPL * 64; i += THREADS)
         *reinterpret_cast<bf16x8*>(wl + (size_t)i * 8) = *reinterpret_cast<const bf16x8*>(tab + (size_t)i * 8);
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias) bv = *reinterpret_cast<const f32x4*>(bias);
@@ -320,7 +348,7 @@ __global__ __launch_bounds__(THREADS, DIL == 1 ? 3 : (DIL == 2 ? 2 : 1)) void fw
     int it = 0;
     while (tile < s.ntiles) {
         if (!(dbg & DBG_NOSTAGE))
-            pref_commit<ST, MODE>(pf, sl, planes, pos.t0 - s.pad_t, 4 * pos.g_base - 2, s.T, s.F, in_scale, in_shift, alpha, 0, 0, nullptr);
+            pref_commit<ST, MODE, NPL>(pf, sl, planes, pos.t0 - s.pad_t, 4 * pos.g_base - 2, s.T, s.F, in_scale, in_shift, alpha, 0, 0, nullptr);
         if (it == 0) stamp(dbg_buf, dbg, 1);
         __syncthreads();
         if (it == 0) stamp(dbg_buf, dbg, 2);
@@ -329,7 +357,7 @@ __global__ __launch_bounds__(THREADS, DIL == 1 ? 3 : (DIL == 2 ? 2 : 1)) void fw
         if (next < s.ntiles) {
             pos = tile_pos(s, next);
             if (!(dbg & DBG_NOSTAGE))
-                pref_load<ST, MASK>(pf, sl, x, mask_src, pos.img, pos.t0 - s.pad_t, 4 * pos.g_base - 2, s.T, s.F, s.F);
+                pref_load<ST, MASK>(pf, sl, x, mask_src, in_bf16, pos.img, pos.t0 - s.pad_t, 4 * pos.g_base - 2, s.T, s.F, s.F);
         }
         // the wave's share of the block's bin groups: a contiguous run, in passes of at most NMAX groups of nearly equal
         // size (register budget: a pass keeps N x 3 activation fragments)
@@ -342,12 +370,12 @@ __global__ __launch_bounds__(THREADS, DIL == 1 ? 3 : (DIL == 2 ? 2 : 1)) void fw
         const int t = cur.t0 + myrow;
         const bool rowok = t < s.T;
         const long long rowoff = (cur.img + (long long)t * s.F) * C;
-        float* yrow = y + rowoff;
-        const float* mrow = OUTMASK ? out_mask + rowoff : nullptr;
+        void* yrow = const_cast<void*>(ptr_at(y, rowoff, out_bf16));
+        const void* mrow = OUTMASK ? ptr_at(out_mask, rowoff, out_bf16) : nullptr;
         const int fbase = 4 * cur.g_base;
         while (n > 0) {
             const int m = (n + npass - 1) / npass;
-#define C2M_PASS(NN) fwd_pass<ST, DIL, NN, OUTMASK>(planes, wl, gl, lane, bv, mrow, yrow, fbase, s.F, rowok, alpha, store)
+#define C2M_PASS(NN) fwd_pass<ST, DIL, NN, OUTMASK, NPL>(planes, wl, gl, lane, bv, mrow, yrow, out_bf16, fbase, s.F, rowok, alpha, store)
             switch (m) {
                 case 1: C2M_PASS(1); break;
                 case 2: C2M_PASS(2); break;
@@ -385,17 +413,18 @@ __device__ __forceinline__ bf16x4 tr_read(const u16* p) {
 }
 __device__ __forceinline__ bf16x8 cat(bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
 
-template <int DIL, int MODE>
+template <int DIL, int MODE, int NPL>
 __global__ __launch_bounds__(THREADS, DIL <= 2 ? 2 : 1) void wgrad_kernel(
-    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mask_src,
-    float* __restrict__ partials, Shape s, float alpha, int dbg, unsigned long long* dbg_buf) {
+    const void* __restrict__ x, const void* __restrict__ dy, const void* __restrict__ mask_src,
+    float* __restrict__ partials, int dt, Shape s, float alpha, int dbg, unsigned long long* dbg_buf) {
     typedef Stage<4 * (GPB + 1) + 4, 16 + (KT - 1) * DIL> SD;      // dy tile with its time halo
     typedef Stage<4 * (GPB + 1) + 4, 16> SA;                       // activation tile
     static_assert(SD::RS == SA::RS, "one row stride");
     extern __shared__ __attribute__((aligned(16))) u16 lds[];
     stamp(dbg_buf, dbg, 0);
     u16* dpl = lds;
-    u16* apl = lds + NP * SD::PS;
+    u16* apl = lds + NPL * SD::PS;
+    const bool x_bf16 = (dt & DT_IN) != 0, dy_bf16 = (dt & DT_DY) != 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
@@ -422,14 +451,14 @@ __global__ __launch_bounds__(THREADS, DIL <= 2 ? 2 : 1) void wgrad_kernel(
     Pref<SA::NB, MASK> pa;
     TilePos pos = tile_pos(s, tile < s.ntiles ? tile : 0);
     if (tile < s.ntiles && !(dbg & DBG_NOSTAGE)) {
-        pref_load<SD, false>(pd, sd, dy, nullptr, pos.img, pos.t0 - lo, 4 * pos.g_base - 2, s.T, s.F, s.F);
-        pref_load<SA, MASK>(pa, sa, x, mask_src, pos.img, pos.t0, 4 * pos.g_base - 2, s.T, s.F, min(s.F, 4 * (pos.g_base + pos.ng)));
+        pref_load<SD, false>(pd, sd, dy, nullptr, dy_bf16, pos.img, pos.t0 - lo, 4 * pos.g_base - 2, s.T, s.F, s.F);
+        pref_load<SA, MASK>(pa, sa, x, mask_src, x_bf16, pos.img, pos.t0, 4 * pos.g_base - 2, s.T, s.F, min(s.F, 4 * (pos.g_base + pos.ng)));
     }
     int it = 0;
     while (tile < s.ntiles) {
         if (!(dbg & DBG_NOSTAGE)) {
-            pref_commit<SD, PTTS_IN_NONE>(pd, sd, dpl, pos.t0 - lo, 4 * pos.g_base - 2, s.T, s.F, nullptr, nullptr, alpha, lo, 2 + 4 * pos.ng, &bsum);
-            pref_commit<SA, MODE>(pa, sa, apl, pos.t0, 4 * pos.g_base - 2, s.T, s.F, nullptr, nullptr, alpha, 0, 0, nullptr);
+            pref_commit<SD, PTTS_IN_NONE, NPL>(pd, sd, dpl, pos.t0 - lo, 4 * pos.g_base - 2, s.T, s.F, nullptr, nullptr, alpha, lo, 2 + 4 * pos.ng, &bsum);
+            pref_commit<SA, MODE, NPL>(pa, sa, apl, pos.t0, 4 * pos.g_base - 2, s.T, s.F, nullptr, nullptr, alpha, 0, 0, nullptr);
         }
         if (it == 0) stamp(dbg_buf, dbg, 1);
         __syncthreads();
@@ -439,31 +468,32 @@ __global__ __launch_bounds__(THREADS, DIL <= 2 ? 2 : 1) void wgrad_kernel(
         if (next < s.ntiles) {
             pos = tile_pos(s, next);
             if (!(dbg & DBG_NOSTAGE)) {
-                pref_load<SD, false>(pd, sd, dy, nullptr, pos.img, pos.t0 - lo, 4 * pos.g_base - 2, s.T, s.F, s.F);
-                pref_load<SA, MASK>(pa, sa, x, mask_src, pos.img, pos.t0, 4 * pos.g_base - 2, s.T, s.F, min(s.F, 4 * (pos.g_base + pos.ng)));
+                pref_load<SD, false>(pd, sd, dy, nullptr, dy_bf16, pos.img, pos.t0 - lo, 4 * pos.g_base - 2, s.T, s.F, s.F);
+                pref_load<SA, MASK>(pa, sa, x, mask_src, x_bf16, pos.img, pos.t0, 4 * pos.g_base - 2, s.T, s.F, min(s.F, 4 * (pos.g_base + pos.ng)));
             }
         }
         for (int gp = wave; gp < ng2 && !(dbg & DBG_NOMFMA); gp += 4) {
             // A operand: a[row 4 lg + e&3][group 2 gp + (e >> 2)][(fi, ci) = li]  -- staged bin of group g, fi: 4 g + 2 + fi
-            bf16x8 af[NP];
+            bf16x8 af[NPL];
 #pragma unroll
-            for (int p = 0; p < NP; ++p) af[p] = cat(tr_read(abase0 + 32 * gp + p * SA::PS), tr_read(abase1 + 32 * gp + p * SA::PS));
+            for (int p = 0; p < NPL; ++p) af[p] = cat(tr_read(abase0 + 32 * gp + p * SA::PS), tr_read(abase1 + 32 * gp + p * SA::PS));
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
                 // B operand: dy[staged row 4 lg + e&3 + (KT-1-kt) dil][staged bin 4 (g + hb) + fo][co], (fo, co) = li;
                 // the upper half of hb = 0 is the lower half of hb = 1
-                bf16x4 d0[NP], d1[NP], d2[NP];
+                bf16x4 d0[NPL], d1[NPL], d2[NPL];
 #pragma unroll
-                for (int p = 0; p < NP; ++p) {
+                for (int p = 0; p < NPL; ++p) {
                     const int off = 32 * gp + p * SD::PS + (KT - 1 - kt) * DIL * SD::RS;
                     d0[p] = tr_read(dbase0 + off);
                     d1[p] = tr_read(dbase1 + off);
                     d2[p] = tr_read(dbase2 + off);
                 }
-#define C2M_MM(PA, PW)                                                                                                   \
+#define C2M_MM(PA_, PW_)                                                                                                 \
+                { constexpr int PA = PA_ < NPL ? PA_ : 0, PW = PW_ < NPL ? PW_ : 0;                                      \
                 acc[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA], cat(d0[PW], d1[PW]), acc[kt][0], 0, 0, 0);   \
-                acc[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA], cat(d1[PW], d2[PW]), acc[kt][1], 0, 0, 0);
-                C2M_PRODUCTS(C2M_MM)
+                acc[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA], cat(d1[PW], d2[PW]), acc[kt][1], 0, 0, 0); }
+                C2M_PRODUCTS_NPL(NPL, C2M_MM);
 #undef C2M_MM
             }
         }

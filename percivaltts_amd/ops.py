@@ -799,6 +799,16 @@ class _C1WgradT(object):
         cls.src = cls.key = cls.planes = None
 
 
+def clear_caches():
+    """Forget every operand derived from a weight or an input (bf16 planes, transposed frames, Toeplitz tables, the reused
+    context-Conv1D product).  A hipGraph capture must start from empty caches: an entry made before the capture would be
+    taken instead of being recomputed INSIDE the graph, and every replay would then read the stale copy."""
+    _C1Split.clear()
+    _C1WgradT.clear()
+    _C2M.clear()
+    _C1Cache.key = _C1Cache.ap = _C1Cache.y = None
+
+
 def conv1d_split(on):
     """Switch the bf16x6 split product of the context Conv1D forward on or off (see _C1Split); None: the default."""
     _C1Split.enabled = _C1Split.default if on is None else bool(on)
@@ -908,6 +918,24 @@ def conv1d(v, w, b=None):
 BN_EPS, BN_MOMENTUM = 1e-3, 0.99   # Keras defaults
 
 
+class _SyncBN(object):
+    """SyncBN option of the data-parallel step (cfg.train_sync_batchnorm; SURVEY 8e note 1): the per-channel sums of a
+    BatchNormalization layer (sum x, sum x^2 forward; the two gradient sums backward) are all-reduced over the ranks, so
+    that W ranks with B samples each normalise like one process with W*B.  Off by default: per-rank statistics."""
+    world = 1
+
+
+def sync_batchnorm(world):
+    """world > 1: synchronise BatchNorm statistics over that many ranks (torch.distributed must be initialised); 1: off."""
+    _SyncBN.world = int(world) if world else 1
+
+
+def _allreduce_small(t):
+    import torch.distributed as dist
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
 class BatchNormTrainFn(torch.autograd.Function):
     """(scale, shift) from the batch statistics of z [.., C]; updates the moving statistics in place."""
     @staticmethod
@@ -916,6 +944,10 @@ class BatchNormTrainFn(torch.autograd.Function):
         C = z.shape[-1]
         rows = z.numel() // C
         sums = colsums(z.view(rows, C))
+        ctx.sync = _SyncBN.world
+        if ctx.sync > 1:          # the statistics of the global batch: one tiny all-reduce (2C doubles)
+            _allreduce_small(sums)
+            rows = rows * ctx.sync
         dev = z.device
         scale = torch.empty(C, dtype=torch.float32, device=dev)
         shift = torch.empty(C, dtype=torch.float32, device=dev)
@@ -942,6 +974,14 @@ class BatchNormTrainFn(torch.autograd.Function):
         c2 = torch.empty(C, dtype=torch.float32, device=dev)
         call('ptts_bn_bwd_coefs', ptr(dscale), ptr(dshift), ptr(mean), ptr(rstd), ptr(gamma), rows, C,
              ptr(dgamma), ptr(dbeta), ptr(c0), ptr(c2), stream())
+        if ctx.sync > 1:
+            # the terms through the statistics carry every rank's loss: their coefficients come from the all-reduced sums
+            # over the global row count; dgamma / dbeta stay this rank's own share (the flat-gradient all-reduce adds them)
+            both = torch.cat([dscale, dshift])
+            _allreduce_small(both)
+            scratch = torch.empty(2 * C, dtype=torch.float32, device=dev)
+            call('ptts_bn_bwd_coefs', ptr(both[:C]), ptr(both[C:]), ptr(mean), ptr(rstd), ptr(gamma), rows * ctx.sync, C,
+                 ptr(scratch[:C]), ptr(scratch[C:]), ptr(c0), ptr(c2), stream())
         dz = None
         if ctx.needs_input_grad[0]:
             dz = torch.empty_like(z)

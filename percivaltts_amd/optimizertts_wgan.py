@@ -109,6 +109,9 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         cfg.train_wgan_stack_real_fake = True        # critic(real) and critic(fake) as one stacked 2B pass (exact: no BatchNorm)
         cfg.train_wgan_reuse_ctx_conv = True         # generator step reuses the critic step's G-context-Conv1D product (same batch)
         cfg.train_wgan_early_critic = True           # generator step: critic starts on the spectral branch, BLSTM joins for the LS term
+        cfg.train_wgan_graph_split = False           # hipGraph of forward + backward only, update launched eagerly (what data parallelism uses; settable for tests)
+        cfg.train_wgan_async_update = None           # all-reduce + Adam on a communication stream, overlapped with the next forward that does not need the weights (None: on when world > 1)
+        cfg.train_sync_batchnorm = False             # data parallelism: BatchNorm statistics over all ranks (SyncBN) instead of per rank
         cfg.train_wgan_split_bf16 = None             # context Conv1D forward + weight gradient as bf16x6 split products (fp32 arithmetic on the bf16 matrix cores, ops._C1Split); None: the default (on; PTTS_CONV1D_SPLIT=0 turns it off), False: fp32 MFMA kernels
         return cfg
 
@@ -157,6 +160,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         if self.world > 1:   # identical replicas to start from
             parallel.broadcast_(self.critic_opti.flat.flat)
             parallel.broadcast_(self.gen_opti.flat.flat)
+        ops.sync_batchnorm(self.world if bool(getattr(cfg, 'train_sync_batchnorm', False)) else 1)
 
         # kept for API compatibility: Keras needed target arrays, the kernels take the signs directly
         self.wgan_valid = -np.ones((cfg.train_batch_size, 1, 1))
@@ -185,12 +189,15 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         self.critic_model = self.critic_net
         self.generator_model = generator
         self._graphs = {}
+        self._pending = {}           # 'critic' / 'generator' -> event of an optimiser update still running on the communication stream
+        self._comm = None
 
     # ---- device-side losses ----------------------------------------------------------------------------------
     def _fake_sample(self, X, training):
         """G(x) with the generator frozen: batch statistics in training mode but NO moving-average update
         (hard parts)."""
         memo = {'freeze_bn_stats': True}
+        self._wait_update('generator')
         with torch.no_grad():
             if self._gen_spec is not None:
                 spec = self._gen_spec(X, training=training, memo=memo)
@@ -204,6 +211,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         """Total critic loss and its three parts on device tensors X [B,T,ctx], Y [B,T,out]."""
         if fake is None:
             fake = self._fake_sample(X, training)
+        self._wait_update('critic')
         x_hat = RandomWeightedAverage(X.shape[0])([Y, fake], alpha).requires_grad_(True)
         streams = bool(getattr(self.cfg, 'train_wgan_parallel_streams', False))
         if getattr(self.cfg, 'train_wgan_stack_real_fake', True) and self._critic_is_per_sample():
@@ -234,6 +242,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
     def generator_loss(self, X, Y, training=True):
         m = self._model.kerasmodel
         node_spec = getattr(self._model, 'node_spec', None)
+        self._wait_update('generator')
         if getattr(self, '_gen_spec', None) is not None and node_spec is not None and m.single_output and \
                 bool(getattr(self.cfg, 'train_wgan_early_critic', True)):
             # The critic reads the spectral columns only (the condition under which the critic step prunes the other
@@ -249,12 +258,14 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             voc = self._model.vocoder
             feat = torch.zeros(X.shape[0], X.shape[1], voc.featuressize(), dtype=torch.float32, device=X.device)
             feat[:, :, 1:1 + voc.specsize()] = spec
+            self._wait_update('critic')          # the critic's update of this batch may still be in flight: G's forward above did not need it
             valid = self.critic_net(feat, X, training=training)
             l_w = wasserstein_loss(-1.0, valid)
             values = m._run(feed, training, None, values=values)
             pred = kl.to_tensor(values[id(out_node)])
         else:
             pred = m(X, training=training)
+            self._wait_update('critic')
             valid = self.critic_net(pred, X, training=training)
             l_w = wasserstein_loss(-1.0, valid)
         if self._errtype == 'WGAN':
@@ -263,18 +274,60 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         return self._wgan_weight * l_w + l_ls, (l_w, l_ls)
 
     # ---- device-side steps (no host synchronisation) -----------------------------------------------------------
-    def critic_step(self, X, Y, alpha=None):
+    # ---- optimiser updates: all-reduce of the flat gradient + Adam, optionally on a communication stream -------------------
+    def _async(self):
+        a = getattr(self.cfg, 'train_wgan_async_update', None)
+        return (self.world > 1) if a is None else bool(a)
+
+    def _wait_update(self, kind):
+        """Make the current stream wait for a still-running update of that network's weights (no-op otherwise)."""
+        ev = self._pending.pop(kind, None) if getattr(self, '_pending', None) else None
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def wait_updates(self):
+        self._wait_update('critic'); self._wait_update('generator')
+
+    def _update(self, kind):
+        """All-reduce (sum over ranks; the 1/world goes into Adam's gscale) and the Adam step of one network.  With
+        cfg.train_wgan_async_update both run on a communication stream behind an event of the backward pass: the compute
+        stream goes straight on to the next forward that does not read these weights (the frozen generator's sample of the
+        next critic step; the generator's forward of the generator step) and waits only where it needs them."""
+        opti = self.critic_opti if kind == 'critic' else self.gen_opti
+
+        def run():
+            opti.step(parallel.allreduce_sum_(opti.flat.grad))
+            if kind == 'critic' and self.cfg.train_wgan_weight_clip:
+                c = float(self.cfg.train_wgan_weight_clip)
+                opti.clip_weights(-c, c)
+
+        if not self._async() or torch.cuda.is_current_stream_capturing():
+            run()
+            return
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(priority=-1)
+        cur = torch.cuda.current_stream()
+        self._comm.wait_stream(cur)
+        with torch.cuda.stream(self._comm):
+            run()
+            self._pending[kind] = self._comm.record_event()
+
+    def _critic_grads(self, X, Y, alpha=None):
+        fake = self._fake_sample(X, True)      # first: it does not need the critic's weights (a pending update may still run)
+        self._wait_update('critic')
         self.critic_opti.zero_grad()
         with ops.deferred_weight_grads():       # the Dense layers' weight gradients run as one grouped launch at exit
-            total, _ = self.critic_loss(X, Y, alpha, training=True)
+            total, _ = self.critic_loss(X, Y, alpha, training=True, fake=fake)
             total.backward()
-        self.critic_opti.step(parallel.allreduce_sum_(self.critic_opti.flat.grad))
-        if self.cfg.train_wgan_weight_clip:
-            c = float(self.cfg.train_wgan_weight_clip)
-            self.critic_opti.clip_weights(-c, c)
         return total.detach()
 
-    def generator_step(self, X, Y):
+    def critic_step(self, X, Y, alpha=None):
+        total = self._critic_grads(X, Y, alpha)
+        self._update('critic')
+        return total
+
+    def _generator_grads(self, X, Y):
+        self._wait_update('generator')
         self.gen_opti.zero_grad()
         cps = self.critic_opti.flat.params
         for p in cps: p.requires_grad_(False)      # frozen critic (:160-161)
@@ -284,42 +337,62 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
                 total.backward()
         finally:
             for p in cps: p.requires_grad_(True)
-        self.gen_opti.step(parallel.allreduce_sum_(self.gen_opti.flat.grad))
         return total.detach()
 
+    def generator_step(self, X, Y):
+        total = self._generator_grads(X, Y)
+        self._update('generator')
+        return total
+
     # hipGraph replay of a whole step: static input buffers, one capture per (kind, shape)
-    def _graphed(self, kind, X, Y):
-        key = (kind, tuple(X.shape), tuple(Y.shape))
+    def _graphed(self, kind, X, Y, alpha=None):
+        """hipGraph replay of a step.  One process: the whole step (forward, backward, Adam) is one graph.  Data parallel: the
+        graph ends with the backward pass -- the gradient all-reduce cannot be captured -- and the update follows eagerly."""
+        whole = self.world == 1 and not bool(getattr(self.cfg, 'train_wgan_graph_split', False))
+        key = (kind, tuple(X.shape), tuple(Y.shape), whole)
         ent = self._graphs.get(key)
         if ent is None:
+            self.wait_updates()
             sX, sY = X.clone(), Y.clone()
             sA = torch.rand(X.shape[0], device=X.device, dtype=torch.float32)
-            fn = (lambda: self.critic_step(sX, sY, sA)) if kind == 'critic' else (lambda: self.generator_step(sX, sY))
+            if whole:
+                fn = (lambda: self.critic_step(sX, sY, sA)) if kind == 'critic' else (lambda: self.generator_step(sX, sY))
+            else:
+                fn = (lambda: self._critic_grads(sX, sY, sA)) if kind == 'critic' else (lambda: self._generator_grads(sX, sY))
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(2):     # warm-up outside capture (allocator, workspace growth)
                     fn()
+                    if not whole:
+                        self._update(kind); self.wait_updates()
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
+            ops.clear_caches()         # every derived operand (bf16 planes, Toeplitz tables) must be rebuilt inside the graph
             with torch.cuda.graph(g):
                 out = fn()
+            ops.clear_caches()         # ... and the graph's private copies are not for eager code
             ent = (g, sX, sY, sA, out)
             self._graphs[key] = ent
         g, sX, sY, sA, out = ent
         sX.copy_(X); sY.copy_(Y)
         if kind == 'critic':
-            sA.uniform_(0.0, 1.0)
+            if alpha is None: sA.uniform_(0.0, 1.0)
+            else: sA.copy_(alpha.reshape(-1))
+        self.wait_updates()            # the replay reads (and, in one process, writes) both networks' weights
         g.replay()
-        # the replayed Adam / clip kernels changed the weights behind every weight-keyed cache (bf16 planes, Toeplitz
-        # tables): the Python-side epoch bump of KerasAdam.step() is not part of the graph
-        (self.critic_opti if kind == 'critic' else self.gen_opti).flat.epoch += 1
+        if whole:
+            # the replayed Adam / clip kernels changed the weights behind every weight-keyed cache (bf16 planes, Toeplitz
+            # tables): the Python-side epoch bump of KerasAdam.step() is not part of the graph
+            (self.critic_opti if kind == 'critic' else self.gen_opti).flat.epoch += 1
+        else:
+            self._update(kind)
         return out
 
-    def device_step(self, batchid, X, Y):
+    def device_step(self, batchid, X, Y, alpha=None):
         """One `train_on_batch` worth of device work on resident tensors; returns (critic_loss, generator_loss|None)
         as device scalars."""
-        use_graph = bool(self.cfg.train_wgan_hipgraph) and self.world == 1
+        use_graph = bool(self.cfg.train_wgan_hipgraph)
         critic_runs = 10 if (self.generator_updates < 25) or (self.generator_updates % 500 == 0) else 5   # (:225-228)
         gen_too = batchid % critic_runs == 0
         # the generator step that follows on the same batch reuses the generator's context-Conv1D product of the critic
@@ -329,7 +402,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         if split is not None and bool(split) != ops._C1Split.enabled:
             ops.conv1d_split(split)
         try:
-            lc = self._graphed('critic', X, Y) if use_graph else self.critic_step(X, Y)
+            lc = self._graphed('critic', X, Y, alpha) if use_graph else self.critic_step(X, Y, alpha)
             lg = None
             if gen_too:
                 lg = self._graphed('generator', X, Y) if use_graph else self.generator_step(X, Y)
@@ -347,6 +420,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         return None if lg is None else float(lg.item())
 
     def update_validation_cost(self, costs, X_vals, Y_vals):
+        self.wait_updates()
         costs['model_rmse_validation'].append(data.cost_model_prediction_rmse(self._model, [X_vals], Y_vals))
 
         def gen_cost(x, y):
@@ -378,6 +452,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             print('Restoring optimizer failed from ' + fname + '. Fresh optimizer used instead (i.e. momentums, etc., might be wrong)')
 
     def saveTrainingStateLossSpecific(self, fstate):
+        self.wait_updates()
         self.saveOptimizer(self.gen_opti, fstate + '.generator.optimizer.npz')
         self.saveOptimizer(self.critic_opti, fstate + '.critic.optimizer.npz')
         np.savez(fstate + '.model.weights.npz', *self._model.kerasmodel.get_weights())

@@ -92,6 +92,62 @@ def test_two_ranks_equal_manual_gradient_averaging():
     np.testing.assert_allclose(res[0][2], opt.gen_opti.flat.flat.cpu().numpy(), rtol=2e-4, atol=2e-6)
 
 
+def _worker_syncbn(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'RANK': str(rank), 'WORLD_SIZE': str(world),
+                       'LOCAL_RANK': '0', 'PTTS_DIST_BACKEND': 'gloo'})
+    import io, contextlib
+    from percivaltts_amd import optimizertts_wgan, parallel
+    tm, cfg, mod, crit, X, Y, al = _setup()
+    cfg.train_sync_batchnorm = True
+    cfg.train_wgan_critic_LSWGANtransidx = 30.0
+    with contextlib.redirect_stdout(io.StringIO()):
+        opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype='WLSWGAN', critic=crit)
+        opt.prepare()
+    lo, hi = parallel.shard_batch(X.shape[0], world, rank)
+    Xd, Yd = tm.f32(X[lo:hi]), tm.f32(Y[lo:hi])
+    lg = opt.generator_step(Xd, Yd)
+    torch.cuda.synchronize()
+    moving = np.concatenate([t.detach().cpu().numpy().ravel() for k, t in mod.kerasmodel.weights() if 'moving' in k])
+    q.put((rank, opt.gen_opti.flat.grad.cpu().numpy() / world, float(lg), moving))
+    parallel.barrier()
+
+
+def test_syncbn_two_ranks_equal_one_process_on_the_whole_batch():
+    """cfg.train_sync_batchnorm (SURVEY 8e note 1): with the BatchNorm sums all-reduced, two ranks on the two halves of a
+    batch take the generator step of ONE process on the whole batch -- same moving statistics after the step, the mean of
+    the two ranks' losses is the loss of the batch, and the all-reduced, 1/W-scaled gradient is the gradient of the batch.
+    (Per-rank statistics, the default, are the single-GPU semantics of the rank's own B samples instead.)"""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_syncbn, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_array_equal(res[0][3], res[1][3])
+    # the same step by one process on the whole batch
+    from percivaltts_amd import optimizertts_wgan
+    import io, contextlib
+    tm, cfg, mod, crit, X, Y, al = _setup()
+    cfg.train_wgan_critic_LSWGANtransidx = 30.0
+    with contextlib.redirect_stdout(io.StringIO()):
+        opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype='WLSWGAN', critic=crit)
+        opt.prepare()
+    lg = opt.generator_step(tm.f32(X), tm.f32(Y))
+    torch.cuda.synchronize()
+    g_full = opt.gen_opti.flat.grad.cpu().numpy()
+    moving = np.concatenate([t.detach().cpu().numpy().ravel() for k, t in mod.kerasmodel.weights() if 'moving' in k])
+    np.testing.assert_allclose(0.5 * (res[0][2] + res[1][2]), float(lg), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(res[0][3], moving, rtol=1e-5, atol=1e-6)
+    err = np.linalg.norm(res[0][1] - g_full) / np.linalg.norm(g_full)
+    assert err < 1e-4, err
+
+
 def test_bench_two_ranks_prints_one_line():
     """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank; here gloo and both
     ranks on the one GPU): every collective must be entered by both ranks, rank 0 prints ONE JSON line."""

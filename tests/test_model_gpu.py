@@ -269,7 +269,7 @@ def test_hipgraph_replay_matches_eager():
             opt._graphed('critic', Xd, Yd)
             crit.model.set_weights([w.numpy() for w in cw])
             opt.critic_opti.m.zero_(); opt.critic_opti.v.zero_(); opt.critic_opti.step_count.zero_()
-            g, sX, sY, sA, out = opt._graphs[('critic', tuple(Xd.shape), tuple(Yd.shape))]
+            g, sX, sY, sA, out = opt._graphs[('critic', tuple(Xd.shape), tuple(Yd.shape), True)]
             losses = []
             for _ in range(3):
                 sA.copy_(ald); g.replay(); losses.append(float(out.item()))
@@ -298,3 +298,90 @@ def test_parallel_streams_match_single_stream():
     np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-5, atol=1e-6)
     close(res[1][2], res[0][2], 1e-4, 1e-6, 'last critic gradient, 3 streams vs 1', kinks=True)
     close(res[1][1], res[0][1], 1e-4, 1e-6, 'critic weights after 3 steps, 3 streams vs 1', kinks=True)
+
+
+def test_async_update_on_a_communication_stream_matches_the_plain_step():
+    """What data parallelism runs, exercised in one process: the optimiser update (all-reduce + Adam) on a communication
+    stream behind an event of the backward pass, with the compute stream going on to the next forward and waiting only
+    where it reads the updated weights (cfg.train_wgan_async_update).  Six train_on_batch-equivalents (critic steps and two
+    generator steps) must leave bit for bit the weights of the plain eager steps (deterministic mode)."""
+    from percivaltts_amd import optimizertts_wgan, ops
+    res = []
+    ops.deterministic(True)
+    try:
+        for on in (False, True):
+            cfg, voc, mod, crit, a, gw, cw, X, Y, al = build('default')
+            cfg.train_wgan_async_update = on
+            opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype='WLSWGAN', critic=crit)
+            opt.prepare()
+            opt.generator_updates = 26          # critic_runs = 5: batch 0 and batch 5 also train the generator
+            Xd, Yd = f32(X), f32(Y)
+            losses = []
+            ag = torch.Generator().manual_seed(17)
+            for b in range(6):
+                lc, lg = opt.device_step(b, Xd, Yd, alpha=torch.rand(Xd.shape[0], generator=ag).cuda())   # injected: no RNG in the comparison
+                losses.append(float(lc))
+            assert on == bool(opt._pending)        # the last update is still registered as in flight
+            opt.wait_updates(); torch.cuda.synchronize()
+            res.append((losses, opt.critic_opti.flat.flat.detach().cpu().clone(), opt.gen_opti.flat.flat.detach().cpu().clone(),
+                        int(opt.critic_opti.step_count), int(opt.gen_opti.step_count)))
+    finally:
+        ops.deterministic(False)
+    assert res[0][3:] == res[1][3:] == (6, 2)
+    np.testing.assert_allclose(res[1][0], res[0][0], rtol=0, atol=0)
+    assert torch.equal(res[1][1], res[0][1]) and torch.equal(res[1][2], res[0][2])
+
+
+def test_split_hipgraph_recomputes_every_weight_derived_operand():
+    """cfg.train_wgan_graph_split (what a data-parallel run uses: the gradient all-reduce cannot be captured): the hipGraph
+    ends with the backward pass and the update follows eagerly.  Every operand derived from the weights (Toeplitz tables of
+    the Conv2D kernels, bf16 planes) must be rebuilt INSIDE the graph: the graphs are replayed at five different weight
+    states (the states an eager run went through) and their gradients compared with the eager run's at the same state --
+    no Adam step in between that would turn a last-bit difference into a sign flip of the first updates."""
+    from percivaltts_amd import optimizertts_wgan, ops
+    ops.deterministic(True)
+    try:
+        cfg, voc, mod, crit, a, gw, cw, X, Y, al = build('default')
+        opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype='WLSWGAN', critic=crit)
+        opt.prepare()
+        opt.generator_updates = 26
+        Xd, Yd = f32(X), f32(Y)
+        ag = torch.Generator().manual_seed(17)
+        alphas = [torch.rand(Xd.shape[0], generator=ag).cuda() for _ in range(5)]
+        moving = [t for k, t in mod.kerasmodel.weights() if 'moving' in k]
+
+        def state():
+            return [t.detach().clone() for t in (opt.critic_opti.flat.flat, opt.gen_opti.flat.flat)] + [t.detach().clone() for t in moving]
+
+        def load(st):
+            opt.wait_updates()
+            opt.critic_opti.flat.flat.copy_(st[0]); opt.gen_opti.flat.flat.copy_(st[1])
+            for dst, src in zip(moving, st[2:]): dst.copy_(src)
+            opt.critic_opti.flat.epoch += 1; opt.gen_opti.flat.epoch += 1
+
+        trace = []
+        for b in range(5):
+            st = state()
+            lc = opt.critic_step(Xd, Yd, alphas[b]); gc = opt.critic_opti.flat.grad.detach().clone()
+            st2 = state()
+            lg = opt.generator_step(Xd, Yd); gg = opt.gen_opti.flat.grad.detach().clone()
+            trace.append((st, float(lc), gc, st2, float(lg), gg))
+        # the same states through the split graphs
+        opt.cfg.train_wgan_hipgraph = True; opt.cfg.train_wgan_graph_split = True
+        opt._graphed('critic', Xd, Yd, alphas[0]); opt._graphed('generator', Xd, Yd)      # capture (their warm-up steps move the weights)
+        for b, (st, lc, gc, st2, lg, gg) in enumerate(trace):
+            load(st)
+            lc_g = opt._graphed('critic', Xd, Yd, alphas[b])
+            opt.wait_updates(); torch.cuda.synchronize()
+            close(lc_g, lc, 1e-6, 1e-7, 'critic loss, graph vs eager, state {}'.format(b))
+            err = float((opt.critic_opti.flat.grad - gc).norm() / gc.norm())
+            assert err < 1e-5, 'critic gradient, state {}: rel L2 {:.3e}'.format(b, err)
+            load(st2)
+            lg_g = opt._graphed('generator', Xd, Yd)
+            opt.wait_updates(); torch.cuda.synchronize()
+            close(lg_g, lg, 1e-6, 1e-7, 'generator loss, graph vs eager, state {}'.format(b))
+            err = float((opt.gen_opti.flat.grad - gg).norm() / gg.norm())
+            assert err < 1e-5, 'generator gradient, state {}: rel L2 {:.3e}'.format(b, err)
+        assert len(opt._graphs) == 2
+    finally:
+        ops.deterministic(False)
