@@ -127,14 +127,21 @@ int ptts_conv2d_reduce_grouped(const ptts_conv2d_reduce_desc* descs, int n, void
  * ------------------------------------------------------------------------------------- */
 int ptts_conv2d_mfma_supported(int F, int Cin, int Cout, int KT, int KF, int dil_t);
 size_t ptts_conv2d_mfma_table_bytes(int KT);
-int ptts_conv2d_mfma_tables(const float* w, void* table_fwd, void* table_bwd, int KT, int KF, int Cin, int Cout, void* stream);
-int ptts_conv2d_mfma_fwd(const float* x, const void* table, const float* bias, const float* in_scale, const float* in_shift,
-                         const float* mask_src, const float* out_mask, float* y,
-                         int B, int T, int F, int KT, int dil_t, int pad_t, int in_mode, float alpha, void* stream);
+int ptts_conv2d_mfma_tables(const float* w, void* table_fwd, void* table_bwd, int KT, int KF, int Cin, int Cout,
+                            int planes /*3: fp32 split, 1: bf16 copy of the kernel*/, void* stream);
+/* planes = 3: fp32 arithmetic (six products), every tensor fp32.  planes = 1: bf16 arithmetic (BASELINE configs[2]; time
+ * dilation 1): ONE product per position with the bf16 copy of the kernel, fp32 accumulation; x and mask_src are bf16 in
+ * HBM when in_bf16 (else fp32, rounded to bf16 on load), y and out_mask are bf16 when out_bf16 (else fp32). */
+int ptts_conv2d_mfma_fwd(const void* x, const void* table, const float* bias, const float* in_scale, const float* in_shift,
+                         const void* mask_src, const void* out_mask, void* y,
+                         int B, int T, int F, int KT, int dil_t, int pad_t, int in_mode, float alpha,
+                         int planes, int in_bf16, int out_bf16, void* stream);
 size_t ptts_conv2d_mfma_wgrad_workspace_bytes(int B, int T);
-int ptts_conv2d_mfma_wgrad_partials(const float* dy, const float* x, const float* mask_src, void* workspace,
+/* x (and mask_src) bf16 when x_bf16, dy bf16 when dy_bf16; the partial sums and the reduced gradients are fp32 always. */
+int ptts_conv2d_mfma_wgrad_partials(const void* dy, const void* x, const void* mask_src, void* workspace,
                                     size_t workspace_bytes, int* nblocks_out, int* npart_out, int B, int T, int F,
-                                    int KT, int dil_t, int pad_t, int in_mode, float alpha, void* stream);
+                                    int KT, int dil_t, int pad_t, int in_mode, float alpha,
+                                    int planes, int x_bf16, int dy_bf16, void* stream);
 int ptts_conv2d_mfma_debug(int flags, void* stamp_buf);
 
 /* ---------------------------------------------------------------------------------------

@@ -350,16 +350,33 @@ def count_params_generic(ctxsize, hidden, nlayers, specsize, nmsize):
     return n
 
 
-def critic_forward(weights, a, features, ctx):
-    """D(features [B,T,out], ctx [B,T,ctxsize]) -> [B,T,1]."""
+def bf16_st(x):
+    """Round to bfloat16 (through fp32, as the kernels hold fp32 values) with a straight-through gradient: the value the
+    bf16-storage path keeps in HBM / feeds to the matrix cores, differentiable like the identity."""
+    return x + (x.detach().to(torch.float32).to(torch.bfloat16).to(x.dtype) - x.detach())
+
+
+def critic_forward(weights, a, features, ctx, bf16_stack=False):
+    """D(features [B,T,out], ctx [B,T,ctxsize]) -> [B,T,1].
+    bf16_stack (build extension, BASELINE configs[2]; the reference is fp32 throughout): the 4 -> 4 channel layers of the
+    Conv2D stack multiply in bf16 -- activation rounded to bf16 after the LeakyReLU, the kernel's bf16 copy, exact products,
+    wide accumulation -- and the maps between them are stored as bf16; the first layer, the map handed on to the dense
+    layers, the biases and the master weights stay fp32."""
     take = _Take(weights)
     B, T = features.shape[0], features.shape[1]
     spec = features[:, :, 1:1 + a.specsize]                        # networks_critic.py:58
     if a.L > 0:
         h = spec.reshape(B, T, a.specsize, 1)
-        for _ in range(a.L):
+        z = None
+        for li in range(a.L):
             w, b = take(2)
-            h = lrelu(conv2d_nhwc(h, w, b))
+            if bf16_stack and li >= 1:
+                z = conv2d_nhwc(bf16_st(lrelu(z)), bf16_st(w), b)
+                if li < a.L - 1:
+                    z = bf16_st(z)                                 # stored as bf16
+            else:
+                z = conv2d_nhwc(h if li == 0 else lrelu(z), w, b)
+        h = lrelu(z)
         h = h.reshape(B, T, a.specsize * a.C)                      # f-major, c-minor
     else:
         h = spec
@@ -466,16 +483,16 @@ def wls_weights(specsize, noisesize, vuvsize, LScoef, transidx, transcoef=1.0 / 
     return 1.0 - w, float(np.mean(w))
 
 
-def critic_step_loss(cw, gw, a, X, Y, alpha, gp_lambda=10.0, training=True):
+def critic_step_loss(cw, gw, a, X, Y, alpha, gp_lambda=10.0, training=True, bf16_stack=False):
     """One critic loss (optimizertts_wgan.py:115-154): returns (total, parts dict).  training=False is the evaluation of
     update_validation_cost (:259-260, `critic_model.evaluate`, learning phase 0): G's BatchNorm uses its moving statistics;
     the gradient penalty is still part of the loss."""
     with torch.no_grad():
         fake = generator_forward(gw, a, X, training=training)      # frozen G; learning phase 1 -> batch statistics
-    valid = critic_forward(cw, a, Y, X)
-    fake_v = critic_forward(cw, a, fake, X)
+    valid = critic_forward(cw, a, Y, X, bf16_stack)
+    fake_v = critic_forward(cw, a, fake, X, bf16_stack)
     x_hat = random_weighted_average(Y, fake, alpha).detach().requires_grad_(True)
-    v_hat = critic_forward(cw, a, x_hat, X)
+    v_hat = critic_forward(cw, a, x_hat, X, bf16_stack)
     gp, g = gradient_penalty_loss(v_hat, x_hat)
     l_valid = wasserstein_loss(-1.0, valid)
     l_fake = wasserstein_loss(+1.0, fake_v)

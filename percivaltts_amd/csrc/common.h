@@ -10,6 +10,10 @@ namespace ptts {
 void set_error(const char* fmt, ...);
 // ptts_set_deterministic(): fixed-order reductions only (no fp32 atomics between workgroups), at a price in speed
 bool deterministic();
+// Zero fills by kernel, not hipMemsetAsync: memset nodes of a captured hipGraph were found not to be replayed reliably on
+// this stack (tests/test_model_gpu.py::test_split_hipgraph_...: bias-gradient and loss scalars came back unzeroed).
+int zero_f32(float* p, size_t n, hipStream_t st);
+int zero_f32_2d(float* p, size_t ld, size_t cols, size_t rows, hipStream_t st);
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();

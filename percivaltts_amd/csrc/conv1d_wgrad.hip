@@ -198,9 +198,8 @@ extern "C" int ptts_conv1d_wgrad_t(const float* xt, const float* yt, float* dw, 
     if (nsplit < 1) nsplit = 1;
     if (nsplit > qsteps) nsplit = qsteps;
     g.nsplit = nsplit; g.steps_per_split = (qsteps + nsplit - 1) / nsplit;
-    hipError_t e = hipMemsetAsync(dw, 0, (size_t)KW * C * N * sizeof(float), st);
-    if (e == hipSuccess && db) e = hipMemsetAsync(db, 0, (size_t)N * sizeof(float), st);
-    if (e != hipSuccess) { set_error("conv1d_wgrad_t: memset failed: %s", hipGetErrorString(e)); return PTTS_ELAUNCH; }
+    if (zero_f32(dw, (size_t)KW * C * N, st) != PTTS_OK) return PTTS_ELAUNCH;
+    if (db && zero_f32(db, (size_t)N, st) != PTTS_OK) return PTTS_ELAUNCH;
 #define PTTS_WT_LAUNCH(KWV)                                                                                               \
     {                                                                                                                     \
         static bool attr = false;                                                                                         \

@@ -558,11 +558,13 @@ extern "C" int ptts_conv2d_mfma_debug(int flags, void* stamp_buf) {
 
 extern "C" size_t ptts_conv2d_mfma_table_bytes(int KT_) { return (size_t)KT_ * NP * 64 * 8 * sizeof(u16); }
 
+// planes: 3 = fp32 arithmetic (three-way split), 1 = bf16 arithmetic (the kernel rounded to bf16: the "weights copy in bf16")
 extern "C" int ptts_conv2d_mfma_tables(const float* w, void* table_fwd, void* table_bwd, int KT_, int KF_, int Cin, int Cout,
-                                       void* stream) {
+                                       int planes, void* stream) {
     PTTS_REQUIRE(w && (table_fwd || table_bwd), "conv2d_mfma_tables: null pointer");
     PTTS_REQUIRE(KT_ == 5 && KF_ == 5 && Cin == 4 && Cout == 4, "conv2d_mfma_tables: only 5x5, 4 -> 4 channels (got %dx%d, %d -> %d)", KT_, KF_, Cin, Cout);
-    hipLaunchKernelGGL(toeplitz_table_kernel, dim3(2), dim3(64 * KT), 0, (hipStream_t)stream, w, (u16*)table_fwd, (u16*)table_bwd);
+    PTTS_REQUIRE(planes == 1 || planes == 3, "conv2d_mfma_tables: planes must be 1 (bf16) or 3 (fp32 split), got %d", planes);
+    hipLaunchKernelGGL(toeplitz_table_kernel, dim3(2), dim3(64 * KT), 0, (hipStream_t)stream, w, (u16*)table_fwd, (u16*)table_bwd, planes);
     return check_launch("conv2d_mfma_tables");
 }
 
@@ -585,9 +587,9 @@ Shape make_shape(int B, int T, int F, int pad_t) {
 }
 bool shape_ok(const Shape& s) { return s.ntiles > 0 && s.ntiles < (1 << 20) && s.nfb < 4096 && s.ntt < 4096; }
 
-template <int DIL> constexpr size_t lds_fwd() { return ((size_t)NP * Stage<4 * GPB + 4, 16 + (KT - 1) * DIL>::PS + (size_t)KT * NP * 64 * 8) * sizeof(u16); }
-template <int DIL> constexpr size_t lds_wgrad() {
-    const size_t planes = (size_t)NP * (Stage<4 * (GPB + 1) + 4, 16 + (KT - 1) * DIL>::PS + Stage<4 * (GPB + 1) + 4, 16>::PS) * sizeof(u16);
+template <int DIL, int NPL> constexpr size_t lds_fwd() { return ((size_t)NPL * Stage<4 * GPB + 4, 16 + (KT - 1) * DIL>::PS + (size_t)KT * NPL * 64 * 8) * sizeof(u16); }
+template <int DIL, int NPL> constexpr size_t lds_wgrad() {
+    const size_t planes = (size_t)NPL * (Stage<4 * (GPB + 1) + 4, 16 + (KT - 1) * DIL>::PS + Stage<4 * (GPB + 1) + 4, 16>::PS) * sizeof(u16);
     const size_t red = (size_t)(4 * KT * 2 * 4 * 64 + THREADS * 4) * sizeof(float);
     return planes > red ? planes : red;
 }
@@ -608,10 +610,12 @@ extern "C" int ptts_conv2d_mfma_supported(int F, int Cin, int Cout, int KT_, int
 // y = bias + conv(transform(x), w) through the forward table; with out_mask: y *= (out_mask > 0 ? 1 : alpha)
 // (the backward-data pass: x = dy, table = the transposed table, pad_t = (KT-1) dil - pad_t(forward), out_mask = the
 // forward layer's pre-activation input).
-extern "C" int ptts_conv2d_mfma_fwd(const float* x, const void* table, const float* bias, const float* in_scale,
-                                    const float* in_shift, const float* mask_src, const float* out_mask, float* y,
+// planes 3: fp32 arithmetic, x / y fp32.  planes 1: bf16 arithmetic (dilation 1): x and mask_src are bf16 when
+// in_bf16, y and out_mask are bf16 when out_bf16, fp32 otherwise.
+extern "C" int ptts_conv2d_mfma_fwd(const void* x, const void* table, const float* bias, const float* in_scale,
+                                    const float* in_shift, const void* mask_src, const void* out_mask, void* y,
                                     int B, int T, int F, int KT_, int dil_t, int pad_t, int in_mode, float alpha,
-                                    void* stream) {
+                                    int planes, int in_bf16, int out_bf16, void* stream) {
     PTTS_REQUIRE(x && table && y, "conv2d_mfma_fwd: null tensor");
     PTTS_REQUIRE(B > 0 && T > 0 && F > 0 && KT_ == 5, "conv2d_mfma_fwd: bad dims B=%d T=%d F=%d KT=%d", B, T, F, KT_);
     PTTS_REQUIRE(dil_t == 1 || dil_t == 2 || dil_t == 4 || dil_t == 8, "conv2d_mfma_fwd: time dilation %d has no kernel (1, 2, 4, 8)", dil_t);
@@ -622,27 +626,31 @@ extern "C" int ptts_conv2d_mfma_fwd(const float* x, const void* table, const flo
     PTTS_REQUIRE(pad_t >= 0 && pad_t <= (KT - 1) * dil_t, "conv2d_mfma_fwd: bad pad_t %d", pad_t);
     PTTS_REQUIRE(alpha >= 0.f && alpha <= 1.f, "conv2d_mfma_fwd: LeakyReLU slope %g outside [0, 1]", alpha);
     PTTS_REQUIRE((long long)(T + 64) * F * C < (1LL << 31), "conv2d_mfma_fwd: utterance too large for 32-bit tile offsets");
+    PTTS_REQUIRE(planes == 3 || (planes == 1 && dil_t == 1), "conv2d_mfma_fwd: planes %d / dilation %d: bf16 arithmetic is built for dilation 1", planes, dil_t);
+    PTTS_REQUIRE(planes == 1 || (!in_bf16 && !out_bf16), "conv2d_mfma_fwd: bf16 tensors need planes == 1");
     const Shape s = make_shape(B, T, F, pad_t);
     PTTS_REQUIRE(shape_ok(s), "conv2d_mfma_fwd: too many tiles");
     hipStream_t st = (hipStream_t)stream;
     const bool om = out_mask != nullptr;
-#define C2M_L(DIL, MODE, OM)                                                                                             \
+    const int dt = (in_bf16 ? DT_IN : 0) | (out_bf16 ? DT_OUT : 0);
+#define C2M_L(DIL, MODE, OM, NPL)                                                                                        \
     do {                                                                                                                 \
-        constexpr size_t lds = lds_fwd<DIL>();                                                                           \
+        constexpr size_t lds = lds_fwd<DIL, NPL>();                                                                      \
         static_assert(lds <= LDS_MAX, "tile does not fit the LDS");                                                      \
         static bool attr = false;                                                                                        \
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_kernel<DIL, MODE, OM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX); attr = true; } \
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_kernel<DIL, MODE, OM, NPL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX); attr = true; } \
         const int grid = grid_for(s.ntiles, lds, DIL == 1 ? 3 : (DIL == 2 ? 2 : 1));                                     \
-        hipLaunchKernelGGL((fwd_kernel<DIL, MODE, OM>), dim3(grid), dim3(THREADS), lds, st, x, (const u16*)table, bias,  \
-                           in_scale, in_shift, mask_src, out_mask, y, s, alpha, g_dbg, g_dbg_buf);                       \
+        hipLaunchKernelGGL((fwd_kernel<DIL, MODE, OM, NPL>), dim3(grid), dim3(THREADS), lds, st, x, (const u16*)table, bias, \
+                           in_scale, in_shift, mask_src, out_mask, y, dt, s, alpha, g_dbg, g_dbg_buf);                   \
     } while (0)
-#define C2M_M(DIL)                                                                                                       \
+#define C2M_M(DIL, NPL)                                                                                                  \
     do {                                                                                                                 \
-        if (in_mode == PTTS_IN_LRELU) { if (om) C2M_L(DIL, PTTS_IN_LRELU, true); else C2M_L(DIL, PTTS_IN_LRELU, false); } \
-        else if (in_mode == PTTS_IN_MASKMUL) { PTTS_REQUIRE(!om, "conv2d_mfma_fwd: MASKMUL with an output mask has no kernel"); C2M_L(DIL, PTTS_IN_MASKMUL, false); } \
-        else { if (om) C2M_L(DIL, PTTS_IN_NONE, true); else C2M_L(DIL, PTTS_IN_NONE, false); }                           \
+        if (in_mode == PTTS_IN_LRELU) { if (om) C2M_L(DIL, PTTS_IN_LRELU, true, NPL); else C2M_L(DIL, PTTS_IN_LRELU, false, NPL); } \
+        else if (in_mode == PTTS_IN_MASKMUL) { PTTS_REQUIRE(!om, "conv2d_mfma_fwd: MASKMUL with an output mask has no kernel"); C2M_L(DIL, PTTS_IN_MASKMUL, false, NPL); } \
+        else { if (om) C2M_L(DIL, PTTS_IN_NONE, true, NPL); else C2M_L(DIL, PTTS_IN_NONE, false, NPL); }                 \
     } while (0)
-    if (dil_t == 1) C2M_M(1); else if (dil_t == 2) C2M_M(2); else if (dil_t == 4) C2M_M(4); else C2M_M(8);
+    if (planes == 1) C2M_M(1, 1);
+    else if (dil_t == 1) C2M_M(1, 3); else if (dil_t == 2) C2M_M(2, 3); else if (dil_t == 4) C2M_M(4, 3); else C2M_M(8, 3);
 #undef C2M_M
 #undef C2M_L
     return check_launch("conv2d_mfma_fwd");
@@ -654,10 +662,12 @@ extern "C" size_t ptts_conv2d_mfma_wgrad_workspace_bytes(int B, int T) {
 }
 
 // per-workgroup partial sums of dW / dbias as rows [nblocks][npart] behind a 4096-byte head of `workspace` (the layout of
-// ptts_conv2d_bwd_partials: ptts_conv2d_reduce_grouped adds them into the gradient buffers)
-extern "C" int ptts_conv2d_mfma_wgrad_partials(const float* dy, const float* x, const float* mask_src, void* workspace,
+// ptts_conv2d_bwd_partials: ptts_conv2d_reduce_grouped adds them into the gradient buffers).  planes / x_bf16 / dy_bf16 as
+// in ptts_conv2d_mfma_fwd (mask_src has x's type); the sums are fp32 either way.
+extern "C" int ptts_conv2d_mfma_wgrad_partials(const void* dy, const void* x, const void* mask_src, void* workspace,
                                                size_t workspace_bytes, int* nblocks_out, int* npart_out, int B, int T, int F,
-                                               int KT_, int dil_t, int pad_t, int in_mode, float alpha, void* stream) {
+                                               int KT_, int dil_t, int pad_t, int in_mode, float alpha,
+                                               int planes, int x_bf16, int dy_bf16, void* stream) {
     PTTS_REQUIRE(dy && x && workspace && nblocks_out && npart_out, "conv2d_mfma_wgrad: null pointer");
     PTTS_REQUIRE(B > 0 && T > 0 && F > 0 && KT_ == 5, "conv2d_mfma_wgrad: bad dims");
     PTTS_REQUIRE(dil_t == 1 || dil_t == 2 || dil_t == 4 || dil_t == 8, "conv2d_mfma_wgrad: time dilation %d has no kernel (1, 2, 4, 8)", dil_t);
@@ -666,29 +676,33 @@ extern "C" int ptts_conv2d_mfma_wgrad_partials(const float* dy, const float* x, 
     PTTS_REQUIRE(pad_t >= 0 && pad_t <= (KT - 1) * dil_t, "conv2d_mfma_wgrad: bad pad_t %d", pad_t);
     PTTS_REQUIRE(alpha >= 0.f && alpha <= 1.f, "conv2d_mfma_wgrad: LeakyReLU slope %g outside [0, 1]", alpha);
     PTTS_REQUIRE((long long)(T + 64) * F * C < (1LL << 31), "conv2d_mfma_wgrad: utterance too large for 32-bit tile offsets");
+    PTTS_REQUIRE(planes == 3 || (planes == 1 && dil_t == 1), "conv2d_mfma_wgrad: planes %d / dilation %d: bf16 arithmetic is built for dilation 1", planes, dil_t);
+    PTTS_REQUIRE(planes == 1 || (!x_bf16 && !dy_bf16), "conv2d_mfma_wgrad: bf16 tensors need planes == 1");
     const Shape s = make_shape(B, T, F, pad_t);
     PTTS_REQUIRE(shape_ok(s), "conv2d_mfma_wgrad: too many tiles");
     const size_t need = ptts_conv2d_mfma_wgrad_workspace_bytes(B, T);
     if (workspace_bytes < need) { set_error("conv2d_mfma_wgrad: workspace %zu < %zu", workspace_bytes, need); return PTTS_EWORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     float* parts = reinterpret_cast<float*>((char*)workspace + 4096);
+    const int dt = (x_bf16 ? DT_IN : 0) | (dy_bf16 ? DT_DY : 0);
     int grid = 0;
-#define C2M_L(DIL, MODE)                                                                                                 \
+#define C2M_L(DIL, MODE, NPL)                                                                                            \
     do {                                                                                                                 \
-        constexpr size_t lds = lds_wgrad<DIL>();                                                                         \
+        constexpr size_t lds = lds_wgrad<DIL, NPL>();                                                                    \
         static_assert(lds <= LDS_MAX, "tile does not fit the LDS");                                                      \
         static bool attr = false;                                                                                        \
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<DIL, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX); attr = true; } \
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<DIL, MODE, NPL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX); attr = true; } \
         grid = grid_for(s.ntiles, lds, DIL <= 2 ? 2 : 1);                                                                \
-        hipLaunchKernelGGL((wgrad_kernel<DIL, MODE>), dim3(grid), dim3(THREADS), lds, st, x, dy, mask_src, parts, s, alpha, g_dbg, g_dbg_buf); \
+        hipLaunchKernelGGL((wgrad_kernel<DIL, MODE, NPL>), dim3(grid), dim3(THREADS), lds, st, x, dy, mask_src, parts, dt, s, alpha, g_dbg, g_dbg_buf); \
     } while (0)
-#define C2M_M(DIL)                                                                                                       \
+#define C2M_M(DIL, NPL)                                                                                                  \
     do {                                                                                                                 \
-        if (in_mode == PTTS_IN_LRELU) C2M_L(DIL, PTTS_IN_LRELU);                                                         \
-        else if (in_mode == PTTS_IN_MASKMUL) C2M_L(DIL, PTTS_IN_MASKMUL);                                                \
-        else C2M_L(DIL, PTTS_IN_NONE);                                                                                   \
+        if (in_mode == PTTS_IN_LRELU) C2M_L(DIL, PTTS_IN_LRELU, NPL);                                                    \
+        else if (in_mode == PTTS_IN_MASKMUL) C2M_L(DIL, PTTS_IN_MASKMUL, NPL);                                           \
+        else C2M_L(DIL, PTTS_IN_NONE, NPL);                                                                              \
     } while (0)
-    if (dil_t == 1) C2M_M(1); else if (dil_t == 2) C2M_M(2); else if (dil_t == 4) C2M_M(4); else C2M_M(8);
+    if (planes == 1) C2M_M(1, 1);
+    else if (dil_t == 1) C2M_M(1, 3); else if (dil_t == 2) C2M_M(2, 3); else if (dil_t == 4) C2M_M(4, 3); else C2M_M(8, 3);
 #undef C2M_M
 #undef C2M_L
     *nblocks_out = grid;

@@ -739,7 +739,7 @@ extern "C" int ptts_gp_scale_rows(const float* g, const float* coef, const float
 extern "C" int ptts_mean_scaled(const float* v, long long n, float sign, float* out, void* stream) {
     PTTS_REQUIRE(v && out && n > 0, "mean_scaled: bad args");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) { set_error("mean_scaled: memset"); return PTTS_ELAUNCH; }
+    if (zero_f32(out, 1, st) != PTTS_OK) return PTTS_ELAUNCH;
     int nb = (int)((n + 4095) / 4096);
     if (nb > 256) nb = 256;
     if (deterministic()) nb = 1;      // one workgroup: one float add into the zeroed scalar
@@ -751,7 +751,7 @@ extern "C" int ptts_wlse_fwd(const float* y, const float* yhat, const float* w, 
                              void* stream) {
     PTTS_REQUIRE(y && yhat && out && rows > 0 && D > 0, "wlse_fwd: bad args");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) { set_error("wlse_fwd: memset"); return PTTS_ELAUNCH; }
+    if (zero_f32(out, 1, st) != PTTS_OK) return PTTS_ELAUNCH;
     const long long n = rows * D;
     int nb = (int)((n + 4095) / 4096);
     if (nb > 512) nb = 512;

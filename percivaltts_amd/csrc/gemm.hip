@@ -996,15 +996,9 @@ extern "C" int ptts_gemm(const float* A, const float* Bm, const float* bias, flo
     g.workers = (int)workers;
     const bool split = (g.iters_total % workers != 0) || ((g.iters_total / workers) % g.ksteps != 0);
     if (split && !accumulate) {
-        hipError_t e;
-        if (ldc == N) e = hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), st);
-        else e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, st);
-        if (e != hipSuccess) { set_error("gemm: memset failed: %s", hipGetErrorString(e)); return PTTS_ELAUNCH; }
+        if (zero_f32_2d(C, (size_t)ldc, (size_t)N, (size_t)M, st) != PTTS_OK) return PTTS_ELAUNCH;
     }
-    if (colsum_b && hipMemsetAsync(colsum_b, 0, (size_t)N * sizeof(float), st) != hipSuccess) {
-        set_error("gemm: colsum memset failed");
-        return PTTS_ELAUNCH;
-    }
+    if (colsum_b && zero_f32(colsum_b, (size_t)N, st) != PTTS_OK) return PTTS_ELAUNCH;
     dim3 grid(g.workers), block(GEMM_THREADS);
     const bool conv = seg_stride != 0;
 #define PTTS_GEMM_LAUNCH(TA, TB, CV, MD) hipLaunchKernelGGL((gemm_f32_mfma_kernel<TA, TB, CV, MD>), grid, block, 0, st, g)

@@ -381,8 +381,7 @@ extern "C" int ptts_conv1d_bf16x6(const void* a1, const void* a2, const void* a3
     g.workers = (int)workers;
     // partial tiles are combined with atomics into a zeroed y
     if (g.iters_total % workers != 0 || (g.iters_total / workers) % g.cblocks != 0) {
-        hipError_t e = hipMemsetAsync(y, 0, (size_t)g.M * N * sizeof(float), st);
-        if (e != hipSuccess) { set_error("conv1d_bf16x6: memset failed: %s", hipGetErrorString(e)); return PTTS_ELAUNCH; }
+        if (zero_f32(y, (size_t)g.M * N, st) != PTTS_OK) return PTTS_ELAUNCH;
     }
     hipLaunchKernelGGL(gemm_bf16x6_kernel, dim3(g.workers), dim3(S_THREADS), S_LDS_BYTES, st, g);
     return check_launch("conv1d_bf16x6");
@@ -599,8 +598,7 @@ extern "C" int ptts_conv1d_wgrad_bf16x6(const void* xt1, const void* xt2, const 
     if (nsplit < 1) nsplit = 1;
     if (nsplit > qsteps) nsplit = qsteps;
     g.nsplit = nsplit; g.steps_per_split = (qsteps + nsplit - 1) / nsplit;
-    hipError_t e = hipMemsetAsync(dw, 0, (size_t)KW * C * N * sizeof(float), st);
-    if (e != hipSuccess) { set_error("conv1d_wgrad_bf16x6: memset failed: %s", hipGetErrorString(e)); return PTTS_ELAUNCH; }
+    if (zero_f32(dw, (size_t)KW * C * N, st) != PTTS_OK) return PTTS_ELAUNCH;
 #define PTTS_WG_LAUNCH(KWV)                                                                                               \
     {                                                                                                                     \
         static bool attr = false;                                                                                         \

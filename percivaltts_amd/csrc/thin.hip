@@ -244,10 +244,7 @@ int thin_gemm_dispatch(const float* A, const float* Bm, const float* bias, float
     }
     if (transA == 1 && transB == 0 && N <= 2 && K >= 1024 && !bias && !out_mask && rows_per_seg >= K && !deterministic()) {
         if (!accumulate) {
-            hipError_t e;
-            if (ldc == N) e = hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), st);
-            else e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, st);
-            if (e != hipSuccess) { set_error("wcol: memset failed"); return PTTS_ELAUNCH; }
+            if (zero_f32_2d(C, (size_t)ldc, (size_t)N, (size_t)M, st) != PTTS_OK) return PTTS_ELAUNCH;
         }
         const int cb = (M + 63) / 64;
         int rb = 1024 / cb;

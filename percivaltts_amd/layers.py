@@ -255,6 +255,7 @@ class Conv2D(Layer):
         self.filters, self.use_bias, self.activation = int(filters), bool(use_bias), activation
         self.kt, self.kf = int(kernel_size[0]), int(kernel_size[1])
         self.dil_t, self.causal = int(dil_t), bool(causal)
+        self.bf16 = None          # 'out16' / 'out32': bf16 arithmetic with a bf16 / fp32 result map (ops.Conv2dFn); set by the network builder
 
     def build(self, in_shapes):
         cin = in_shapes[0][-1]
@@ -268,7 +269,7 @@ class Conv2D(Layer):
         v = vals[0]
         if isinstance(v, LazyConcat):
             v = v.tensor()
-        z = ops.conv2d(v, self.kernel, self.bias, self.dil_t, ops.PAD_CAUSAL if self.causal else ops.PAD_SAME)
+        z = ops.conv2d(v, self.kernel, self.bias, self.dil_t, ops.PAD_CAUSAL if self.causal else ops.PAD_SAME, self.bf16)
         return _apply_activation(z, self.activation)
 
 

@@ -32,8 +32,16 @@ class Critic:
 
         if cfgarch.arch_gen_nbcnnlayers > 0:
             l_spec = kl.Reshape([vocoder.specsize(), 1])(l_spec)
-            for _ in range(cfgarch.arch_gen_nbcnnlayers):
-                l_spec = kl.Conv2D(cfgarch.arch_gen_nbfilters, [cfgarch.arch_gen_winlen, cfgarch.arch_spec_freqlen])(l_spec)
+            # build extension (BASELINE configs[2]): cfgarch.arch_critic_bf16 stores the maps between the 4 -> 4 channel layers
+            # (and their gradients) as bf16 and multiplies in bf16 with fp32 accumulation; the first layer (1 -> 4) and the
+            # map handed to the dense layers stay fp32, like the master weights and every weight gradient
+            bf16 = bool(getattr(cfgarch, 'arch_critic_bf16', False))
+            L = cfgarch.arch_gen_nbcnnlayers
+            for li in range(L):
+                conv = kl.Conv2D(cfgarch.arch_gen_nbfilters, [cfgarch.arch_gen_winlen, cfgarch.arch_spec_freqlen])
+                if bf16 and li >= 1 and cfgarch.arch_gen_nbfilters == 4 and cfgarch.arch_gen_winlen == 5 and cfgarch.arch_spec_freqlen == 5:
+                    conv.bf16 = 'out16' if li < L - 1 else 'out32'
+                l_spec = conv(l_spec)
                 l_spec = kl.LeakyReLU(alpha=0.3)(l_spec)
             l_spec = kl.Reshape([l_spec.shape[-2] * l_spec.shape[-1]])(l_spec)
         else:

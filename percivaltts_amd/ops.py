@@ -237,18 +237,18 @@ class _C2M(object):
         return x.is_cuda and Cin == 4 and Cout == 4 and KT == 5 and KF == 5 and dil_t in (1, 2, 4, 8)
 
     @classmethod
-    def table(cls, w, transposed):
+    def table(cls, w, transposed, planes=3):
         flat = getattr(w, '_ptts_flat', None)
         epoch = None if flat is None else flat.epoch
         sid = torch.cuda.current_stream().cuda_stream
-        key = (id(w), sid)         # one copy per stream: the build is ordered with its consumers by the stream itself
+        key = (id(w), sid, planes)         # one copy per stream: the build is ordered with its consumers by the stream itself
         ent = cls.tables.get(key)
         if ent is None or ent[0] is not w or ent[1] != w._version or ent[2] != epoch or flat is None:
             nb = _hip.lib().ptts_conv2d_mfma_table_bytes(5)
             reuse = ent is not None and ent[0] is w
             tf = ent[3] if reuse else torch.empty(nb, dtype=torch.uint8, device=w.device)
             tb = ent[4] if reuse else torch.empty(nb, dtype=torch.uint8, device=w.device)
-            call('ptts_conv2d_mfma_tables', ptr(w), ptr(tf), ptr(tb), 5, 5, 4, 4, stream(), tag=(5, 5))
+            call('ptts_conv2d_mfma_tables', ptr(w), ptr(tf), ptr(tb), 5, 5, 4, 4, planes, stream(), tag=(5, 5, planes))
             ent = (w, w._version, epoch, tf, tb)
             if len(cls.tables) > 512:
                 cls.tables = {}
@@ -275,26 +275,54 @@ def conv2d_path_description():
             if _C2M.enabled else 'fp32 packed-FMA stencil')
 
 
-def _conv2d_mfma_fwd(x, w, table, b, scale, shift, mask_src, out_mask, mode, alpha, dil_t, pad_t):
+def _is16(t):
+    return t is not None and t.dtype == torch.bfloat16
+
+
+def _conv2d_mfma_fwd(x, w, table, b, scale, shift, mask_src, out_mask, mode, alpha, dil_t, pad_t, planes=3, out_bf16=False):
     B, T, F, _ = x.shape
-    y = torch.empty((B, T, F, 4), dtype=torch.float32, device=x.device)
+    assert planes in (1, 3) and (planes == 1 or not (_is16(x) or out_bf16)), 'bf16 tensors need the one-plane (bf16 arithmetic) kernels'
+    assert mask_src is None or mask_src.dtype == x.dtype, 'conv2d: the mask source has the input\'s storage type'
+    y = torch.empty((B, T, F, 4), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    assert out_mask is None or out_mask.dtype == y.dtype, 'conv2d: the output mask has the output\'s storage type'
     call('ptts_conv2d_mfma_fwd', ptr(x), ptr(table), ptr(b), ptr(scale), ptr(shift), ptr(mask_src), ptr(out_mask), ptr(y),
-         B, T, F, 5, dil_t, pad_t, mode, alpha, stream(), tag=(B, T, F, 4, 4, mode, int(out_mask is not None)))
+         B, T, F, 5, dil_t, pad_t, mode, alpha, planes, int(_is16(x)), int(out_bf16), stream(),
+         tag=(B, T, F, 4, 4, mode, int(out_mask is not None), planes))
     return y
 
 
-def _conv2d_mfma_wgrad(dy, x, mask_src, mode, alpha, dil_t, pad_t):
+def _conv2d_mfma_wgrad(dy, x, mask_src, mode, alpha, dil_t, pad_t, planes=3):
     """Partial sums of dW / dbias: (buffer, nblocks, npart); the rows start 4096 bytes into the buffer."""
     B, T, F, _ = x.shape
+    assert planes == 1 or not (_is16(x) or _is16(dy))
+    assert mask_src is None or mask_src.dtype == x.dtype
     nws = _hip.lib().ptts_conv2d_mfma_wgrad_workspace_bytes(B, T)
     buf = torch.empty(int(nws), dtype=torch.uint8, device=x.device)
     nblocks, npart = ctypes.c_int(0), ctypes.c_int(0)
     call('ptts_conv2d_mfma_wgrad_partials', ptr(dy), ptr(x), ptr(mask_src), ptr(buf), buf.numel(), ctypes.byref(nblocks),
-         ctypes.byref(npart), B, T, F, 5, dil_t, pad_t, mode, alpha, stream(), tag=(B, T, F, 4, 4, mode))
+         ctypes.byref(npart), B, T, F, 5, dil_t, pad_t, mode, alpha, planes, int(_is16(x)), int(_is16(dy)), stream(),
+         tag=(B, T, F, 4, 4, mode, planes))
     return buf, nblocks.value, npart.value
 
 
-def _conv2d_fwd_raw(x, w, b, scale, shift, mask_src, mode, alpha, dil_t, pad_mode):
+def _st(t, name='tensor'):
+    """Validate a conv2d map of the bf16-storage path: contiguous device tensor, fp32 or bf16."""
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype in (torch.float32, torch.bfloat16) and t.is_contiguous()):
+        raise _hip.HipLibraryError('{}: expected a contiguous float32 / bfloat16 device tensor, got {} {} contiguous={}'.format(
+            name, t.device, t.dtype, t.is_contiguous()))
+    return t
+
+
+def _conv2d_fwd_raw(x, w, b, scale, shift, mask_src, mode, alpha, dil_t, pad_mode, planes=3, out_bf16=False):
+    if planes == 1:
+        # bf16 arithmetic / storage (BASELINE configs[2]): matrix-core kernels only
+        _st(x, 'conv2d.x'); _st(mask_src, 'conv2d.mask_src'); f32c(w, 'conv2d.w'); f32c(b, 'conv2d.b'); f32c(scale); f32c(shift)
+        if not (_C2M.eligible(x, w, dil_t) and dil_t == 1 and 0.0 <= alpha <= 1.0):
+            raise _hip.HipLibraryError('conv2d: bf16 storage is built for the 4 -> 4 channel 5x5 layers at dilation 1')
+        return _conv2d_mfma_fwd(x, w, _C2M.table(w, False, 1), b, scale, shift, mask_src, None, mode, alpha, dil_t,
+                                _C2M.pad_t(dil_t, pad_mode), 1, out_bf16)
     f32c(x, 'conv2d.x'); f32c(w, 'conv2d.w'); f32c(b, 'conv2d.b'); f32c(scale); f32c(shift); f32c(mask_src)
     B, T, F, Cin = x.shape
     KT, KF, Ci2, Cout = w.shape
@@ -312,24 +340,29 @@ def _conv2d_fwd_raw(x, w, b, scale, shift, mask_src, mode, alpha, dil_t, pad_mod
 
 
 def _conv2d_bwd_raw(dy, x, w, scale, shift, mask_src, mode, alpha, dil_t, pad_mode,
-                    want_dx, want_dw, want_db, want_affine):
-    f32c(dy, 'conv2d_bwd.dy'); f32c(x, 'conv2d_bwd.x'); f32c(w); f32c(scale); f32c(shift); f32c(mask_src)
+                    want_dx, want_dw, want_db, want_affine, planes=3):
+    if planes == 1:
+        _st(dy, 'conv2d_bwd.dy'); _st(x, 'conv2d_bwd.x'); _st(mask_src); f32c(w)
+        assert scale is None and not want_affine, 'conv2d: no BatchNorm-fused input on the bf16-storage path'
+    else:
+        f32c(dy, 'conv2d_bwd.dy'); f32c(x, 'conv2d_bwd.x'); f32c(w); f32c(scale); f32c(shift); f32c(mask_src)
     B, T, F, Cin = x.shape
     KT, KF, _, Cout = w.shape
     assert dy.shape == (B, T, F, Cout), 'conv2d_bwd: dy shape {} vs {}'.format(tuple(dy.shape), (B, T, F, Cout))
     assert mask_src is None or mask_src.shape == x.shape
     dev = x.device
-    if _C2M.enabled and _C2M.eligible(x, w, dil_t) and scale is None and not want_affine and 0.0 <= alpha <= 1.0:
+    if (planes == 1 or _C2M.enabled) and _C2M.eligible(x, w, dil_t) and scale is None and not want_affine and 0.0 <= alpha <= 1.0:
         # matrix-core kernels: backward data = forward through the transposed table with the layer input's LeakyReLU mask
-        # in the store; weight gradient = per-workgroup partial sums + the grouped reduction
+        # in the store; weight gradient = per-workgroup partial sums + the grouped reduction.  The gradient of a map is
+        # stored like the map (bf16 storage: dx has x's type)
         pad_t = _C2M.pad_t(dil_t, pad_mode)
         dx = dw = db = None
         if want_dx:
             assert mode != IN_MASKMUL, 'conv2d_bwd: dx is not defined for MASKMUL (weight-only sweep)'
-            dx = _conv2d_mfma_fwd(dy, w, _C2M.table(w, True), None, None, None, None, x if mode == IN_LRELU else None,
-                                  IN_NONE, alpha, dil_t, 4 * dil_t - pad_t)
+            dx = _conv2d_mfma_fwd(dy, w, _C2M.table(w, True, planes), None, None, None, None, x if mode == IN_LRELU else None,
+                                  IN_NONE, alpha, dil_t, 4 * dil_t - pad_t, planes, _is16(x))
         if want_dw or want_db:
-            buf, nblocks, npart = _conv2d_mfma_wgrad(dy, x, mask_src, mode, alpha, dil_t, pad_t)
+            buf, nblocks, npart = _conv2d_mfma_wgrad(dy, x, mask_src, mode, alpha, dil_t, pad_t, planes)
             dw = torch.zeros_like(w) if want_dw else None
             db = torch.zeros(Cout, dtype=torch.float32, device=dev) if want_db else None
             desc = (_hip.Conv2dReduceDesc * 1)()
@@ -353,19 +386,19 @@ def _conv2d_bwd_raw(dy, x, w, scale, shift, mask_src, mode, alpha, dil_t, pad_mo
     return dx, (dw if want_dw else None), db, dscale, dshift
 
 
-def _conv2d_bwd_deferred(dy, x, w, mask_src, mode, alpha, dil_t, pad_mode, want_dx, gw, gb):
+def _conv2d_bwd_deferred(dy, x, w, mask_src, mode, alpha, dil_t, pad_mode, want_dx, gw, gb, planes=3):
     """conv2d backward whose dw / dbias stay as per-workgroup partial sums in a buffer of their own; the reduction into
     the gradient buffers gw / gb is queued for the grouped launch at flush time.  Returns dx (or None), or False when
     this shape has no tiled kernel."""
     B, T, F, Cin = x.shape
     KT, KF, _, Cout = w.shape
-    if _C2M.enabled and _C2M.eligible(x, w, dil_t) and 0.0 <= alpha <= 1.0:
+    if (planes == 1 or _C2M.enabled) and _C2M.eligible(x, w, dil_t) and 0.0 <= alpha <= 1.0:
         pad_t = _C2M.pad_t(dil_t, pad_mode)
         dx = None
         if want_dx:
-            dx = _conv2d_mfma_fwd(dy, w, _C2M.table(w, True), None, None, None, None, x if mode == IN_LRELU else None,
-                                  IN_NONE, alpha, dil_t, 4 * dil_t - pad_t)
-        buf, nblocks, npart = _conv2d_mfma_wgrad(dy, x, mask_src, mode, alpha, dil_t, pad_t)
+            dx = _conv2d_mfma_fwd(dy, w, _C2M.table(w, True, planes), None, None, None, None, x if mode == IN_LRELU else None,
+                                  IN_NONE, alpha, dil_t, 4 * dil_t - pad_t, planes, _is16(x))
+        buf, nblocks, npart = _conv2d_mfma_wgrad(dy, x, mask_src, mode, alpha, dil_t, pad_t, planes)
         cur = torch.cuda.current_stream()
         if all(cur.cuda_stream != st.cuda_stream for st in _Deferred.streams):
             _Deferred.streams.append(cur)
@@ -443,20 +476,25 @@ def _affine_act_bwd_raw(dy, x, y, scale, shift, act, alpha, want_dx=True):
 # Conv2D  (kl.Conv2D: networks_critic.py:67; networktts.py:123; modeltts_common.py:100)
 # ----------------------------------------------------------------------------------------------
 class Conv2dFn(torch.autograd.Function):
+    """bf16 = None: fp32 arithmetic and storage.  bf16 = 'out16' / 'out32' (BASELINE configs[2]): bf16 arithmetic on the
+    matrix cores -- the input map may be stored as bf16 or fp32, the result is stored as bf16 / fp32; the gradient of a
+    map is stored like the map; weight gradients and master weights stay fp32."""
     @staticmethod
-    def forward(ctx, x, w, b, scale, shift, mode, alpha, dil_t, pad_mode):
+    def forward(ctx, x, w, b, scale, shift, mode, alpha, dil_t, pad_mode, bf16=None):
         ctx.save_for_backward(x, w, scale, shift)
         ctx.has_b = b is not None
         ctx.cfg = (mode, alpha, dil_t, pad_mode)
+        ctx.planes = 1 if bf16 else 3
         # persistent gradient buffers of kernel / bias (deferred, grouped reduction of the backward's partial sums)
         ctx.gw = grad_target(w) if _Deferred.active else None
         ctx.gb = grad_target(b) if (_Deferred.active and b is not None) else None
-        return _conv2d_fwd_raw(x, w, b, scale, shift, None, mode, alpha, dil_t, pad_mode)
+        return _conv2d_fwd_raw(x, w, b, scale, shift, None, mode, alpha, dil_t, pad_mode, ctx.planes, bf16 == 'out16')
 
     @staticmethod
     def backward(ctx, dy):
         x, w, scale, shift = ctx.saved_tensors
         mode, alpha, dil_t, pad_mode = ctx.cfg
+        planes = ctx.planes
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_b and ctx.needs_input_grad[2]
         need_aff = scale is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
         dy = dy.contiguous()
@@ -466,25 +504,25 @@ class Conv2dFn(torch.autograd.Function):
             # differentiable backward (gradient penalty): dx is itself a Function of (dy, w)
             if scale is not None:
                 raise RuntimeError('second-order gradients through a BatchNorm-fused conv2d are not supported')
-            dx = Conv2dBwdDataFn.apply(dy, x, w, mode, alpha, dil_t, pad_mode, ctx.gw)
+            dx = Conv2dBwdDataFn.apply(dy, x, w, mode, alpha, dil_t, pad_mode, ctx.gw, planes)
             dw = db = None
             if need_w or need_b:
                 with torch.no_grad():
                     if _conv2d_can_defer(ctx, need_w, need_b) and \
                             _conv2d_bwd_deferred(dy, x, w, None, mode, alpha, dil_t, pad_mode, False,
-                                                 ctx.gw if need_w else None, ctx.gb if need_b else None) is not False:
-                        return dx, None, None, None, None, None, None, None, None
+                                                 ctx.gw if need_w else None, ctx.gb if need_b else None, planes) is not False:
+                        return dx, None, None, None, None, None, None, None, None, None
                     _, dw, db, _, _ = _conv2d_bwd_raw(dy, x, w, None, None, None, mode, alpha, dil_t, pad_mode,
-                                                      False, need_w, need_b, False)
-            return dx, dw, db, None, None, None, None, None, None
+                                                      False, need_w, need_b, False, planes)
+            return dx, dw, db, None, None, None, None, None, None, None
         if (need_w or need_b) and not need_aff and scale is None and _conv2d_can_defer(ctx, need_w, need_b):
             dxd = _conv2d_bwd_deferred(dy, x, w, None, mode, alpha, dil_t, pad_mode, need_x,
-                                       ctx.gw if need_w else None, ctx.gb if need_b else None)
+                                       ctx.gw if need_w else None, ctx.gb if need_b else None, planes)
             if dxd is not False:
-                return dxd, None, None, None, None, None, None, None, None
+                return dxd, None, None, None, None, None, None, None, None, None
         dx, dw, db, dscale, dshift = _conv2d_bwd_raw(dy, x, w, scale, shift, None, mode, alpha, dil_t, pad_mode,
-                                                     need_x, need_w, need_b, need_aff)
-        return dx, dw, db, dscale, dshift, None, None, None, None
+                                                     need_x, need_w, need_b, need_aff, planes)
+        return dx, dw, db, dscale, dshift, None, None, None, None, None
 
 
 def _conv2d_can_defer(ctx, need_w, need_b):
@@ -494,12 +532,13 @@ def _conv2d_can_defer(ctx, need_w, need_b):
 class Conv2dBwdDataFn(torch.autograd.Function):
     """dx = d(a)/d(x) * conv^T(dy, w).  Linear in dy and in w; its backward is the second-order sweep."""
     @staticmethod
-    def forward(ctx, dy, x, w, mode, alpha, dil_t, pad_mode, gw=None):
+    def forward(ctx, dy, x, w, mode, alpha, dil_t, pad_mode, gw=None, planes=3):
         ctx.save_for_backward(dy, x, w)
         ctx.cfg = (mode, alpha, dil_t, pad_mode)
         ctx.gw = gw
+        ctx.planes = planes
         dx, _, _, _, _ = _conv2d_bwd_raw(dy, x, w, None, None, None, mode, alpha, dil_t, pad_mode,
-                                         True, False, False, False)
+                                         True, False, False, False, planes)
         return dx
 
     @staticmethod
@@ -507,24 +546,25 @@ class Conv2dBwdDataFn(torch.autograd.Function):
     def backward(ctx, u):
         dy, x, w = ctx.saved_tensors
         mode, alpha, dil_t, pad_mode = ctx.cfg
+        planes = ctx.planes
         u = u.contiguous()
         m2, msk = (IN_MASKMUL, x) if mode == IN_LRELU else (IN_NONE, None)
         cot_dy = cot_w = None
         if ctx.needs_input_grad[0]:
-            cot_dy = _conv2d_fwd_raw(u, w, None, None, None, msk, m2, alpha, dil_t, pad_mode)
+            cot_dy = _conv2d_fwd_raw(u, w, None, None, None, msk, m2, alpha, dil_t, pad_mode, planes, _is16(dy))
         if ctx.needs_input_grad[2]:
             if _Deferred.active and not _Flags.deterministic and ctx.gw is not None and \
-                    _conv2d_bwd_deferred(dy, u, w, msk, m2, alpha, dil_t, pad_mode, False, ctx.gw, None) is not False:
-                return cot_dy, None, None, None, None, None, None, None
+                    _conv2d_bwd_deferred(dy, u, w, msk, m2, alpha, dil_t, pad_mode, False, ctx.gw, None, planes) is not False:
+                return cot_dy, None, None, None, None, None, None, None, None
             _, cot_w, _, _, _ = _conv2d_bwd_raw(dy, u, w, None, None, msk, m2, alpha, dil_t, pad_mode,
-                                                False, True, False, False)
-        return cot_dy, None, cot_w, None, None, None, None, None
+                                                False, True, False, False, planes)
+        return cot_dy, None, cot_w, None, None, None, None, None, None
 
 
-def conv2d(v, w, b=None, dil_t=1, pad_mode=PAD_SAME):
-    """z_out = conv2d(act(v), w) + b on [B,T,F,Cin]; `v` is a tensor or a Lazy."""
+def conv2d(v, w, b=None, dil_t=1, pad_mode=PAD_SAME, bf16=None):
+    """z_out = conv2d(act(v), w) + b on [B,T,F,Cin]; `v` is a tensor or a Lazy.  bf16: see Conv2dFn."""
     z, mode, scale, shift, alpha = _prep(v)
-    return Conv2dFn.apply(z, w, b, scale, shift, mode, alpha, dil_t, pad_mode)
+    return Conv2dFn.apply(z, w, b, scale, shift, mode, alpha, dil_t, pad_mode, bf16)
 
 
 # ----------------------------------------------------------------------------------------------

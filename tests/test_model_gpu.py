@@ -385,3 +385,71 @@ def test_split_hipgraph_recomputes_every_weight_derived_operand():
         assert len(opt._graphs) == 2
     finally:
         ops.deterministic(False)
+
+
+def test_bf16_storage_critic_conv_stack():
+    """BASELINE configs[2] (build extension; the reference is fp32, README.md:166): cfg.arch_critic_bf16 keeps the maps between
+    the critic's 4 -> 4 channel Conv2D layers, and their gradients, as bf16 in HBM and multiplies in bf16 on the matrix cores
+    with fp32 accumulation; master weights, weight gradients, the first layer and everything outside the stack stay fp32.
+    Oracle: fp64 with the same roundings (oracle.bf16_st: activation after the LeakyReLU, the kernel's bf16 copy, the stored
+    maps) and straight-through gradients.  Derived tolerances: a stored value is off by at most 2^-9 relative, and a
+    different summation order can move a stored map by one bf16 ulp (2^-8) where the fp64 sum lies at a rounding boundary, so
+    forward values are compared at 2^-7 of the map's scale; the oracle's backward does not round the stored gradient maps
+    (7 layers: sqrt(14) x 2^-9 = 0.7 % expected), so gradients are bounded by 3e-2 relative L2 -- and both must stay within
+    the bf16 error budget of the fp32 oracle."""
+    from percivaltts_amd import optimizertts_wgan, vocoders, modeltts_common, networks_critic, ops
+    import percivaltts_amd
+    g = dict(ctx=61, spec=65, nm=20, H=32, nctx=1, kctx=21, L=8, C=4, kt=5, kf=5, B=3, T=50)
+    cfg = percivaltts_amd.configuration()
+    cfg.arch_hiddenwidth = g['H']; cfg.arch_ctx_nbcnnlayers = g['nctx']; cfg.arch_ctx_winlen = g['kctx']
+    cfg.arch_gen_nbcnnlayers = g['L']; cfg.arch_gen_nbfilters = g['C']; cfg.arch_gen_winlen = g['kt']
+    cfg.arch_spec_freqlen = g['kf']; cfg.train_batch_size = g['B']
+    cfg.arch_critic_bf16 = True
+    voc = vocoders.VocoderPML(16000, 0.005, g['spec'], g['nm'])
+    mod = modeltts_common.DCNNF0SpecNoiseFeatures(g['ctx'], voc, cfg)
+    crit = networks_critic.Critic(voc, g['ctx'], cfg)
+    a = O.Arch(g['ctx'], g['spec'], g['nm'], g['H'], g['nctx'], g['kctx'], g['L'], g['C'], g['kt'], g['kf'])
+    gw = O.random_weights(O.generator_weight_shapes(a), seed=11)
+    cw = O.random_weights(O.critic_weight_shapes(a), seed=12)
+    mod.kerasmodel.set_weights([w.numpy() for w in gw]); crit.model.set_weights([w.numpy() for w in cw])
+    gen = torch.Generator().manual_seed(5)
+    X = torch.rand(g['B'], g['T'], g['ctx'], generator=gen, dtype=torch.float64) * 2 - 1
+    Y = torch.randn(g['B'], g['T'], a.outsize, generator=gen, dtype=torch.float64)
+    al = torch.rand(g['B'], generator=gen, dtype=torch.float64)
+    opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype='WLSWGAN', critic=crit)
+    opt.prepare()
+    from percivaltts_amd import layers as kl
+    modes = [l.bf16 for l in crit.model.layers_list if isinstance(l, kl.Conv2D)]
+    assert modes == [None] + ['out16'] * 6 + ['out32'], modes
+    Xd, Yd, ald = f32(X), f32(Y), f32(al)
+
+    # ---- forward
+    with torch.no_grad(), ops._hip.KernelTimer() as kt:
+        v = crit.model(Yd, Xd, training=False)
+    assert sum(1 for r in kt.records if r[0] == 'ptts_conv2d_mfma_fwd' and r[1][-1] == 1) == 7      # one-plane kernels
+    v16 = O.critic_forward(cw, a, Y, X, bf16_stack=True)
+    v32 = O.critic_forward(cw, a, Y, X)
+    scale = float(v16.abs().mean())
+    assert float((v.double().cpu() - v16).abs().max()) < 2.0 ** -7 * max(scale, float(v16.abs().max())), 'critic forward vs bf16 oracle'
+    rel16 = float((v.double().cpu() - v16).norm() / v16.norm()); rel32 = float((v.double().cpu() - v32).norm() / v32.norm())
+    assert rel16 < 3e-3 and rel32 < 3e-2 and rel16 < rel32, (rel16, rel32)
+
+    # ---- critic step: loss parts and gradients (first and second order through the bf16 maps)
+    for w in cw: w.requires_grad_(True)
+    total, parts = O.critic_step_loss(cw, gw, a, X, Y, al, gp_lambda=10.0, bf16_stack=True)
+    grads = torch.autograd.grad(total, cw)
+    opt.critic_opti.zero_grad()
+    with ops.deferred_weight_grads():
+        tot_d, (lv, lf, gp) = opt.critic_loss(Xd, Yd, ald, training=True)
+        tot_d.backward()
+    close(lv, parts['valid'], 5e-3, 1e-4, 'L valid (bf16)')
+    close(lf, parts['fake'], 5e-3, 1e-4, 'L fake (bf16)')
+    close(gp, parts['gp'], 2e-2, 1e-4, 'gradient penalty (bf16)')
+    num = den = 0.0
+    for p, g_ in zip(opt.critic_opti.flat.params, grads):
+        assert p.grad.dtype == torch.float32
+        num += float((p.grad.detach().cpu().double() - g_.detach()).pow(2).sum()); den += float(g_.detach().pow(2).sum())
+    assert num <= (3e-2 ** 2) * den, 'critic gradients (bf16 stack): relative L2 error {:.3e}'.format((num / den) ** 0.5)
+    # the generator step through the frozen bf16 critic runs and is finite
+    lg = opt.generator_step(Xd, Yd)
+    assert torch.isfinite(lg) and torch.isfinite(opt.gen_opti.flat.grad).all()

@@ -119,7 +119,7 @@ def test_conv2d_mfma_tables_are_the_split_of_the_toeplitz_blocks(ops):
     nb = ops._hip.lib().ptts_conv2d_mfma_table_bytes(5)
     assert nb == 5 * 3 * 64 * 8 * 2
     tf = torch.zeros(nb, dtype=torch.uint8, device='cuda'); tb = torch.zeros(nb, dtype=torch.uint8, device='cuda')
-    call('ptts_conv2d_mfma_tables', ptr(w.cuda()), ptr(tf), ptr(tb), 5, 5, 4, 4, stream())
+    call('ptts_conv2d_mfma_tables', ptr(w.cuda()), ptr(tf), ptr(tb), 5, 5, 4, 4, 3, stream())
     wn = w.numpy()
     for tab, transposed in ((tf, False), (tb, True)):
         got = tab.view(torch.bfloat16).float().cpu().numpy().reshape(5, 3, 64, 8)
@@ -197,6 +197,43 @@ def test_conv2d_mfma_against_the_oracle_and_the_fp32_stencil(ops, case):
     for nm, got_m, got_s, want, (rt, at) in zip(('y', 'dx', 'dw', 'db', 'y (affine)', 'y (maskmul)', 'dw (maskmul)'), res_m, res_s, wants, tols):
         close(got_m, want, rtol=rt, atol=at, what=nm + ' [matrix cores]')
         close(got_s, want, rtol=rt, atol=at, what=nm + ' [fp32 stencil]')
+
+
+@pytest.mark.parametrize('in16,out16', [(False, True), (True, True), (True, False)])
+def test_conv2d_bf16_storage_layer(ops, in16, out16):
+    """One 4 -> 4 channel 5x5 layer of the bf16-storage path (ops.conv2d(..., bf16=...), csrc/conv2d_mfma.hip with one
+    plane): input map stored as fp32 or bf16, result stored as bf16 or fp32.  Forward against the fp64 oracle with the
+    same roundings -- activation to bf16 after the LeakyReLU, the kernel's bf16 copy, exact products, the result rounded
+    once when stored as bf16: at most one bf16 ulp (2^-8) apart where the sums differ in order.  Backward: dx has the
+    input's storage type, dw / db are fp32; against the oracle's fp64 backward of the same rounded forward, at the bf16
+    budget (2^-8 per stored value)."""
+    B, T, F = 2, 40, 65
+    g = gen(71)
+    x = torch.randn(B, T, F, 4, generator=g, dtype=torch.float64)
+    if in16:
+        x = x.to(torch.bfloat16).double()          # a map that already lies in HBM as bf16
+    w = torch.randn(5, 5, 4, 4, generator=g, dtype=torch.float64) * 0.2
+    b = torch.randn(4, generator=g, dtype=torch.float64)
+    dy = torch.randn(B, T, F, 4, generator=g, dtype=torch.float64)
+    xr, wr, br = ref(x, True), ref(w, True), ref(b, True)
+    yr = O.conv2d_nhwc(O.bf16_st(O.lrelu(xr)), O.bf16_st(wr), br)
+    if out16:
+        yr = O.bf16_st(yr)
+        dy = dy.to(torch.bfloat16).double()
+    yr.backward(dy)
+    xd = x.to(torch.bfloat16 if in16 else torch.float32).cuda().requires_grad_(True)
+    wd, bd = dev(w, True), dev(b, True)
+    yd = ops.conv2d(ops.Lazy(xd, lrelu=True), wd, bd, bf16='out16' if out16 else 'out32')
+    assert yd.dtype == (torch.bfloat16 if out16 else torch.float32)
+    ulp = 2.0 ** -8
+    err = (yd.double().cpu() - yr.detach()).abs()
+    assert float((err / (yr.detach().abs() + 1e-2)).max()) < (1.1 * ulp if out16 else 1e-4), float((err / (yr.detach().abs() + 1e-2)).max())
+    yd.backward(dy.to(yd.dtype).cuda())
+    assert xd.grad.dtype == xd.dtype and wd.grad.dtype == torch.float32 and bd.grad.dtype == torch.float32
+    gx = float((xd.grad.double().cpu() - xr.grad).norm() / xr.grad.norm())
+    gwt = float((wd.grad.double().cpu() - wr.grad).norm() / wr.grad.norm())
+    assert gx < 2.0 ** -8 and gwt < 2.0 ** -8, (gx, gwt)       # dx: rounded dy planes and (bf16 x) a rounded store
+    close(bd.grad, br.grad, rtol=2e-4, atol=1e-3, what='db')     # db sums the raw dy values: fp32 accuracy
 
 
 @pytest.mark.parametrize('case', [(2, 12, 9, 2, 3, 3), (2, 40, 65, 4, 5, 5)])

@@ -19,7 +19,7 @@ b = torch.randn(4, generator=g).cuda()
 lib = _hip.lib()
 nb = lib.ptts_conv2d_mfma_table_bytes(5)
 tf = torch.empty(nb, dtype=torch.uint8, device='cuda'); tb = torch.empty(nb, dtype=torch.uint8, device='cuda')
-call('ptts_conv2d_mfma_tables', ptr(w), ptr(tf), ptr(tb), 5, 5, 4, 4, stream())
+call('ptts_conv2d_mfma_tables', ptr(w), ptr(tf), ptr(tb), 5, 5, 4, 4, 3, stream())
 pad = 2 * dil
 
 if os.environ.get('C2M_ONLY'):
@@ -29,10 +29,10 @@ if os.environ.get('C2M_ONLY'):
     y = torch.empty_like(x)
     nblocks = ctypes.c_int(0); npart = ctypes.c_int(0)
     for _ in range(int(os.environ.get('C2M_REPS', '10'))):
-        call('ptts_conv2d_mfma_fwd', ptr(x), ptr(tf), ptr(b), None, None, None, None, ptr(y), B, T, F, 5, dil, pad, ops.IN_LRELU, 0.3, stream())
-        call('ptts_conv2d_mfma_fwd', ptr(dy), ptr(tb), None, None, None, None, ptr(x), ptr(y), B, T, F, 5, dil, 4 * dil - pad, ops.IN_NONE, 0.3, stream())
+        call('ptts_conv2d_mfma_fwd', ptr(x), ptr(tf), ptr(b), None, None, None, None, ptr(y), B, T, F, 5, dil, pad, ops.IN_LRELU, 0.3, 3, 0, 0, stream())
+        call('ptts_conv2d_mfma_fwd', ptr(dy), ptr(tb), None, None, None, None, ptr(x), ptr(y), B, T, F, 5, dil, 4 * dil - pad, ops.IN_NONE, 0.3, 3, 0, 0, stream())
         call('ptts_conv2d_mfma_wgrad_partials', ptr(dy), ptr(x), None, ptr(ws), ws.numel(), ctypes.byref(nblocks), ctypes.byref(npart),
-             B, T, F, 5, dil, pad, ops.IN_LRELU, 0.3, stream())
+             B, T, F, 5, dil, pad, ops.IN_LRELU, 0.3, 3, 0, 0, stream())
     torch.cuda.synchronize()
     sys.exit(0)
 
@@ -42,7 +42,7 @@ def rel(a, ref):
 def fwd_new(xx, table, bias, mask_src, out_mask, mode, pad_t):
     y = torch.empty_like(xx)
     call('ptts_conv2d_mfma_fwd', ptr(xx), ptr(table), ptr(bias), None, None, ptr(mask_src), ptr(out_mask), ptr(y),
-         B, T, F, 5, dil, pad_t, mode, 0.3, stream())
+         B, T, F, 5, dil, pad_t, mode, 0.3, 3, 0, 0, stream())
     return y
 
 def timeit(fn, n=30):
@@ -78,7 +78,7 @@ def wgrad_new(mode, mask_src):
     ws = torch.empty(nws, dtype=torch.uint8, device='cuda')
     nblocks = ctypes.c_int(0); npart = ctypes.c_int(0)
     call('ptts_conv2d_mfma_wgrad_partials', ptr(dy), ptr(x), ptr(mask_src), ptr(ws), ws.numel(), ctypes.byref(nblocks), ctypes.byref(npart),
-         B, T, F, 5, dil, pad, mode, 0.3, stream())
+         B, T, F, 5, dil, pad, mode, 0.3, 3, 0, 0, stream())
     return ws, nblocks.value, npart.value
 ws, nblocks, npart = wgrad_new(ops.IN_LRELU, None)
 parts = ws[4096:].view(torch.float32)[:nblocks * npart].view(nblocks, npart)
@@ -111,7 +111,7 @@ print('  weight grad old {:7.1f}   new {:7.1f}'.format(
     timeit(lambda: wgrad_new(ops.IN_LRELU, None))))
 print('  fused bwd   old {:7.1f}'.format(
     timeit(lambda: ops._conv2d_bwd_raw(dy, x, w, None, None, None, ops.IN_LRELU, 0.3, dil, ops.PAD_SAME, True, True, True, False))))
-print('  tables          {:7.1f}'.format(timeit(lambda: call('ptts_conv2d_mfma_tables', ptr(w), ptr(tf), ptr(tb), 5, 5, 4, 4, stream()))))
+print('  tables          {:7.1f}'.format(timeit(lambda: call('ptts_conv2d_mfma_tables', ptr(w), ptr(tf), ptr(tb), 5, 5, 4, 4, 3, stream()))))
 
 # ---- where the time goes: phase switches and per-workgroup stamps (s_memtime = shader clock / ... 100 MHz constant clock)
 nblk = B * ((T + 15) // 16)
