@@ -50,6 +50,8 @@ def parse():
     ap.add_argument('--fp32-mfma', action='store_true', help='context Conv1D forward and weight gradient on the fp32 MFMA pipe instead of the bf16x6 split products')
     ap.add_argument('--no-reference-shape', action='store_true', help="skip the leg at the reference's own training geometry (B=10, T=400, 425 -> 163)")
     ap.add_argument('--no-unreduced', action='store_true', help='skip the timed loop with every exact work reduction switched off')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help="bf16: BASELINE configs[2] -- the maps between the critic's 4->4 Conv2D layers and their gradients stored as bf16, bf16 products with fp32 accumulation; master weights, weight gradients and everything outside the stack fp32")
+    ap.add_argument('--no-bf16-leg', action='store_true', help='skip the configs[2] side leg of the default (fp32) run')
     ap.add_argument('--sync-bn', action='store_true', help='data parallelism: BatchNorm statistics all-reduced over the ranks (default: per rank)')
     ap.add_argument('--no-gated-leg', action='store_true', help='skip the BASELINE configs[4] leg (gated dilated-causal generator, T=2000)')
     ap.add_argument('--gated-batch', type=int, default=64)
@@ -203,12 +205,15 @@ def roofline_leg(opt, X, Y, args):
     # (summed per repetition: the call list of the first one may hold a refresh of cached operands the others do not)
     t_conv2d = sum(sum(d for (nm, _, d) in r if nm.startswith('ptts_conv2d')) for r in crit_recs) / reps * 1e-3
     n_conv2d = sum(1 for (nm, _, _) in crit_recs[-1] if nm.startswith('ptts_conv2d'))
-    alg_bytes = (149.0 * C + 3.0) * B * T * F * 4.0 if L == 8 else None
+    bf16_stack = bool(getattr(opt.cfg, 'arch_critic_bf16', False))
+    # (149 C + 3) B T F s bytes per critic step, s = 4 (configs[1], fp32) or 2 (configs[2], every map bf16)
+    alg_bytes = (149.0 * C + 3.0) * B * T * F * (2.0 if bf16_stack else 4.0) if L == 8 else None
     if alg_bytes and t_conv2d > 0:
         out['roofline_conv2d'] = {'bound': 'hbm', 'kernel': 'critic 2D-conv stack: {} conv2d fwd/bwd launches per critic step'.format(n_conv2d),
                                   'achieved': alg_bytes / t_conv2d / 1e9, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
                                   'frac': alg_bytes / t_conv2d / 1e9 / PEAK_HBM_GBPS, 'traffic': None,
-                                  'algorithmic_bytes_per_critic_step': alg_bytes, 'time_ms': t_conv2d * 1e3}
+                                  'algorithmic_bytes_per_critic_step': alg_bytes, 'time_ms': t_conv2d * 1e3,
+                                  'maps': ('bf16 between the 4->4 layers (6 of 8 maps and their gradients), fp32 at both ends of the stack' if bf16_stack else 'fp32')}
     out['critic_step_kernel_ms'] = {k: round(v, 4) for k, v in sorted(classes.items(), key=lambda kv: -kv[1])}
     # HBM(+Infinity-Cache) bytes per launch from the separate rocprofv3 PMC passes of the same kernels
     # (tools/profile_round.sh -> tools/summarize_profiles.py -> profiles/<round>_traffic.json; FETCH_SIZE x2 + WRITE_SIZE)
@@ -222,19 +227,22 @@ def roofline_leg(opt, X, Y, args):
             if 'roofline' in out and key:
                 out['roofline']['traffic'] = tr[key]['hbm_bytes_per_launch']
                 out['roofline']['traffic_source'] = 'profiles/' + cands[-1]
-            if 'roofline_conv2d' in out and 'conv2d_fwd_kernel<4, 4, 5, 5, 1, false>' in tr:
-                out['roofline_conv2d']['traffic_fwd_4to4_per_launch'] = tr['conv2d_fwd_kernel<4, 4, 5, 5, 1, false>']['hbm_bytes_per_launch']
+            ck = next((k for k in tr if k.startswith('c2m::fwd_kernel<1, 1, false')), None) or next((k for k in tr if k.startswith('conv2d_fwd_kernel<4, 4')), None)
+            if 'roofline_conv2d' in out and ck and not bf16_stack:
+                out['roofline_conv2d']['traffic_fwd_4to4_per_launch'] = tr[ck]['hbm_bytes_per_launch']
+                out['roofline_conv2d']['traffic_kernel'] = ck
     except (OSError, ValueError, KeyError):
         pass
     return out
 
 
-def build_optimizer(args, ctx, spec, nm, batch, errtype, gated=False):
+def build_optimizer(args, ctx, spec, nm, batch, errtype, gated=False, bf16=None):
     """Generator + critic + optimiser at one geometry (random-init weights of the named architecture)."""
     import io, contextlib
     from percivaltts_amd import vocoders, modeltts_common, networks_critic, optimizertts_wgan
     cfg = make_cfg(args)
     cfg.train_batch_size = batch
+    cfg.arch_critic_bf16 = (args.dtype == 'bf16') if bf16 is None else bool(bf16)
     if gated:       # BASELINE configs[4]: pGCNN2D spectral branch, time dilations 1,2,4,8,1,2,4,8, causal padding
         cfg.arch_gen_gated = True; cfg.arch_gen_dilations = [1, 2, 4, 8]; cfg.arch_gen_causal = True
     cfg.train_wgan_hipgraph = bool(args.graph) and int(os.environ.get('WORLD_SIZE', '1')) <= 1
@@ -387,6 +395,21 @@ def main():
                                     'value': nr * rB * rT * world / dtr, 'unit': 'frames/s', 'ms_per_step': dtr / nr * 1e3,
                                     'steps': nr, 'cycle_ms': rcyc}
         del ropt, rb
+    if args.dtype == 'f32' and not args.no_bf16_leg:
+        # BASELINE configs[2]: same shapes, the critic's conv stack with bf16 maps (gradient penalty on, lambda = 10)
+        _, bvoc, _, _, bopt = build_optimizer(args, args.ctx, spec, nm, B, args.errtype, bf16=True)
+        nb = max(6, min(args.steps, 60))
+        dtb, bcyc = timed_loop(bopt, batches, nb, 6, dev)
+        leg = {'workload': 'BASELINE configs[2]: same shapes, bf16 maps between the 4->4 layers of the critic\'s Conv2D stack (and their gradients), '
+                           'bf16 products with fp32 accumulation, fp32 master weights and weight gradients, gradient penalty lambda=10',
+               'value': nb * B * T * world / dtb, 'unit': 'frames/s', 'ms_per_step': dtb / nb * 1e3, 'steps': nb, 'cycle_ms': bcyc, 'dtype': 'bf16'}
+        if not args.no_roofline:
+            rl = roofline_leg(bopt, batches[0][0], batches[0][1], args)
+            if 'roofline_conv2d' in rl:
+                leg['roofline_conv2d'] = rl['roofline_conv2d']
+        extra['config2_bf16'] = leg
+        del bopt
+        torch.cuda.empty_cache()
     if not args.no_gated_leg:
         # BASELINE configs[4]: generator spectral branch from gated convolutions (networktts.py:128-134) with time dilations
         # 1,2,4,8,1,2,4,8 and causal padding, long context T = 2000; fp32, per GPU
@@ -410,10 +433,11 @@ def main():
         res = {
             'metric': 'acoustic frames/sec per WGAN-GP critic+gen step', 'value': frames / dt, 'unit': 'frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: synthetic [{b},{t},{c}]->[{b},{t},{o}] (f0 1 + spec 65 + noise 20), DCNN generator + '
-                                   '2D-conv critic, fp32, {e}, lambda=10, schedule 5 critic steps : 1 generator step; '
-                                   'step = one train_on_batch'.format(b=B, t=T, c=args.ctx, o=voc.featuressize(), e=args.errtype),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[{n}]: synthetic [{b},{t},{c}]->[{b},{t},{o}] (f0 1 + spec 65 + noise 20), DCNN generator + '
+                                   '2D-conv critic, {d}, {e}, lambda=10, schedule 5 critic steps : 1 generator step; '
+                                   'step = one train_on_batch'.format(n=2 if args.dtype == 'bf16' else 1, b=B, t=T, c=args.ctx, o=voc.featuressize(), e=args.errtype,
+                                                                      d='bf16 maps in the critic conv stack (fp32 elsewhere)' if args.dtype == 'bf16' else 'fp32'),
                        'per_gpu_batch': B, 'global_batch': B * world, 'frames_per_step_per_gpu': B * T,
                        'parallelism': 'dp{}'.format(world), 'hipgraph': bool(cfg.train_wgan_hipgraph),
                        'hip_streams': 3 if par_streams else 1,

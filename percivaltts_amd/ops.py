@@ -788,15 +788,19 @@ class _C1Split(object):
         return planes, Crows
 
     @classmethod
-    def frames_t(cls, src, ap, KW):
-        """Frame-major planes of the padded frames ap [B][T+KW-1][C], kept for `src` (the tensor the layer was called
-        with): the weight gradients of generator and critic read the same context input."""
-        B, Tp, C = ap.shape
-        Pp = cls.plane_len(B, Tp - (KW - 1), KW)
+    def frames_t(cls, src, saved, padded, B, T, C, KW):
+        """Frame-major planes of the zero-padded frames of the layer input (`saved`: the padded buffer [B][T+KW-1][C], or the
+        input itself, padded on the fly by the split pass), kept for `src` (the tensor the layer was called with): the
+        weight gradients of generator and critic read the same context input."""
+        Tp = T + KW - 1
+        Pp = cls.plane_len(B, T, KW)
         key = None if src is None else (src._version, tuple(src.shape), KW, torch.cuda.current_stream().cuda_stream)
         if src is not None and cls.xt_src is src and cls.xt_key == key:
             return cls.xt_planes
-        planes, Crows = cls.transposed(ap, B, Tp, C, 0, Tp, Pp)
+        if padded:
+            planes, Crows = cls.transposed(saved, B, Tp, C, 0, Tp, Pp)
+        else:
+            planes, Crows = cls.transposed(saved, B, T, C, (KW - 1) // 2, Tp, Pp)
         out = (planes, Crows, Pp)
         if src is not None:
             cls.xt_src, cls.xt_key, cls.xt_planes = src, key, out
@@ -857,7 +861,9 @@ def conv1d_split(on):
 
 class Conv1dFn(torch.autograd.Function):
     """y[b,t,:] = b + sum_k a[b,t+k-pl,:].w[k];  `a` (already activated) is given, 'same' zero padding.
-    pre = (padded input, product) computed earlier for exactly these operands (see _C1Cache)."""
+    pre = (saved input, padded?, product) computed earlier for exactly these operands (see _C1Cache).
+    The split (bf16x6) kernels read their own planes of `a`: no zero-padded copy of the input is made for them (it was a
+    61 MB fill + copy per call at BASELINE size); the fp32 GEMM paths still take the padded frame buffer."""
     @staticmethod
     def forward(ctx, a, w, b, pre=None):
         f32c(a, 'conv1d.a'); f32c(w, 'conv1d.w')
@@ -866,7 +872,7 @@ class Conv1dFn(torch.autograd.Function):
         assert Ci2 == Cin
         pl = (KW - 1) // 2
         if pre is not None:
-            ap, y = pre
+            saved, padded, y = pre
         else:
             y = torch.empty((B, T, N), dtype=torch.float32, device=a.device)
             if _C1Split.enabled and not _Flags.deterministic and _C1Split.eligible(a, w):
@@ -874,15 +880,14 @@ class Conv1dFn(torch.autograd.Function):
                 wp = _C1Split.kernel(w)
                 call('ptts_conv1d_bf16x6', ptr(xp[0]), ptr(xp[1]), ptr(xp[2]), ptr(wp[0]), ptr(wp[1]), ptr(wp[2]), ptr(b), ptr(y),
                      B, T, KW, Cp, N, stream(), tag=(B, T, KW, Cp, N))
-                # the fp32 padded frames are the weight gradient's operand: only made when a backward can follow
-                need_ap = _C1Cache.capture or ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-                ap = _pad_time(a, pl, KW - 1 - pl) if need_ap else a.new_empty(0)
+                saved, padded = a, False
             else:
-                ap = _pad_time(a, pl, KW - 1 - pl)
-                gemm_raw(ap, w, y, B * T, N, KW * Cin, lda=Cin, rows_per_seg=T, seg_stride=(T + KW - 1) * Cin, bias=b)
+                saved, padded = _pad_time(a, pl, KW - 1 - pl), True
+                gemm_raw(saved, w, y, B * T, N, KW * Cin, lda=Cin, rows_per_seg=T, seg_stride=(T + KW - 1) * Cin, bias=b)
             if _C1Cache.capture:
-                _C1Cache.ap = ap
-        ctx.save_for_backward(ap, w)
+                _C1Cache.ap = (saved, padded)
+        ctx.save_for_backward(saved, w)
+        ctx.padded = padded
         ctx.x_src = a
         ctx.has_b = b is not None
         ctx.dims = (B, T, Cin, KW, N, pl)
@@ -891,23 +896,27 @@ class Conv1dFn(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
-        ap, w = ctx.saved_tensors
+        saved, w = ctx.saved_tensors
         B, T, Cin, KW, N, pl = ctx.dims
         dy = dy.contiguous()
         da = dw = db = None
         need_b = ctx.has_b and ctx.needs_input_grad[2] and not _Flags.skip_param_grads
-        if ctx.needs_input_grad[1] and not _Flags.skip_param_grads and _C1Split.enabled and not _Flags.deterministic and dy.is_cuda \
-                and _C1Split.eligible_wgrad(KW, N) and ap.numel() > 0:
+        want_w = ctx.needs_input_grad[1] and not _Flags.skip_param_grads
+
+        def padded_frames():
+            return saved if ctx.padded else _pad_time(saved, pl, KW - 1 - pl)
+
+        if want_w and _C1Split.enabled and not _Flags.deterministic and dy.is_cuda and _C1Split.eligible_wgrad(KW, N):
             # the weight gradient as a bf16x6 split product over frame-major planes (csrc/split.hip)
-            xt, Crows, Pp = _C1Split.frames_t(ctx.x_src, ap, KW)
+            xt, Crows, Pp = _C1Split.frames_t(ctx.x_src, saved, ctx.padded, B, T, Cin, KW)
             yt, _ = _C1Split.transposed(dy, B, T, N, 0, T + KW - 1, Pp)
             dw = torch.empty_like(w)
             call('ptts_conv1d_wgrad_bf16x6', ptr(xt[0]), ptr(xt[1]), ptr(xt[2]), ptr(yt[0]), ptr(yt[1]), ptr(yt[2]), ptr(dw),
                  B, T, KW, Cin, N, Crows, Pp, stream(), tag=(B, T, KW, Cin, N))
-        elif ctx.needs_input_grad[1] and not _Flags.skip_param_grads and _C1WgradT.enabled and not _Flags.deterministic and dy.is_cuda \
-                and _C1Split.eligible_wgrad(KW, N) and ap.numel() > 0 and B * T >= 2048:
+        elif want_w and _C1WgradT.enabled and not _Flags.deterministic and dy.is_cuda \
+                and _C1Split.eligible_wgrad(KW, N) and B * T >= 2048:
             # exact fp32 over frame-major operands (csrc/conv1d_wgrad.hip); the bias gradient comes with it
-            xt, Crows, Pp = _C1WgradT.frames_t(ctx.x_src, ap, KW)
+            xt, Crows, Pp = _C1WgradT.frames_t(ctx.x_src, padded_frames(), KW)
             yt = torch.empty((N, Pp), dtype=torch.float32, device=dy.device)
             call('ptts_transpose_frames', ptr(dy), ptr(yt), B, T, N, 0, T + KW - 1, N, Pp, stream(), tag=(B, T, N))
             dw = torch.empty_like(w)
@@ -915,11 +924,11 @@ class Conv1dFn(torch.autograd.Function):
                 db = torch.empty(N, dtype=torch.float32, device=dy.device)
             call('ptts_conv1d_wgrad_t', ptr(xt), ptr(yt), ptr(dw), ptr(db), B, T, KW, Cin, N, Crows, Pp, stream(),
                  tag=(B, T, KW, Cin, N))
-        elif ctx.needs_input_grad[1] and not _Flags.skip_param_grads:
+        elif want_w:
             dw = torch.empty_like(w)
             if need_b and N > 4:          # bias gradient taken from the B tiles of the weight-gradient product
                 db = torch.empty(N, dtype=torch.float32, device=dy.device)
-            gemm_raw(ap, dy, dw, KW * Cin, N, B * T, transA=1, lda=Cin, rows_per_seg=T,
+            gemm_raw(padded_frames(), dy, dw, KW * Cin, N, B * T, transA=1, lda=Cin, rows_per_seg=T,
                      seg_stride=(T + KW - 1) * Cin, colsum_b=db)
         if need_b and db is None:
             db = _colsum_f32(dy.view(B * T, N))
@@ -948,7 +957,7 @@ def conv1d(v, w, b=None):
             c.key, c.y = key, y
             return y
         if c.key == key and c.y is not None and c.ap is not None:
-            return Conv1dFn.apply(a, w, b, (c.ap, c.y))
+            return Conv1dFn.apply(a, w, b, (c.ap[0], c.ap[1], c.y))
     return Conv1dFn.apply(a, w, b)
 
 

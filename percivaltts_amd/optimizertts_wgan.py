@@ -76,6 +76,28 @@ def freq2fwspecidx(freq, fs, nbbnds):
     return int(above[0]) if len(above) > 0 else int(nbbnds - 1)
 
 
+class _DeviceCosts(list):
+    """costs_tra_critic_batches of the reference (a list of floats, :219) whose new entries stay on the device: a critic
+    step then costs no host synchronisation; the floats are fetched -- all at once -- when the list is read."""
+    def __init__(self):
+        list.__init__(self)
+        self._pending = []
+
+    def append_device(self, t):
+        self._pending.append(t.detach().reshape(()))
+
+    def _sync(self):
+        if self._pending:
+            vals = torch.stack(self._pending).cpu().tolist()
+            self._pending = []
+            list.extend(self, [float(v) for v in vals])
+
+    def __len__(self): self._sync(); return list.__len__(self)
+    def __iter__(self): self._sync(); return list.__iter__(self)
+    def __getitem__(self, i): self._sync(); return list.__getitem__(self, i)
+    def __repr__(self): self._sync(); return list.__repr__(self)
+
+
 class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
 
     costs_tra_critic_batches = []
@@ -84,7 +106,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
     def __init__(self, cfgtomerge, model, errtype='WGAN', critic=None, **kwargs):
         optimizertts.OptimizerTTS.__init__(self, cfgtomerge, model, errtype, **kwargs)
         self.critic = critic
-        self.costs_tra_critic_batches = []
+        self.costs_tra_critic_batches = _DeviceCosts()
         self.generator_updates = 0
 
     def default_options(self, cfg):
@@ -416,7 +438,8 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         X_trab, Y_trab = self._local_shard(X_trab, Y_trab)
         X, Y = self._to_dev(X_trab), self._to_dev(Y_trab)
         lc, lg = self.device_step(batchid, X, Y)
-        self.costs_tra_critic_batches.append(float(lc.item()))
+        # the critic's loss stays on the device (no host synchronisation on the 4 of 5 batches that do not train the generator)
+        self.costs_tra_critic_batches.append_device(lc)
         return None if lg is None else float(lg.item())
 
     def update_validation_cost(self, costs, X_vals, Y_vals):
@@ -432,14 +455,15 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             return float(total.item())
 
         costs['model_validation'].append(data.cost_model_mfn(gen_cost, [X_vals, Y_vals]))
-        costs['critic_training'].append(np.mean(self.costs_tra_critic_batches))
+        critic_batches = [c for c in self.costs_tra_critic_batches]      # (fetches the device-side entries)
+        costs['critic_training'].append(np.mean(critic_batches))
         costs['critic_validation'].append(data.cost_model_mfn(critic_cost, [Y_vals, X_vals]))
         costs['critic_validation_ltm'].append(np.mean(costs['critic_validation'][-self.cfg.train_wgan_validation_ltm_winlen:]))
         cost_val = costs['critic_validation_ltm'][-1]
 
-        if np.mean(self.costs_tra_critic_batches) <= 0.0:
+        if np.mean(critic_batches) <= 0.0:
             print('Average critic loss is negative: Training is likely to take ages to converge or not converge at all. ')
-        self.costs_tra_critic_batches = []
+        self.costs_tra_critic_batches = _DeviceCosts()
         return cost_val
 
     def saveOptimizer(self, optimizer, fname):

@@ -156,7 +156,7 @@ def test_bench_two_ranks_prints_one_line():
     env = dict(os.environ, PTTS_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
-           '--batch', '4', '--frames', '40', '--no-cpu-baseline', '--no-gated-leg', '--no-reference-shape']
+           '--batch', '4', '--frames', '40', '--no-cpu-baseline', '--no-gated-leg', '--no-reference-shape', '--no-bf16-leg']
     out = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     lines = [l for l in out.stdout.decode().splitlines() if l.startswith('{')]

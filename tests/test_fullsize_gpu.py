@@ -363,6 +363,56 @@ def test_deterministic_mode_is_bit_reproducible_at_full_size(setup):
     assert rel_l2(gg_def, gg1) < 5e-4, rel_l2(gg_def, gg1)
 
 
+def test_bf16_storage_critic_at_full_size():
+    """BASELINE configs[2] at its real size: the critic with bf16 maps in its Conv2D stack (cfg.arch_critic_bf16) against the
+    same critic in fp32 on the same weights and batch.  Size-independent properties: the losses agree within the bf16 budget
+    (stored values off by <= 2^-9 each, 7 bf16 layers: well inside 2e-2), the gradient of the whole critic agrees to a few
+    per cent in relative L2, sample independence holds (a sub-batch gives the rows of the batch: the tiling does not couple
+    samples), and the weight gradients are fp32."""
+    import bench
+    from percivaltts_amd import vocoders, modeltts_common, networks_critic, optimizertts_wgan, backend_hip, ops
+
+    class A: batch = B; frames = T; ctx = CTX
+    dev = backend_hip.device()
+    voc = vocoders.VocoderPML(16000, 0.005, SPEC, NM)
+    res = {}
+    weights = None
+    for name, bf in (('f32', False), ('bf16', True)):
+        cfg = bench.make_cfg(A)
+        cfg.arch_critic_bf16 = bf
+        with contextlib.redirect_stdout(io.StringIO()):
+            mod = modeltts_common.DCNNF0SpecNoiseFeatures(CTX, voc, cfg)
+            crit = networks_critic.Critic(voc, CTX, cfg)
+            if weights is None:
+                weights = (mod.kerasmodel.get_weights(), crit.model.get_weights())
+            else:
+                mod.kerasmodel.set_weights(weights[0]); crit.model.set_weights(weights[1])
+            opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype='WLSWGAN', critic=crit)
+            opt.prepare()
+        X, Y = bench.synthetic(B, T, CTX, voc.featuressize(), SPEC, 321, dev)
+        g = torch.Generator().manual_seed(3)
+        alpha = torch.rand(B, generator=g).cuda()
+        with torch.no_grad():
+            fake = opt._fake_sample(X, True).detach()
+        opt.critic_opti.zero_grad()
+        with ops.deferred_weight_grads():
+            total, parts = opt.critic_loss(X, Y, alpha, training=True, fake=fake)
+            total.backward()
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            full = crit.model(Y, X, training=False)
+            sub = crit.model(Y[8:16].contiguous(), X[8:16].contiguous(), training=False)
+        res[name] = (total.detach().clone(), [p.detach().clone() for p in parts], opt.critic_opti.flat.grad.detach().clone(), full, sub)
+        assert opt.critic_opti.flat.grad.dtype == torch.float32
+        del opt, mod, crit
+    (t32, p32, g32, f32_, s32), (t16, p16, g16, f16, s16) = res['f32'], res['bf16']
+    for a_, b_, nm in zip(p16, p32, ('valid', 'fake', 'gp')):
+        close(a_, b_, 2e-2, 2e-3, 'bf16 vs fp32 critic: ' + nm)
+    assert rel_l2(g16, g32) < 6e-2, rel_l2(g16, g32)
+    assert rel_l2(f16, f32_) < 2e-2, rel_l2(f16, f32_)
+    assert rel_l2(f16[8:16], s16) < 5e-6          # same roundings whatever the batch around a sample
+
+
 def test_gated_dilated_causal_generator_at_T2000():
     """BASELINE configs[4] at its real length: the generator's spectral branch from gated convolutions (pGCNN2D,
     networktts.py:128-134) with time dilations 1,2,4,8,1,2,4,8 and causal padding (build extensions), T = 2000.

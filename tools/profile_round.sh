@@ -2,18 +2,21 @@
 # Run ON THE GPU BOX (through gpurun): rocprofv3 kernel trace of the default bench command plus separate PMC passes
 # (HBM traffic of the dominant kernels) -> gpurun_out/prof_<tag>/ ; summarise with tools/summarize_profiles.py.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err
 echo "trace done" > $OUT/progress.txt
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python tools/gemm_probe.py both 3 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python tools/gemm_probe.py both 3 > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_split -- python tools/split_probe.py 3 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_split -- python tools/split_probe.py 3 > /dev/null 2>&1
-echo "gemm pmc done" >> $OUT/progress.txt
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_conv -- python tools/conv2d_probe.py 3 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_conv -- python tools/conv2d_probe.py 3 > /dev/null 2>&1
+# HBM traffic: FETCH_SIZE and WRITE_SIZE in passes of their own (TCC slots), kernel trace only beside them
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_split -- python3 tools/split_probe.py 3 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_split -- python3 tools/split_probe.py 3 > /dev/null 2>&1
+echo "conv1d pmc done" >> $OUT/progress.txt
+export C2M_ONLY=1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_conv -- python3 tools/conv2d_mfma_probe.py > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_conv -- python3 tools/conv2d_mfma_probe.py > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d $OUT/pmc_sq_conv -- python3 tools/conv2d_mfma_probe.py > /dev/null 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM SQ_INSTS_SALU --output-format csv -d $OUT/pmc_lds_conv -- python3 tools/conv2d_mfma_probe.py > /dev/null 2>&1
+unset C2M_ONLY
 echo "conv pmc done" >> $OUT/progress.txt
 ls -R $OUT | head -40

@@ -8,7 +8,7 @@ import json
 import os
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 src = os.path.join('gpurun_out', 'prof_' + tag)
 os.makedirs('profiles', exist_ok=True)
 
@@ -45,14 +45,30 @@ def pmc(dirname, counter):
 
 traffic = {}
 for fdir, wdir in (('pmc_fetch', 'pmc_write'), ('pmc_fetch_conv', 'pmc_write_conv'), ('pmc_fetch_split', 'pmc_write_split')):
+    if not glob.glob(src + '/' + fdir + '/runc/*_counter_collection.csv'):
+        continue
     fe, wr = pmc(fdir, 'FETCH_SIZE'), pmc(wdir, 'WRITE_SIZE')
     for k in fe:
-        if not ('gemm' in k or 'conv2d' in k or 'split3' in k or 'wgrad' in k) or k in traffic:
+        if not ('gemm' in k or 'conv2d' in k or 'split3' in k or 'wgrad' in k or 'c2m' in k) or k in traffic:
             continue
         f_kib = sum(fe[k]) / len(fe[k])
         w_kib = sum(wr.get(k, [0.0])) / max(1, len(wr.get(k, [0.0])))
         traffic[k] = {'fetch_bytes_raw': f_kib * 1024, 'fetch_bytes_corrected_x2': 2 * f_kib * 1024, 'write_bytes': w_kib * 1024,
                       'hbm_bytes_per_launch': (2 * f_kib + w_kib) * 1024, 'launches_averaged': len(fe[k])}
 json.dump(traffic, open('profiles/%s_traffic.json' % tag, 'w'), indent=1, sort_keys=True)
+# SQ / LDS counters of the conv2d_mfma kernels (averages per launch)
+sq = {}
+for d in ('pmc_sq_conv', 'pmc_lds_conv'):
+    for f in glob.glob(src + '/' + d + '/runc/*_counter_collection.csv'):
+        acc = {}
+        for r in csv.DictReader(open(f)):
+            k = short(r['Kernel_Name'])
+            if 'c2m' not in k:
+                continue
+            acc.setdefault(k, {}).setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
+        for k, dct in acc.items():
+            sq.setdefault(k, {}).update({c: sum(v) / len(v) for c, v in dct.items()})
+if sq:
+    json.dump(sq, open('profiles/%s_conv2d_mfma_counters.json' % tag, 'w'), indent=1, sort_keys=True)
 print(open('profiles/%s_kernel_stats.txt' % tag).read()[:3500])
 print(json.dumps(traffic, indent=1)[:3000])
