@@ -10,7 +10,8 @@ import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 src = os.path.join('gpurun_out', 'prof_' + tag)
-os.makedirs('profiles', exist_ok=True)
+outdir = sys.argv[2] if len(sys.argv) > 2 else 'profiles'
+os.makedirs(outdir, exist_ok=True)
 
 
 def short(name):
@@ -26,9 +27,9 @@ lines = ['# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baselin
 for r in rows[:40]:
     lines.append('%8s %12.1f %11.1f %11.1f %11.1f %6.2f  %s' % (r['Calls'], float(r['TotalDurationNs']) / 1e3, float(r['AverageNs']) / 1e3,
                  float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3, float(r['Percentage']), short(r['Name'])))
-open('profiles/%s_kernel_stats.txt' % tag, 'w').write('\n'.join(lines) + '\n')
+open(outdir + '/%s_kernel_stats.txt' % tag, 'w').write('\n'.join(lines) + '\n')
 bench = open(src + '/bench.json').read().strip()
-open('profiles/%s_bench_under_rocprof.json' % tag, 'w').write(bench + '\n')
+open(outdir + '/%s_bench_under_rocprof.json' % tag, 'w').write(bench + '\n')
 
 
 def pmc(dirname, counter):
@@ -55,7 +56,7 @@ for fdir, wdir in (('pmc_fetch', 'pmc_write'), ('pmc_fetch_conv', 'pmc_write_con
         w_kib = sum(wr.get(k, [0.0])) / max(1, len(wr.get(k, [0.0])))
         traffic[k] = {'fetch_bytes_raw': f_kib * 1024, 'fetch_bytes_corrected_x2': 2 * f_kib * 1024, 'write_bytes': w_kib * 1024,
                       'hbm_bytes_per_launch': (2 * f_kib + w_kib) * 1024, 'launches_averaged': len(fe[k])}
-json.dump(traffic, open('profiles/%s_traffic.json' % tag, 'w'), indent=1, sort_keys=True)
+json.dump(traffic, open(outdir + '/%s_traffic.json' % tag, 'w'), indent=1, sort_keys=True)
 # SQ / LDS counters of the conv2d_mfma kernels (averages per launch)
 sq = {}
 for d in ('pmc_sq_conv', 'pmc_lds_conv'):
@@ -69,6 +70,6 @@ for d in ('pmc_sq_conv', 'pmc_lds_conv'):
         for k, dct in acc.items():
             sq.setdefault(k, {}).update({c: sum(v) / len(v) for c, v in dct.items()})
 if sq:
-    json.dump(sq, open('profiles/%s_conv2d_mfma_counters.json' % tag, 'w'), indent=1, sort_keys=True)
-print(open('profiles/%s_kernel_stats.txt' % tag).read()[:3500])
+    json.dump(sq, open(outdir + '/%s_conv2d_mfma_counters.json' % tag, 'w'), indent=1, sort_keys=True)
+print(open(outdir + '/%s_kernel_stats.txt' % tag).read()[:3500])
 print(json.dumps(traffic, indent=1)[:3000])
