@@ -361,9 +361,10 @@ __global__ __launch_bounds__(THREADS, DIL == 1 ? 3 : (DIL == 2 ? 2 : 1)) void fw
         }
         // the wave's share of the block's bin groups: a contiguous run, in passes of at most NMAX groups of nearly equal
         // size (register budget: a pass keeps N x 3 activation fragments)
-        const int per = cur.ng >> 2, rem = cur.ng & 3;
-        int gl = wave * per + min(wave, rem);
-        int n = per + (wave < rem ? 1 : 0);
+        // (the wave that takes the odd group changes from tile to tile: the waves of a workgroup sit on different SIMDs)
+        const int per = cur.ng >> 2, rem = cur.ng & 3, wr = (wave + it) & 3;
+        int gl = wr * per + min(wr, rem);
+        int n = per + (wr < rem ? 1 : 0);
         if (dbg & DBG_NOMFMA) n = 0;
         constexpr int NMAX = (OUTMASK || MASK) ? 4 : 5;
         int npass = (n + NMAX - 1) / NMAX;

@@ -127,11 +127,16 @@ def phases(name, fn):
     fn(); torch.cuda.synchronize()
     lib.ptts_conv2d_mfma_debug(0, None)
     s = buf.view(nblk, 8); s = s[s[:, 4] != 0].double()
+    STAMPS[name] = s.cpu().numpy()
     d = [(s[:, i + 1] - s[:, i]).median().item() for i in range(4)]
     span = (s[:, 4].max() - s[:, 0].min()).item()
     print('     stamps (s_memtime ticks, median over workgroups): stage {:.0f}  barrier {:.0f}  first mfma pass {:.0f}  rest {:.0f}   lifetime {:.0f}   kernel span {:.0f}'.format(
         d[0], d[1], d[2], d[3], (s[:, 4] - s[:, 0]).median().item(), span))
+STAMPS = {}
 print('phase switches [us]:')
 phases('fwd lrelu', lambda: fwd_new(x, tf, b, None, None, ops.IN_LRELU, pad))
 phases('bwd data', lambda: fwd_new(dy, tb, None, None, x, ops.IN_NONE, 4 * dil - pad))
 phases('weight grad', lambda: wgrad_new(ops.IN_LRELU, None))
+import numpy as np
+os.makedirs('gpurun_out', exist_ok=True)
+np.savez('gpurun_out/c2m_stamps.npz', **{k.replace(' ', '_'): v for k, v in STAMPS.items()})
