@@ -28,6 +28,7 @@
 // stored as bf16 or fp32 as the caller asks.  Weight gradients stay fp32.
 #include "common.h"
 #include <cstdlib>
+#include <algorithm>
 
 namespace ptts {
 namespace c2m {
@@ -61,12 +62,33 @@ __device__ __forceinline__ void stamp(unsigned long long* buf, int dbg, int slot
     if ((dbg & DBG_STAMPS) && threadIdx.x == 0) buf[(size_t)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memtime();
 }
 
+// x = h1 + h2 + h3, hi = bf16(remainder), round to nearest even (the oracle's np_split3_bf16).  Written out pair-wise: one
+// v_cvt_pk_bf16_f32 per pair and plane, the pair widened again by a shift and a mask -- the generic vector conversions cost
+// 30 instructions per 4 values where this takes 22.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
+}
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = pk_bf16(a, b);
+    const float ra = a - __builtin_bit_cast(float, p1 << 16), rb = b - __builtin_bit_cast(float, p1 & 0xffff0000u);
+    p2 = pk_bf16(ra, rb);
+    const float sa = ra - __builtin_bit_cast(float, p2 << 16), sb = rb - __builtin_bit_cast(float, p2 & 0xffff0000u);
+    p3 = pk_bf16(sa, sb);
+}
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split3(f32x4 v, bf16x4& h1, bf16x4& h2, bf16x4& h3) {
-    h1 = __builtin_convertvector(v, bf16x4);
-    const f32x4 r1 = v - __builtin_convertvector(h1, f32x4);
-    h2 = __builtin_convertvector(r1, bf16x4);
-    const f32x4 r2 = r1 - __builtin_convertvector(h2, f32x4);
-    h3 = __builtin_convertvector(r2, bf16x4);
+    unsigned a1, a2, a3, b1, b2, b3;
+    split3_pair(v[0], v[1], a1, a2, a3);
+    split3_pair(v[2], v[3], b1, b2, b3);
+    h1 = __builtin_bit_cast(bf16x4, (u32x2){a1, b1}); h2 = __builtin_bit_cast(bf16x4, (u32x2){a2, b2}); h3 = __builtin_bit_cast(bf16x4, (u32x2){a3, b3});
+}
+// max(a, b) for finite operands in one instruction (fmaxf canonicalises its operands first)
+__device__ __forceinline__ float max_fast(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -148,6 +170,58 @@ __device__ __forceinline__ TilePos tile_pos(const Shape& s, int tile) {
     return p;
 }
 
+// The work list of a persistent workgroup.  With G workgroups and n tiles: R = n / G full rounds (tile = wg + r G) and
+// L = n % G left-over tiles.  A left-over round that occupies few workgroups for a whole tile time is the most expensive part
+// of the launch ([64,400,65,4]: 1600 tiles on 768 workgroups -> 64 of them would run a third tile while 704 idle), so every
+// left-over tile is cut into S pieces along the frequency axis for S times as many workgroups.  The FIRST tile of a workgroup
+// is cut into FS pieces as well: all workgroups start at once, nothing overlaps the loads of their first piece, and the
+// smaller it is the sooner the matrix pipe has work.  Pieces are multiples of `unit` bin groups wide.
+struct Sched { int G, R, L, S, FS, unit; };
+struct Work { int tile, g0, ng; };       // ng == 0: nothing
+__device__ __forceinline__ int sched_items(const Sched& c, int wg) {
+    return (c.R >= 1 ? c.FS + c.R - 1 : 0) + (wg < c.L * c.S ? 1 : 0);
+}
+__device__ __forceinline__ Work piece_of(int tile, int ngt, int p, int k, int unit) {
+    Work w; w.tile = tile; w.g0 = 0; w.ng = ngt;
+    if (k > 1) {                       // (whole tiles, the common case, stay clear of the integer divisions)
+        int per = (ngt + k - 1) / k;
+        per = (per + unit - 1) & ~(unit - 1);          // unit is 1 or 2
+        w.g0 = p * per;
+        w.ng = max(0, min(per, ngt - w.g0));
+    }
+    return w;
+}
+// item `it` of workgroup `wg` (0 <= it < sched_items); ngt_of(tile) = bin groups of that tile's block
+__device__ __forceinline__ Work work_item(const Shape& s, const Sched& c, int wg, int it) {
+    const int nfull = c.R >= 1 ? c.FS + c.R - 1 : 0;
+    int tile, p = 0, k = 1;
+    if (it < nfull) {
+        if (it < c.FS) { tile = wg; p = it; k = c.FS; }
+        else tile = wg + (it - c.FS + 1) * c.G;
+    } else {
+        tile = c.R * c.G + wg / c.S; p = wg % c.S; k = c.S;
+    }
+    const int fb = s.nfb > 1 ? tile - (int)__umulhi((unsigned)tile, s.magic_nfb) * s.nfb : 0;
+    const int ngt = min(GPB, s.NG - fb * GPB);
+    return piece_of(tile, ngt, p, k, c.unit);
+}
+__device__ __forceinline__ TilePos work_pos(const Shape& s, const Work& w) {
+    TilePos p = tile_pos(s, w.tile);
+    p.g_base += w.g0;
+    p.ng = w.ng;
+    return p;
+}
+// the next non-empty item after `it` (it is advanced), or ng == 0 at the end of the list
+__device__ __forceinline__ Work next_work(const Shape& s, const Sched& c, int wg, int& it, int nitems) {
+    Work w; w.tile = 0; w.g0 = 0; w.ng = 0;
+    while (++it < nitems) {
+        w = work_item(s, c, wg, it);
+        if (w.ng > 0) break;
+    }
+    if (it >= nitems) w.ng = 0;
+    return w;
+}
+
 // What a lane needs to know about its NB staging slots, computed once per workgroup (tile-independent):
 // slot idx = tid + 256 u -> staged row r = idx / SB, staged bin c = idx % SB
 template <class ST>
@@ -187,13 +261,14 @@ __device__ __forceinline__ const void* ptr_at(const void* p, long long off /*ele
 template <class ST, bool MASK>
 __device__ __forceinline__ void pref_load(Pref<ST::NB, MASK>& pf, const Slots<ST>& sl, const void* __restrict__ src,
                                           const void* __restrict__ msk, bool bf16, long long img, int t_org, int f_org, int T, int F,
-                                          int f_end /*bins >= f_end are staged as zeros (f_end <= F)*/) {
+                                          int f_end /*bins >= f_end are staged as zeros (f_end <= F)*/,
+                                          int c_end = 1 << 20 /*staged bins >= c_end are not needed: zeros, no load*/) {
     const void* base = ptr_at(src, (img + (long long)t_org * F + f_org) * C, bf16);         // wave-uniform
     const void* mbase = MASK ? ptr_at(msk, (img + (long long)t_org * F + f_org) * C, bf16) : nullptr;
 #pragma unroll
     for (int u = 0; u < ST::NB; ++u) {
         const int r = sl.rc[u] >> 8, c = sl.rc[u] & 255;
-        const bool ok = sl.rc[u] >= 0 && (unsigned)(t_org + r) < (unsigned)T && (unsigned)(f_org + c) < (unsigned)f_end;
+        const bool ok = sl.rc[u] >= 0 && c < c_end && (unsigned)(t_org + r) < (unsigned)T && (unsigned)(f_org + c) < (unsigned)f_end;
         pf.v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (MASK) pf.m[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (ok) {
@@ -235,7 +310,7 @@ __device__ __forceinline__ void pref_commit(const Pref<ST::NB, MODE == PTTS_IN_M
                 if (!ok) a = f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) a[e] = fmaxf(a[e], alpha * a[e]);      // LeakyReLU for 0 <= alpha <= 1
+            for (int e = 0; e < 4; ++e) a[e] = max_fast(a[e], alpha * a[e]);      // LeakyReLU for 0 <= alpha <= 1
         } else if (MODE == PTTS_IN_MASKMUL) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) a[e] = a[e] * (pf.m[u][e] > 0.f ? 1.f : alpha);
@@ -320,48 +395,52 @@ template <int DIL, int MODE, bool OUTMASK, int NPL>
 __global__ __launch_bounds__(THREADS, DIL == 1 ? 3 : (DIL == 2 ? 2 : 1)) void fwd_kernel(
     const void* __restrict__ x, const u16* __restrict__ tab, const float* __restrict__ bias,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, const void* __restrict__ mask_src,
-    const void* __restrict__ out_mask, void* __restrict__ y, int dt, Shape s, float alpha, int dbg, unsigned long long* dbg_buf) {
+    const void* __restrict__ out_mask, void* __restrict__ y, int dt, Shape s, Sched sc, float alpha, int dbg, unsigned long long* dbg_buf) {
     typedef Stage<4 * GPB + 4, 16 + (KT - 1) * DIL> ST;
     extern __shared__ __attribute__((aligned(16))) u16 lds[];
     stamp(dbg_buf, dbg, 0);
     u16* planes = lds;
     u16* wl = lds + NPL * ST::PS;
-    const bool in_bf16 = (dt & DT_IN) != 0, out_bf16 = (dt & DT_OUT) != 0;
+    const bool in_bf16 = NPL == 1 && (dt & DT_IN) != 0, out_bf16 = NPL == 1 && (dt & DT_OUT) != 0;   // three planes: fp32 maps
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr bool MASK = MODE == PTTS_IN_MASKMUL;
 
     Slots<ST> sl;
     sl.init();
-    int tile = blockIdx.x;
+    const int wg = blockIdx.x, nitems = sched_items(sc, wg);
+    int item = -1;
+    Work work = next_work(s, sc, wg, item, nitems);
     Pref<ST::NB, MASK> pf;
-    TilePos pos = tile_pos(s, tile < s.ntiles ? tile : 0);
-    if (tile < s.ntiles && !(dbg & DBG_NOSTAGE))
-        pref_load<ST, MASK>(pf, sl, x, mask_src, in_bf16, pos.img, pos.t0 - s.pad_t, 4 * pos.g_base - 2, s.T, s.F, s.F);
+    TilePos pos = work_pos(s, work);
+    if (work.ng > 0 && !(dbg & DBG_NOSTAGE))
+        pref_load<ST, MASK>(pf, sl, x, mask_src, in_bf16, pos.img, pos.t0 - s.pad_t, 4 * pos.g_base - 2, s.T, s.F, s.F, 4 * pos.ng + 4);
+    stamp(dbg_buf, dbg, 5);
     // the table: KT*NPL KB, 16 bytes per lane and copy, once per workgroup
     for (int i = tid; i < KT * NPL * 64; i += THREADS)
         *reinterpret_cast<bf16x8*>(wl + (size_t)i * 8) = *reinterpret_cast<const bf16x8*>(tab + (size_t)i * 8);
+    stamp(dbg_buf, dbg, 6);
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias) bv = *reinterpret_cast<const f32x4*>(bias);
     const bool store = !(dbg & DBG_NOSTORE);
     const int myrow = row_of_lane(lane & 15);
     int it = 0;
-    while (tile < s.ntiles) {
+    while (work.ng > 0) {
         if (!(dbg & DBG_NOSTAGE))
             pref_commit<ST, MODE, NPL>(pf, sl, planes, pos.t0 - s.pad_t, 4 * pos.g_base - 2, s.T, s.F, in_scale, in_shift, alpha, 0, 0, nullptr);
         if (it == 0) stamp(dbg_buf, dbg, 1);
         __syncthreads();
         if (it == 0) stamp(dbg_buf, dbg, 2);
         const TilePos cur = pos;
-        const int next = tile + gridDim.x;
-        if (next < s.ntiles) {
-            pos = tile_pos(s, next);
+        work = next_work(s, sc, wg, item, nitems);
+        if (work.ng > 0) {
+            pos = work_pos(s, work);
             if (!(dbg & DBG_NOSTAGE))
-                pref_load<ST, MASK>(pf, sl, x, mask_src, in_bf16, pos.img, pos.t0 - s.pad_t, 4 * pos.g_base - 2, s.T, s.F, s.F);
+                pref_load<ST, MASK>(pf, sl, x, mask_src, in_bf16, pos.img, pos.t0 - s.pad_t, 4 * pos.g_base - 2, s.T, s.F, s.F, 4 * pos.ng + 4);
         }
-        // the wave's share of the block's bin groups: a contiguous run, in passes of at most NMAX groups of nearly equal
+        // the wave's share of the piece's bin groups: a contiguous run, in passes of at most NMAX groups of nearly equal
         // size (register budget: a pass keeps N x 3 activation fragments)
-        // (the wave that takes the odd group changes from tile to tile: the waves of a workgroup sit on different SIMDs)
+        // (the wave that takes the odd group changes from piece to piece: the waves of a workgroup sit on different SIMDs)
         const int per = cur.ng >> 2, rem = cur.ng & 3, wr = (wave + it) & 3;
         int gl = wr * per + min(wr, rem);
         int n = per + (wr < rem ? 1 : 0);
@@ -389,7 +468,6 @@ __global__ __launch_bounds__(THREADS, DIL == 1 ? 3 : (DIL == 2 ? 2 : 1)) void fw
         }
         if (it == 0) stamp(dbg_buf, dbg, 3);
         __syncthreads();       // the planes are free again
-        tile = next;
         ++it;
     }
     stamp(dbg_buf, dbg, 4);
@@ -417,7 +495,7 @@ __device__ __forceinline__ bf16x8 cat(bf16x4 a, bf16x4 b) { return __builtin_shu
 template <int DIL, int MODE, int NPL>
 __global__ __launch_bounds__(THREADS, DIL <= 2 ? 2 : 1) void wgrad_kernel(
     const void* __restrict__ x, const void* __restrict__ dy, const void* __restrict__ mask_src,
-    float* __restrict__ partials, int dt, Shape s, float alpha, int dbg, unsigned long long* dbg_buf) {
+    float* __restrict__ partials, int dt, Shape s, Sched sc, float alpha, int dbg, unsigned long long* dbg_buf) {
     typedef Stage<4 * (GPB + 1) + 4, 16 + (KT - 1) * DIL> SD;      // dy tile with its time halo
     typedef Stage<4 * (GPB + 1) + 4, 16> SA;                       // activation tile
     static_assert(SD::RS == SA::RS, "one row stride");
@@ -425,7 +503,7 @@ __global__ __launch_bounds__(THREADS, DIL <= 2 ? 2 : 1) void wgrad_kernel(
     stamp(dbg_buf, dbg, 0);
     u16* dpl = lds;
     u16* apl = lds + NPL * SD::PS;
-    const bool x_bf16 = (dt & DT_IN) != 0, dy_bf16 = (dt & DT_DY) != 0;
+    const bool x_bf16 = NPL == 1 && (dt & DT_IN) != 0, dy_bf16 = NPL == 1 && (dt & DT_DY) != 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
@@ -447,16 +525,18 @@ __global__ __launch_bounds__(THREADS, DIL <= 2 ? 2 : 1) void wgrad_kernel(
 
     Slots<SD> sd; sd.init();
     Slots<SA> sa; sa.init();
-    int tile = blockIdx.x;
+    const int wg = blockIdx.x, nitems = sched_items(sc, wg);
+    int item = -1;
+    Work work = next_work(s, sc, wg, item, nitems);
     Pref<SD::NB, false> pd;
     Pref<SA::NB, MASK> pa;
-    TilePos pos = tile_pos(s, tile < s.ntiles ? tile : 0);
-    if (tile < s.ntiles && !(dbg & DBG_NOSTAGE)) {
-        pref_load<SD, false>(pd, sd, dy, nullptr, dy_bf16, pos.img, pos.t0 - lo, 4 * pos.g_base - 2, s.T, s.F, s.F);
-        pref_load<SA, MASK>(pa, sa, x, mask_src, x_bf16, pos.img, pos.t0, 4 * pos.g_base - 2, s.T, s.F, min(s.F, 4 * (pos.g_base + pos.ng)));
+    TilePos pos = work_pos(s, work);
+    if (work.ng > 0 && !(dbg & DBG_NOSTAGE)) {
+        pref_load<SD, false>(pd, sd, dy, nullptr, dy_bf16, pos.img, pos.t0 - lo, 4 * pos.g_base - 2, s.T, s.F, s.F, 4 * pos.ng + 4);
+        pref_load<SA, MASK>(pa, sa, x, mask_src, x_bf16, pos.img, pos.t0, 4 * pos.g_base - 2, s.T, s.F, min(s.F, 4 * (pos.g_base + pos.ng)), 4 * pos.ng + 4);
     }
     int it = 0;
-    while (tile < s.ntiles) {
+    while (work.ng > 0) {
         if (!(dbg & DBG_NOSTAGE)) {
             pref_commit<SD, PTTS_IN_NONE, NPL>(pd, sd, dpl, pos.t0 - lo, 4 * pos.g_base - 2, s.T, s.F, nullptr, nullptr, alpha, lo, 2 + 4 * pos.ng, &bsum);
             pref_commit<SA, MODE, NPL>(pa, sa, apl, pos.t0, 4 * pos.g_base - 2, s.T, s.F, nullptr, nullptr, alpha, 0, 0, nullptr);
@@ -465,15 +545,15 @@ __global__ __launch_bounds__(THREADS, DIL <= 2 ? 2 : 1) void wgrad_kernel(
         __syncthreads();
         if (it == 0) stamp(dbg_buf, dbg, 2);
         const int ng2 = (pos.ng + 1) >> 1;
-        const int next = tile + gridDim.x;
-        if (next < s.ntiles) {
-            pos = tile_pos(s, next);
+        work = next_work(s, sc, wg, item, nitems);
+        if (work.ng > 0) {
+            pos = work_pos(s, work);
             if (!(dbg & DBG_NOSTAGE)) {
-                pref_load<SD, false>(pd, sd, dy, nullptr, dy_bf16, pos.img, pos.t0 - lo, 4 * pos.g_base - 2, s.T, s.F, s.F);
-                pref_load<SA, MASK>(pa, sa, x, mask_src, x_bf16, pos.img, pos.t0, 4 * pos.g_base - 2, s.T, s.F, min(s.F, 4 * (pos.g_base + pos.ng)));
+                pref_load<SD, false>(pd, sd, dy, nullptr, dy_bf16, pos.img, pos.t0 - lo, 4 * pos.g_base - 2, s.T, s.F, s.F, 4 * pos.ng + 4);
+                pref_load<SA, MASK>(pa, sa, x, mask_src, x_bf16, pos.img, pos.t0, 4 * pos.g_base - 2, s.T, s.F, min(s.F, 4 * (pos.g_base + pos.ng)), 4 * pos.ng + 4);
             }
         }
-        for (int gp = wave; gp < ng2 && !(dbg & DBG_NOMFMA); gp += 4) {
+        for (int gp = (wave + it) & 3; gp < ng2 && !(dbg & DBG_NOMFMA); gp += 4) {
             // A operand: a[row 4 lg + e&3][group 2 gp + (e >> 2)][(fi, ci) = li]  -- staged bin of group g, fi: 4 g + 2 + fi
             bf16x8 af[NPL];
 #pragma unroll
@@ -499,8 +579,7 @@ __global__ __launch_bounds__(THREADS, DIL <= 2 ? 2 : 1) void wgrad_kernel(
             }
         }
         if (it == 0) stamp(dbg_buf, dbg, 3);
-        __syncthreads();       // planes free (and, after the last tile, dead: the LDS becomes the reduction scratch)
-        tile = next;
+        __syncthreads();       // planes free (and, after the last piece, dead: the LDS becomes the reduction scratch)
         ++it;
     }
     // ---- one reduction per workgroup, fixed order.  red[wave][kt][hb][r][lane] | bs[256][4]
@@ -594,11 +673,28 @@ template <int DIL, int NPL> constexpr size_t lds_wgrad() {
     const size_t red = (size_t)(4 * KT * 2 * 4 * 64 + THREADS * 4) * sizeof(float);
     return planes > red ? planes : red;
 }
-int grid_for(int ntiles, size_t lds, int max_per_cu) {
+// grid and work list (Sched, above).  Measurement hook: bits 8-10 of the debug flags override the number of pieces of a
+// workgroup's first tile (default 1: cutting it measured slower, the start-up is not bandwidth-bound), bits 12-14 the largest number of pieces of a left-over tile (default 4).
+Sched sched_for(int ntiles, size_t lds, int max_per_cu, int unit) {
     int per_cu = (int)(LDS_MAX / lds);
     if (per_cu > max_per_cu) per_cu = max_per_cu;
     if (per_cu < 1) per_cu = 1;
-    return ntiles < NCU * per_cu ? ntiles : NCU * per_cu;
+    const int maxg = NCU * per_cu;
+    int fs = (g_dbg >> 8) & 7, ts = (g_dbg >> 12) & 7;
+    if (fs == 0) fs = 1;
+    if (ts == 0) ts = 4;
+    Sched c;
+    c.unit = unit;
+    if (ntiles >= maxg) {
+        c.G = maxg; c.R = ntiles / maxg; c.L = ntiles % maxg;
+        c.S = c.L > 0 ? std::max(1, std::min(ts, maxg / c.L)) : 1;
+        c.FS = fs;
+    } else {
+        // fewer tiles than workgroup slots: every tile in S pieces, one piece per workgroup
+        c.S = std::max(1, std::min(ts, maxg / ntiles));
+        c.G = ntiles * c.S; c.R = 0; c.L = ntiles; c.FS = 1;
+    }
+    return c;
 }
 }  // namespace
 
@@ -640,9 +736,9 @@ extern "C" int ptts_conv2d_mfma_fwd(const void* x, const void* table, const floa
         static_assert(lds <= LDS_MAX, "tile does not fit the LDS");                                                      \
         static bool attr = false;                                                                                        \
         if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_kernel<DIL, MODE, OM, NPL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX); attr = true; } \
-        const int grid = grid_for(s.ntiles, lds, DIL == 1 ? 3 : (DIL == 2 ? 2 : 1));                                     \
-        hipLaunchKernelGGL((fwd_kernel<DIL, MODE, OM, NPL>), dim3(grid), dim3(THREADS), lds, st, x, (const u16*)table, bias, \
-                           in_scale, in_shift, mask_src, out_mask, y, dt, s, alpha, g_dbg, g_dbg_buf);                   \
+        const Sched sc = sched_for(s.ntiles, lds, DIL == 1 ? 3 : (DIL == 2 ? 2 : 1), 1);                                 \
+        hipLaunchKernelGGL((fwd_kernel<DIL, MODE, OM, NPL>), dim3(sc.G), dim3(THREADS), lds, st, x, (const u16*)table, bias, \
+                           in_scale, in_shift, mask_src, out_mask, y, dt, s, sc, alpha, g_dbg, g_dbg_buf);               \
     } while (0)
 #define C2M_M(DIL, NPL)                                                                                                  \
     do {                                                                                                                 \
@@ -693,8 +789,9 @@ extern "C" int ptts_conv2d_mfma_wgrad_partials(const void* dy, const void* x, co
         static_assert(lds <= LDS_MAX, "tile does not fit the LDS");                                                      \
         static bool attr = false;                                                                                        \
         if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<DIL, MODE, NPL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX); attr = true; } \
-        grid = grid_for(s.ntiles, lds, DIL <= 2 ? 2 : 1);                                                                \
-        hipLaunchKernelGGL((wgrad_kernel<DIL, MODE, NPL>), dim3(grid), dim3(THREADS), lds, st, x, dy, mask_src, parts, dt, s, alpha, g_dbg, g_dbg_buf); \
+        const Sched sc = sched_for(s.ntiles, lds, DIL <= 2 ? 2 : 1, 2);                                                  \
+        grid = sc.G;                                                                                                     \
+        hipLaunchKernelGGL((wgrad_kernel<DIL, MODE, NPL>), dim3(grid), dim3(THREADS), lds, st, x, dy, mask_src, parts, dt, s, sc, alpha, g_dbg, g_dbg_buf); \
     } while (0)
 #define C2M_M(DIL, NPL)                                                                                                  \
     do {                                                                                                                 \

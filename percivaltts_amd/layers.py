@@ -433,6 +433,20 @@ class GaussianNoiseInput(Layer):
 # --------------------------------------------------------------------------------------------
 # Model
 # --------------------------------------------------------------------------------------------
+_SIDE_STREAMS = {}
+
+def side_streams(n, kind='side'):
+    """The process-wide side streams (per device and kind), created once and shared by every model: each HIP stream
+    created costs every later launch of the process (a second optimiser with streams of its own ran at half the speed of
+    the first, tools/two_opt_probe.py), and a use never outlives the call that forked onto them."""
+    key = (torch.cuda.current_device(), kind)
+    ss = _SIDE_STREAMS.setdefault(key, [])
+    while len(ss) < n:
+        # high priority: a latency-bound chain of small kernels (the BLSTM branch) must not queue behind the wide ones
+        ss.append(torch.cuda.Stream(priority=int(os.environ.get('PTTS_SIDE_PRIO', '-1'))))
+    return ss[:n]
+
+
 class Model(nn.Module):
     """keras.Model(inputs, outputs): evaluates the node graph; also the parameter container."""
     def __init__(self, inputs, outputs):
@@ -600,13 +614,7 @@ class Model(nn.Module):
         return results
 
     def _variant_streams(self, n):
-        ss = getattr(self, '_vstreams', None)
-        if ss is None or len(ss) < n - 1:
-            # high priority: a latency-bound chain of small kernels (the BLSTM branch) must not queue behind the wide ones
-            prio = int(os.environ.get('PTTS_SIDE_PRIO', '-1'))
-            ss = [torch.cuda.Stream(priority=prio) for _ in range(n - 1)]
-            self._vstreams = ss
-        return ss
+        return side_streams(n - 1)
 
     # ---- Keras-like accessors ----------------------------------------------------------------
     def weights(self):

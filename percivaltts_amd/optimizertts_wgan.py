@@ -327,7 +327,8 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             run()
             return
         if self._comm is None:
-            self._comm = torch.cuda.Stream(priority=-1)
+            from . import layers
+            self._comm = layers.side_streams(1, 'comm')[0]
         cur = torch.cuda.current_stream()
         self._comm.wait_stream(cur)
         with torch.cuda.stream(self._comm):
@@ -381,7 +382,8 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
                 fn = (lambda: self.critic_step(sX, sY, sA)) if kind == 'critic' else (lambda: self.generator_step(sX, sY))
             else:
                 fn = (lambda: self._critic_grads(sX, sY, sA)) if kind == 'critic' else (lambda: self._generator_grads(sX, sY))
-            side = torch.cuda.Stream()
+            from . import layers
+            side = layers.side_streams(1, 'capture')[0]
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(2):     # warm-up outside capture (allocator, workspace growth)

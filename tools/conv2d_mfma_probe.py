@@ -113,6 +113,16 @@ print('  fused bwd   old {:7.1f}'.format(
     timeit(lambda: ops._conv2d_bwd_raw(dy, x, w, None, None, None, ops.IN_LRELU, 0.3, dil, ops.PAD_SAME, True, True, True, False))))
 print('  tables          {:7.1f}'.format(timeit(lambda: call('ptts_conv2d_mfma_tables', ptr(w), ptr(tf), ptr(tb), 5, 5, 4, 4, 3, stream()))))
 
+# ---- work-list parameters: pieces of the first tile (fs) and of a left-over tile (ts)
+print('work list sweep [us]  (fs = pieces of a workgroup\'s first tile, ts = pieces of a left-over tile):')
+for fs, ts in ((1, 1), (1, 4), (2, 4), (1, 2), (1, 6)):
+    lib.ptts_conv2d_mfma_debug((fs << 8) | (ts << 12), None)
+    print('  fs {} ts {}: fwd {:6.1f}  maskmul {:6.1f}  dx {:6.1f}  wgrad {:6.1f}'.format(fs, ts,
+        timeit(lambda: fwd_new(x, tf, b, None, None, ops.IN_LRELU, pad)),
+        timeit(lambda: fwd_new(x, tf, None, msk, None, ops.IN_MASKMUL, pad)),
+        timeit(lambda: fwd_new(dy, tb, None, None, x, ops.IN_NONE, 4 * dil - pad)),
+        timeit(lambda: wgrad_new(ops.IN_LRELU, None))))
+lib.ptts_conv2d_mfma_debug(0, None)
 # ---- where the time goes: phase switches and per-workgroup stamps (s_memtime = shader clock / ... 100 MHz constant clock)
 nblk = B * ((T + 15) // 16)
 def phases(name, fn):
@@ -130,8 +140,8 @@ def phases(name, fn):
     STAMPS[name] = s.cpu().numpy()
     d = [(s[:, i + 1] - s[:, i]).median().item() for i in range(4)]
     span = (s[:, 4].max() - s[:, 0].min()).item()
-    print('     stamps (s_memtime ticks, median over workgroups): stage {:.0f}  barrier {:.0f}  first mfma pass {:.0f}  rest {:.0f}   lifetime {:.0f}   kernel span {:.0f}'.format(
-        d[0], d[1], d[2], d[3], (s[:, 4] - s[:, 0]).median().item(), span))
+    print('     stamps (s_memtime ticks, median over workgroups): stage {:.0f}  barrier {:.0f}  first mfma pass {:.0f}  rest {:.0f}   lifetime {:.0f}   | start->loads issued {:.0f}  ->table copied {:.0f}'.format(
+        d[0], d[1], d[2], d[3], (s[:, 4] - s[:, 0]).median().item(), (s[:, 5] - s[:, 0]).median().item(), (s[:, 6] - s[:, 0]).median().item()))
 STAMPS = {}
 print('phase switches [us]:')
 phases('fwd lrelu', lambda: fwd_new(x, tf, b, None, None, ops.IN_LRELU, pad))
