@@ -335,8 +335,9 @@ def main():
         dtv, _ = timed_loop(opt, batches, short, 6, dev)
         opt.cfg.train_wgan_split_bf16 = True
         ops.conv1d_split(True)
-        extra['variant_ctx_conv1d_fp32_mfma'] = {
-            'what': 'same loop, context Conv1D forward and weight gradient on v_mfma_f32_32x32x2_f32 / 16x16x4_f32 (python bench.py --fp32-mfma)',
+        ops.dense_split(True)
+        extra['variant_fp32_mfma_gemms'] = {
+            'what': 'same loop, context Conv1D (forward, weight gradient) and Dense products on the fp32 matrix pipe, v_mfma_f32_32x32x2_f32 / 16x16x4_f32 (python bench.py --fp32-mfma)',
             'value': short * B * T * world / dtv, 'unit': 'frames/s', 'ms_per_step': dtv / short * 1e3, 'steps': short}
     # the same loop with every exact work reduction off: the TF graph's own amount and order of work
     if not args.no_unreduced and not (args.no_prune and args.no_stack and args.no_ctx_reuse and args.no_early_critic):
@@ -445,6 +446,7 @@ def main():
                        'stack_real_fake_critic_pass': bool(cfg.train_wgan_stack_real_fake),
                        'reuse_generator_ctx_conv_within_train_on_batch': bool(cfg.train_wgan_reuse_ctx_conv),
                        'ctx_conv1d_forward_and_weight_gradient': 'bf16x6 split (bf16 MFMA, fp32 accumulate)' if cfg.train_wgan_split_bf16 else 'fp32 MFMA',
+                       'dense_forward_and_backward_data': 'bf16x6 split (bf16 MFMA, fp32 accumulate); weight gradients on the fp32 matrix pipe' if (cfg.train_wgan_split_bf16 and ops._DenseSplit.enabled) else 'fp32 MFMA',
                        'conv2d_stacks': ops.conv2d_path_description() if hasattr(ops, 'conv2d_path_description') else 'fp32 packed-FMA stencil',
                        'batchnorm_statistics': 'per rank (B={} each; SyncBN off)'.format(B) if not getattr(cfg, 'train_sync_batchnorm', False) else 'synchronised over ranks (SyncBN)',
                        'input_batches_rotating': nbuf,

@@ -186,6 +186,20 @@ typedef struct ptts_wgrad_desc {
 } ptts_wgrad_desc;
 int ptts_gemm_wgrad_grouped(const ptts_wgrad_desc* descs, int n, void* stream);
 
+/* The Dense products with M >> N (reference networktts.py:59-63 pFC -> kl.Dense, networks_critic.py:86-93, the LSTM input
+ * projections of networktts.py:85-96, and TF's MatMul gradients) as fp32 products on the bf16 matrix cores by the three-way
+ * operand split of split.hip ("bf16x6": six bf16 MFMA products, fp32 accumulation; dense.hip).  The weight operand B[K][N] is
+ * split once per update into fragment-ordered planes (ptts_split3_dense_weight; transposed = 1 reads w as [N][K], which
+ * makes dX = dY.W^T read W as it lies); ptts_dense_bf16x6 then has the contract of ptts_gemm with transA = 0:
+ * C[M,N] (+)= T(A).B (+ bias), C *= (out_mask > 0 ? 1 : alpha), T = in_mode (PTTS_IN_*) with in_scale/in_shift [K] or
+ * mask_src laid out like A.  N, K, lda, ldc multiples of 4, operands 16-byte aligned (ptts_dense_bf16x6_supported). */
+size_t ptts_dense_planes_bytes(int N, int K);
+int ptts_split3_dense_weight(const float* w, long long ldw, int K, int N, int transposed, void* planes, void* stream);
+int ptts_dense_bf16x6_supported(int M, int N, int K, long long lda, long long ldc);
+int ptts_dense_bf16x6(const float* A, const void* planes, const float* bias, float* C, int M, int N, int K,
+                      long long lda, long long ldc, int in_mode, const float* in_scale, const float* in_shift,
+                      const float* mask_src, float alpha, int accumulate, const float* out_mask, void* stream);
+
 /* The context Conv1D forward (reference networktts.py:116-120: kl.Conv1D(width, winlen, padding='same')) as an fp32
  * product on the bf16 matrix cores by a three-way operand split ("bf16x6"; split.hip): x = x1 + x2 + x3 in bf16 (round
  * to nearest), six bf16 products per operand pair, fp32 accumulation -- fp32-level accuracy at 2.7x less matrix-pipe time.

@@ -422,6 +422,51 @@ def _conv2d_bwd_deferred(dy, x, w, mask_src, mode, alpha, dil_t, pad_mode, want_
     return dx
 
 
+class _DenseSplit(object):
+    """The Dense products with M >> N (forward, backward-data, the masked forward of the second-order sweep, the LSTM
+    input projections) as bf16x6 split products (csrc/dense.hip): fp32 arithmetic on the bf16 matrix cores, like the context
+    Conv1D and the Conv2D stacks.  The weight operand's planes are built once per update and kept per (weight view, stream).
+    PTTS_DENSE_SPLIT=0 or dense_split(False) select the fp32-MFMA kernels of csrc/gemm.hip."""
+    default = os.environ.get('PTTS_DENSE_SPLIT', '1') == '1'
+    enabled = default
+    planes = {}      # (id(owner), data_ptr, K, N, ldb, transB, stream) -> (owner, version, epoch, planes)
+
+    @classmethod
+    def get(cls, Bm, K, N, ldb, transB):
+        """Planes of B[K][N] (transB: stored [N][K]) if Bm is (a view of) a weight of a flat parameter buffer, else None."""
+        owner = Bm if hasattr(Bm, '_ptts_flat') else getattr(Bm, '_base', None)
+        flat = getattr(owner, '_ptts_flat', None)
+        if flat is None:
+            return None
+        key = (id(owner), Bm.data_ptr(), K, N, ldb, transB, torch.cuda.current_stream().cuda_stream)
+        ent = cls.planes.get(key)
+        if ent is None or ent[0] is not owner or ent[1] != owner._version or ent[2] != flat.epoch:
+            reuse = ent is not None and ent[0] is owner
+            buf = ent[3] if reuse else torch.empty(_hip.lib().ptts_dense_planes_bytes(N, K), dtype=torch.uint8, device=Bm.device)
+            call('ptts_split3_dense_weight', ptr(Bm), ldb, K, N, transB, ptr(buf), stream(), tag=(K, N, transB))
+            ent = (owner, owner._version, flat.epoch, buf)
+            if len(cls.planes) > 512:
+                cls.planes = {}
+            cls.planes[key] = ent
+        return ent[3]
+
+    @classmethod
+    def eligible(cls, A, C, M, N, K, lda, ldc, others):
+        if not (cls.enabled and M >= 1024 and N >= 16 and K >= 16 and N % 4 == 0 and K % 4 == 0 and lda % 4 == 0 and ldc % 4 == 0):
+            return False
+        return all(t is None or t.data_ptr() % 16 == 0 for t in (A, C) + tuple(others))
+
+
+def dense_split(on):
+    """Dense products as bf16x6 split products (True, the default) or on the fp32 matrix pipe (False); None restores the default."""
+    _DenseSplit.enabled = _DenseSplit.default if on is None else bool(on)
+
+
+def _ptr_off(t, off):
+    """A tensor whose data pointer lies `off` elements behind t's (no copy, whatever t's strides are)."""
+    return None if t is None else t.as_strided((1,), (1,), t.storage_offset() + off)
+
+
 def gemm_raw(A, Bm, C, M, N, K, transA=0, lda=None, rows_per_seg=None, seg_stride=0, transB=0, ldb=None, ldc=None,
              bias=None, mode=IN_NONE, scale=None, shift=None, mask_src=None, alpha=0.3, accumulate=0, out_mask=None,
              colsum_b=None):
@@ -437,6 +482,20 @@ def gemm_raw(A, Bm, C, M, N, K, transA=0, lda=None, rows_per_seg=None, seg_strid
         ldb = N if transB == 0 else K
     if ldc is None:
         ldc = N
+    if transA == 0 and seg_stride == 0 and rows_per_seg == M and colsum_b is None:
+        # M >> N products against a weight: the bf16x6 split kernel; a few columns beyond a multiple of 256 (the 260-wide
+        # spectral part) go to the thin fp32 kernel
+        N1 = N if (N <= 256 or N % 256 == 0 or N % 256 > 32) else N - N % 256
+        if _DenseSplit.eligible(A, C, M, N1, K, lda, ldc, (bias, scale, shift, mask_src, out_mask)):
+            planes = _DenseSplit.get(Bm, K, N1, ldb, transB)
+            if planes is not None:
+                call('ptts_dense_bf16x6', ptr(A), ptr(planes), ptr(bias), ptr(C), M, N1, K, lda, ldc, mode, ptr(scale), ptr(shift),
+                     ptr(mask_src), alpha, accumulate, ptr(out_mask), stream(), tag=(M, N1, K, transB))
+                if N1 < N:
+                    gemm_raw(A, _ptr_off(Bm, N1 * (ldb if transB else 1)), _ptr_off(C, N1), M, N - N1, K, lda=lda,
+                             transB=transB, ldb=ldb, ldc=ldc, bias=_ptr_off(bias, N1), mode=mode, scale=scale,
+                             shift=shift, mask_src=mask_src, alpha=alpha, accumulate=accumulate, out_mask=_ptr_off(out_mask, N1))
+                return C
     call('ptts_gemm', ptr(A), ptr(Bm), ptr(bias), ptr(C), M, N, K, transA, lda, rows_per_seg, seg_stride,
          transB, ldb, ldc, mode, ptr(scale), ptr(shift), ptr(mask_src), alpha, accumulate, ptr(out_mask), ptr(colsum_b), stream(),
          tag=(M, N, K, transA, transB, int(seg_stride != 0)))
@@ -850,6 +909,7 @@ def clear_caches():
     _C1Split.clear()
     _C1WgradT.clear()
     _C2M.clear()
+    _DenseSplit.planes = {}
     _C1Cache.key = _C1Cache.ap = _C1Cache.y = None
 
 

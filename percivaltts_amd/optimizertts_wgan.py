@@ -134,7 +134,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         cfg.train_wgan_graph_split = False           # hipGraph of forward + backward only, update launched eagerly (what data parallelism uses; settable for tests)
         cfg.train_wgan_async_update = None           # all-reduce + Adam on a communication stream, overlapped with the next forward that does not need the weights (None: on when world > 1)
         cfg.train_sync_batchnorm = False             # data parallelism: BatchNorm statistics over all ranks (SyncBN) instead of per rank
-        cfg.train_wgan_split_bf16 = None             # context Conv1D forward + weight gradient as bf16x6 split products (fp32 arithmetic on the bf16 matrix cores, ops._C1Split); None: the default (on; PTTS_CONV1D_SPLIT=0 turns it off), False: fp32 MFMA kernels
+        cfg.train_wgan_split_bf16 = None             # context Conv1D (forward + weight gradient) and Dense products as bf16x6 split products (fp32 arithmetic on the bf16 matrix cores: ops._C1Split, ops._DenseSplit); None: the defaults (on; PTTS_CONV1D_SPLIT=0 / PTTS_DENSE_SPLIT=0 turn them off), False: fp32 MFMA kernels
         return cfg
 
     # ---------------------------------------------------------------------------------------------------------
@@ -423,8 +423,10 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         # step's fake sample (same input, same not-yet-updated kernel): ops._C1Cache, valid inside this call only
         ops.conv1d_cache(gen_too and not use_graph and bool(getattr(self.cfg, 'train_wgan_reuse_ctx_conv', True)))
         split = getattr(self.cfg, 'train_wgan_split_bf16', None)
-        if split is not None and bool(split) != ops._C1Split.enabled:
-            ops.conv1d_split(split)
+        if split is not None:
+            if bool(split) != ops._C1Split.enabled:
+                ops.conv1d_split(split)
+            ops.dense_split(split)
         try:
             lc = self._graphed('critic', X, Y, alpha) if use_graph else self.critic_step(X, Y, alpha)
             lg = None

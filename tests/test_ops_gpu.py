@@ -808,3 +808,84 @@ def test_cpu_tensor_is_refused(ops):
     from percivaltts_amd._hip import HipLibraryError
     with pytest.raises(HipLibraryError):
         ops.gp_interpolate(torch.zeros(2, 3, 4), torch.zeros(2, 3, 4), torch.zeros(2))
+
+
+@pytest.mark.parametrize('case', [(2048, 256, 256, 0), (1500, 260, 256, 1), (1024, 64, 100, 0), (1100, 2048, 256, 0), (1024, 20, 256, 0),
+                                  (1200, 256, 2048, 1)])
+def test_dense_bf16x6_planes_and_products(ops, case):
+    """csrc/dense.hip: (i) the fragment-ordered weight planes BIT FOR BIT against oracle.np_split3_bf16; (ii) forward
+    (LeakyReLU / BatchNorm-affine on load, bias), backward-data (W^T, output mask) and the masked forward of the second-order
+    sweep against the fp64 oracle at the tolerance of the fp32-MFMA kernel, and A/B against that kernel.  Cases: the critic's
+    shape, a 260-wide output (256 + thin remainder), ragged K, the LSTM projection width, a narrow head, a deep K."""
+    import ctypes
+    M, N, K, transposed = case
+    g = gen(77)
+    A = torch.randn(M, K, generator=g, dtype=torch.float64).float()
+    W = (torch.randn(K, N, generator=g, dtype=torch.float64) / K ** 0.5).float()          # Keras layout [in, out]
+    b = torch.randn(N, generator=g, dtype=torch.float64).float()
+    lib = ops._hip.lib()
+    # ---- (i) planes of B = W (transposed == 0: stored [K][N]) or of B[k][n] = Wt[n][k] with Wt = W^T stored [N][K]
+    Wd = W.cuda()
+    src = Wd.t().contiguous() if transposed else Wd
+    nb = lib.ptts_dense_planes_bytes(N, K)
+    planes = torch.zeros(nb, dtype=torch.uint8, device='cuda')
+    ops.call('ptts_split3_dense_weight', ops.ptr(src), src.shape[1], K, N, transposed, ops.ptr(planes), ops.stream())
+    NT, KS = -(-N // 256) * 16, -(-K // 32)
+    np = O.np
+    got = planes.view(torch.bfloat16).float().view(3, NT, KS, 64, 8).cpu().numpy()
+    want = np.zeros((3, NT * 16, KS * 32), dtype=np.float32)
+    for p, pl in enumerate(O.np_split3_bf16(W.numpy())):                                  # planes of W[k][n]
+        want[p, :N, :K] = pl.T
+    # fragment order: [nt][ks][lane][e] <- n = 16 nt + (lane & 15), k = 32 ks + 8 (lane >> 4) + e
+    w4 = want.reshape(3, NT, 16, KS, 4, 8)                                               # [p][nt][li][ks][lg][e]
+    ref_frag = w4.transpose(0, 1, 3, 4, 2, 5).reshape(3, NT, KS, 64, 8)                   # lane = lg * 16 + li
+    assert (got == ref_frag).all(), 'planes differ from np_split3_bf16 in {} entries'.format(int((got != ref_frag).sum()))
+    assert (got.sum(0) == ref_frag.sum(0)).all()
+    # ---- (ii) the products through ops.gemm_raw (the routing the layers use) against fp64 and against the fp32 kernel
+    from percivaltts_amd import layers
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(src.clone())
+    h = Holder(); flat = layers.FlatParams(h, 'cuda')
+    w = h.w
+    Ad, bd = A.cuda(), b.cuda()
+    scale = (torch.rand(K, generator=g, dtype=torch.float64) + 0.5).float(); shift = torch.randn(K, generator=g, dtype=torch.float64).float()
+    msk = torch.randn(M, K, generator=g, dtype=torch.float64).float()
+    omask = torch.randn(M, N, generator=g, dtype=torch.float64).float()
+    ldb = src.shape[1]
+    def run(split, **kw):
+        ops.dense_split(split)
+        try:
+            C = torch.empty(M, N, dtype=torch.float32, device='cuda')
+            with ops._hip.KernelTimer() as kt:
+                ops.gemm_raw(Ad, w, C, M, N, K, transB=transposed, ldb=ldb, **kw)
+            return C.cpu().double(), [r[0] for r in kt.records]
+        finally:
+            ops.dense_split(None)
+    A64, W64 = A.double(), W.double()
+    variants = [
+        ('plain+bias', dict(bias=bd), A64 @ W64 + b.double()),
+        ('lrelu', dict(mode=ops.IN_LRELU, alpha=0.3), O.lrelu(A64) @ W64),
+        ('affine+lrelu', dict(mode=ops.IN_LRELU, scale=scale.cuda(), shift=shift.cuda(), alpha=0.3, bias=bd),
+         O.lrelu(A64 * scale.double() + shift.double()) @ W64 + b.double()),
+        ('maskmul', dict(mode=ops.IN_MASKMUL, mask_src=msk.cuda(), alpha=0.3), (A64 * torch.where(msk.double() > 0, 1.0, 0.3)) @ W64),
+        ('out_mask', dict(out_mask=omask.cuda(), alpha=0.3), (A64 @ W64) * torch.where(omask.double() > 0, 1.0, 0.3)),
+    ]
+    for name, kw, ref64 in variants:
+        y_split, names = run(True, **kw)
+        y_f32, names32 = run(False, **kw)
+        assert 'ptts_dense_bf16x6' in names and 'ptts_dense_bf16x6' not in names32, (name, names, names32)
+        sc = ref64.abs().mean()
+        e_split = ((y_split - ref64).abs().max() / sc).item(); e_f32 = ((y_f32 - ref64).abs().max() / sc).item()
+        # fp32 accumulation of K terms: a relative error of about sqrt(K) 2^-24 per output, its maximum over 10^5..10^6 outputs
+        # at about 5 sigma -> 8 sqrt(K) 2^-24 of mean |y| (the fp32 kernel's k-interleaved sums do better than that at deep K)
+        assert e_split < 3e-5 and e_split < max(4 * max(e_f32, 2e-6), 8 * 2.0 ** -24 * K ** 0.5), (name, e_split, e_f32)
+    # accumulate
+    ops.dense_split(True)
+    try:
+        C = torch.ones(M, N, dtype=torch.float32, device='cuda')
+        ops.gemm_raw(Ad, w, C, M, N, K, transB=transposed, ldb=ldb, accumulate=1)
+    finally:
+        ops.dense_split(None)
+    close(C, A64 @ W64 + 1.0, rtol=2e-4, atol=2e-4, what='accumulate')
