@@ -93,11 +93,12 @@ struct DenseArgs {
     int accumulate, has_affine;
 };
 
-template <int MODE, int MT>
+template <int MODE, bool AFFINE, int MT>
 __global__ __launch_bounds__(THREADS) void dense_bf16x6_kernel(DenseArgs g) {
     constexpr int TBM = 16 * MT;
-    constexpr int PL = TBM * BK;                              // elements of one plane of a stage
     constexpr int NA = (TBM * 8 + THREADS - 1) / THREADS;     // 16-byte quads (4 k) per lane and k-step
+    constexpr int ROWS = NA * THREADS / 8;                    // staged rows incl. the pad rows the idle lanes of the last slot write
+    constexpr int PL = ROWS * BK;                             // elements of one plane of a stage
     constexpr bool MASK = MODE == PTTS_IN_MASKMUL;
     __shared__ __attribute__((aligned(16))) u16 As[2][3 * PL];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -107,7 +108,8 @@ __global__ __launch_bounds__(THREADS) void dense_bf16x6_kernel(DenseArgs g) {
     const int KS = g.KS;
     const bool wave_live = n0 + 32 * wave < g.N;              // a wave whose columns lie beyond N only stages
 
-    // ---- this lane's staging slots: quad q = tid + 512 j -> row q >> 3, k-quad q & 7 (the same for every j)
+    // ---- this lane's staging slots: quad q = tid + 512 j -> row q >> 3, k-quad q & 7 (the same for every j).  No branches
+    // in the k-loop: rows beyond the tile or M read row 0 and are zeroed by a select, and so are the quads beyond K.
     const int kq = tid & 7;
     const float* pa[NA]; const float* pm[NA]; bool oka[NA]; int dst[NA];
 #pragma unroll
@@ -119,39 +121,37 @@ __global__ __launch_bounds__(THREADS) void dense_bf16x6_kernel(DenseArgs g) {
         pm[j] = MASK ? g.mask_src + base : nullptr;
         dst[j] = row * BK + ((((kq >> 1) ^ ((row >> 1) & 2))) << 3) + (kq & 1) * 4;
     }
-    struct Stage { f32x4 va[NA], vm[MASK ? NA : 1], sc, sh; };
+    struct Stage { f32x4 va[NA], vm[MASK ? NA : 1], sc, sh; bool kok; };
     auto load_a = [&](int s, Stage& sg) {
         const int k = s * BK + 4 * kq;
-        const bool kok = k < g.K;                             // K % 4 == 0: a quad is all inside or all outside
+        sg.kok = k < g.K;                                     // K % 4 == 0: a quad is all inside or all outside
+        const int ko = sg.kok ? s * BK : -4 * kq;             // (outside: the row's first quad, discarded)
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            sg.va[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (MASK) sg.vm[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (oka[j] && kok) {
-                sg.va[j] = *reinterpret_cast<const f32x4*>(pa[j] + s * BK);
-                if (MASK) sg.vm[j] = *reinterpret_cast<const f32x4*>(pm[j] + s * BK);
-            }
+            sg.va[j] = *reinterpret_cast<const f32x4*>(pa[j] + ko);
+            if (MASK) sg.vm[j] = *reinterpret_cast<const f32x4*>(pm[j] + ko);
         }
-        if (MODE == PTTS_IN_LRELU && g.has_affine) {
-            sg.sc = f32x4{0.f, 0.f, 0.f, 0.f}; sg.sh = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (kok) { sg.sc = *reinterpret_cast<const f32x4*>(g.in_scale + k); sg.sh = *reinterpret_cast<const f32x4*>(g.in_shift + k); }
+        if (AFFINE) {
+            sg.sc = *reinterpret_cast<const f32x4*>(g.in_scale + (sg.kok ? k : 0));
+            sg.sh = *reinterpret_cast<const f32x4*>(g.in_shift + (sg.kok ? k : 0));
         }
     };
     auto commit = [&](const Stage& sg, u16* as) {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            if ((tid + j * THREADS) >> 3 >= TBM) continue;
             f32x4 a = sg.va[j];
             if (MODE == PTTS_IN_LRELU) {
-                if (g.has_affine) {
-                    a = a * sg.sc + sg.sh;
-                    if (!oka[j]) a = f32x4{0.f, 0.f, 0.f, 0.f};       // rows beyond M stay zero (sh = 0 beyond K already)
-                }
+                if (AFFINE) a = a * sg.sc + sg.sh;
+                if (!(oka[j] && sg.kok)) a = z4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) a[e] = max_fast(a[e], g.alpha * a[e]);
             } else if (MASK) {
+                if (!(oka[j] && sg.kok)) a = z4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) a[e] = a[e] * (sg.vm[j][e] > 0.f ? 1.f : g.alpha);
+            } else {
+                if (!(oka[j] && sg.kok)) a = z4;
             }
             unsigned a1, a2, a3, b1, b2, b3;
             split3_pair(a[0], a[1], a1, a2, a3);
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(THREADS) void dense_bf16x6_kernel(DenseArgs g) {
     const size_t ps = (size_t)g.NT * KS * 512;
     const u16* wp[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) wp[j] = g.planes + (((size_t)((n0 >> 4) + 2 * wave + j) * KS) * 64 + lane) * 8;
+    for (int j = 0; j < 2; ++j) wp[j] = g.planes + (((size_t)((n0 >> 4) + 2 * (wave_live ? wave : 0) + j) * KS) * 64 + lane) * 8;
     auto load_w = [&](int s, bf16x8 (&wf)[2][3]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -194,49 +194,79 @@ __global__ __launch_bounds__(THREADS) void dense_bf16x6_kernel(DenseArgs g) {
         }
     };
 
+    // One basic block per k-step: the staging of step s+1 (transform, split, LDS stores into the other buffer) and the loads
+    // of step s+2 sit between the MFMAs of step s.  (A wave whose columns lie beyond N runs the same code on the first
+    // tile's planes: the MFMAs are cheap next to a divergent barrier structure, and nothing of it is stored.)
     Stage sg;
-    bf16x8 wf[2][3], wn[2][3];
+    bf16x8 wc[2][3], wn[2][3];
     load_a(0, sg);
-    if (wave_live) load_w(0, wf);
+    load_w(0, wc);
     commit(sg, As[0]);
-    if (KS > 1) load_a(1, sg);
+    load_a(1, sg);
     __syncthreads();
-    for (int s = 0; s < KS; ++s) {
+    // The two waves of a SIMD leave every barrier together; with the staging at the same place of their instruction streams
+    // both would do vector work at the same time and leave the matrix pipe idle.  Waves 0-3 (one per SIMD) stage after two
+    // row tiles, waves 4-7 after MT - 2.
+    auto step = [&](int s, int cut) {
         const u16* as = As[s & 1];
-        if (wave_live && s + 1 < KS) load_w(s + 1, wn);
-        if (wave_live) mfma_rows(as, wf, 0, MT / 2);
-        if (s + 1 < KS) commit(sg, As[(s + 1) & 1]);          // the other buffer: every wave left it at the last barrier
-        if (s + 2 < KS) load_a(s + 2, sg);
-        if (wave_live) mfma_rows(as, wf, MT / 2, MT);
+        load_w(s + 1 < KS ? s + 1 : s, wn);
+        mfma_rows(as, wc, 0, cut);
+        commit(sg, As[(s + 1) & 1]);                          // the other buffer: every wave left it at the last barrier
+        load_a(s + 2, sg);
+        mfma_rows(as, wc, cut, MT);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wc[j][p] = wn[j][p];
         __syncthreads();
-        if (s + 1 < KS) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) wf[j][p] = wn[j][p];
-        }
-    }
+    };
+    if (wave < 4) { for (int s = 0; s < KS; ++s) step(s, 2); }
+    else { for (int s = 0; s < KS; ++s) step(s, MT - 2); }
     if (!wave_live) return;
     // ---- store: lane (li, lg) of acc[i][j] holds row m0 + 16 i + li, columns n0 + 32 wave + 16 j + 4 lg .. + 3
+    const bool interior = m0 + TBM <= g.M;                    // no row guards: the mask / old-value loads go out together
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + 32 * wave + 16 * j + 4 * lg;
         if (n >= g.N) continue;                               // N % 4 == 0
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if (g.bias) bv = *reinterpret_cast<const f32x4*>(g.bias + n);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int m = m0 + 16 * i + li;
-            if (m >= g.M) continue;
-            const long long off = (long long)m * g.ldc + n;
-            f32x4 v = acc[i][j] + bv;
+        const long long off0 = (long long)(m0 + li) * g.ldc + n;
+        if (interior) {
+            f32x4 mk[MT], old[MT];
             if (g.out_mask) {
-                const f32x4 mk = *reinterpret_cast<const f32x4*>(g.out_mask + off);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] * (mk[e] > 0.f ? 1.f : g.out_alpha);
+                for (int i = 0; i < MT; ++i) mk[i] = *reinterpret_cast<const f32x4*>(g.out_mask + off0 + (long long)16 * i * g.ldc);
             }
-            if (g.accumulate) v += *reinterpret_cast<const f32x4*>(g.C + off);
-            *reinterpret_cast<f32x4*>(g.C + off) = v;
+            if (g.accumulate) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) old[i] = *reinterpret_cast<const f32x4*>(g.C + off0 + (long long)16 * i * g.ldc);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                f32x4 v = acc[i][j] + bv;
+                if (g.out_mask) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] * (mk[i][e] > 0.f ? 1.f : g.out_alpha);
+                }
+                if (g.accumulate) v += old[i];
+                *reinterpret_cast<f32x4*>(g.C + off0 + (long long)16 * i * g.ldc) = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int m = m0 + 16 * i + li;
+                if (m >= g.M) continue;
+                const long long off = off0 + (long long)16 * i * g.ldc;
+                f32x4 v = acc[i][j] + bv;
+                if (g.out_mask) {
+                    const f32x4 mk = *reinterpret_cast<const f32x4*>(g.out_mask + off);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] * (mk[e] > 0.f ? 1.f : g.out_alpha);
+                }
+                if (g.accumulate) v += *reinterpret_cast<const f32x4*>(g.C + off);
+                *reinterpret_cast<f32x4*>(g.C + off) = v;
+            }
         }
     }
 }
@@ -312,12 +342,12 @@ extern "C" int ptts_dense_bf16x6(const float* A, const void* planes, const float
     const int mt = pick_mt(M, cb);
     const dim3 grid((unsigned)((M + 16 * mt - 1) / (16 * mt)), (unsigned)cb);
     hipStream_t st = (hipStream_t)stream;
-#define DNS_L(MODE, MT) hipLaunchKernelGGL((dense_bf16x6_kernel<MODE, MT>), grid, dim3(THREADS), 0, st, g)
+#define DNS_L(MODE, AFF, MT) hipLaunchKernelGGL((dense_bf16x6_kernel<MODE, AFF, MT>), grid, dim3(THREADS), 0, st, g)
 #define DNS_M(MT)                                                                \
     do {                                                                         \
-        if (in_mode == PTTS_IN_LRELU) DNS_L(PTTS_IN_LRELU, MT);                  \
-        else if (in_mode == PTTS_IN_MASKMUL) DNS_L(PTTS_IN_MASKMUL, MT);         \
-        else DNS_L(PTTS_IN_NONE, MT);                                            \
+        if (in_mode == PTTS_IN_LRELU) { if (in_scale) DNS_L(PTTS_IN_LRELU, true, MT); else DNS_L(PTTS_IN_LRELU, false, MT); } \
+        else if (in_mode == PTTS_IN_MASKMUL) DNS_L(PTTS_IN_MASKMUL, false, MT);  \
+        else DNS_L(PTTS_IN_NONE, false, MT);                                     \
     } while (0)
     switch (mt) {
         case 4: DNS_M(4); break;
