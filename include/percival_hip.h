@@ -196,6 +196,13 @@ int ptts_gemm_wgrad_grouped(const ptts_wgrad_desc* descs, int n, void* stream);
 size_t ptts_dense_planes_bytes(int N, int K);
 int ptts_split3_dense_weight(const float* w, long long ldw, int K, int N, int transposed, void* planes, void* stream);
 int ptts_dense_bf16x6_supported(int M, int N, int K, long long lda, long long ldc);
+/* One weight-gradient product of ptts_gemm_wgrad_grouped (TF's MatMul gradient w.r.t. the kernel of a kl.Dense / LSTM input
+ * projection, plus the bias gradient) as a bf16x6 split product: C[Kin,N] += T(A)[M,Kin]^T . dY[M,N], colsum_b[N] += column
+ * sums of dY, both operands split on their way into the LDS and read transposed; fp32 atomics into the caller's buffers. */
+int ptts_dense_wgrad_bf16x6_supported(int Kin, int N, int M, long long lda, long long ldb);
+int ptts_dense_wgrad_bf16x6(const float* A, const float* dY, const float* mask_src, const float* in_scale,
+                            const float* in_shift, float* C, float* colsum_b, int Kin, int N, int M,
+                            long long lda, long long ldb, long long ldc, int in_mode, float alpha, void* stream);
 int ptts_dense_bf16x6(const float* A, const void* planes, const float* bias, float* C, int M, int N, int K,
                       long long lda, long long ldc, int in_mode, const float* in_scale, const float* in_shift,
                       const float* mask_src, float alpha, int accumulate, const float* out_mask, void* stream);

@@ -61,6 +61,8 @@ SIGNATURES = {
     'ptts_split3_dense_weight': (c_i, [c_p, c_ll, c_i, c_i, c_i, c_p, c_p]),
     'ptts_dense_bf16x6_supported': (c_i, [c_i, c_i, c_i, c_ll, c_ll]),
     'ptts_dense_bf16x6': (c_i, [c_p] * 4 + [c_i] * 3 + [c_ll, c_ll, c_i, c_p, c_p, c_p, c_f, c_i, c_p, c_p]),
+    'ptts_dense_wgrad_bf16x6_supported': (c_i, [c_i, c_i, c_i, c_ll, c_ll]),
+    'ptts_dense_wgrad_bf16x6': (c_i, [c_p] * 7 + [c_i] * 3 + [c_ll] * 3 + [c_i, c_f, c_p]),
     'ptts_colstats_workspace_bytes': (c_sz, [c_ll, c_i]),
     'ptts_colstats': (c_i, [c_p, c_ll, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_sz, c_p]),
     'ptts_bn_finalize': (c_i, [c_p, c_ll, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),

@@ -286,6 +286,210 @@ static int pick_mt(int M, int col_blocks) {
     return best;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Weight gradient  dW[Kin][N] += T(A)[M][Kin]^T . dY[M][N],  db[N] += sum_m dY[m][:]   (reduction over the M frames).
+// Both operands are activations: each 32-row slab of A (with the pending transform of the layer input) and of dY is split
+// on its way into the LDS as row-major planes [32 m][128 columns] and read TRANSPOSED by ds_read_b64_tr_b16, so that a
+// lane gets 8 consecutive m of its column (the MFMA's k index) -- the construction of conv2d_mfma.hip's weight gradient.
+// A row is eight 32-byte segments (one 16-column MFMA tile each); segment t of row r lies at position
+// (t + r + 4 (r >> 3)) & 7: the four rows a 16-lane group reads, and the two groups of a half-wave, hit disjoint banks.
+// Output tile 128 x 128 per workgroup (8 waves: 2 x 4 MFMA tiles each), the frames of a tile shared out over
+// 256 / tiles workgroups, partial sums added with fp32 atomics into the caller's gradient buffer (as the fp32 grouped
+// kernel does).  The bias gradient is summed from the staged dY values by the workgroups of the first tile row.
+// ------------------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef s16x4 __attribute__((address_space(3)))* lds_s16x4_ptr;
+__device__ __forceinline__ bf16x4 tr_read(const u16* p) {
+    return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p)));
+}
+__device__ __forceinline__ bf16x8 cat8(bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+
+struct WgradArgs {
+    const float* A; const float* dY; const float* mask_src; const float* in_scale; const float* in_shift;
+    float* C; float* colsum;
+    int Kin, N, M;
+    long long lda, ldb, ldc;
+    float alpha;
+    int tiles_n, steps_total, split;         // 128-column tiles along N; 32-row steps of M; workgroups per tile
+    int noflush;                             // measurement hook: leave out the atomic adds
+};
+
+constexpr int WT = 128;                       // tile edge (columns of A x columns of dY)
+constexpr int WROW = WT;                      // elements per staged row of a plane
+constexpr int WPL = 32 * WROW;                // elements of one plane of one operand
+
+template <int MODE, bool AFFINE>
+__global__ __launch_bounds__(THREADS) void dense_wgrad_bf16x6_kernel(WgradArgs g) {
+    constexpr bool MASK = MODE == PTTS_IN_MASKMUL;
+    extern __shared__ __attribute__((aligned(16))) u16 lds_w[];          // [buffer][A planes 0..2 | dY planes 0..2]: 96 KB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int tile = blockIdx.y, tk = tile / g.tiles_n, tn = tile - tk * g.tiles_n;
+    const int k0 = tk * WT, n0 = tn * WT;
+    // this workgroup's share of the 32-row steps
+    const int per = (g.steps_total + g.split - 1) / g.split;
+    const int s_begin = blockIdx.x * per, s_end = min(g.steps_total, s_begin + per);
+    const int nsteps = s_end - s_begin;
+    if (nsteps <= 0) return;
+
+    // ---- staging slots: float4 q = tid + 512 j (j = 0, 1) -> row q >> 5, columns 4 (q & 31) ..; the same columns for both j
+    const int c4 = tid & 31;
+    const bool a_ok = k0 + 4 * c4 < g.Kin, d_ok = n0 + 4 * c4 < g.N;     // Kin, N multiples of 4
+    const float* pa = g.A + (a_ok ? k0 + 4 * c4 : 0);
+    const float* pm = MASK ? g.mask_src + (a_ok ? k0 + 4 * c4 : 0) : nullptr;
+    const float* pd = g.dY + (d_ok ? n0 + 4 * c4 : 0);
+    int dst[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (tid + j * THREADS) >> 5;
+        dst[j] = row * WROW + ((((c4 >> 2) + row + 4 * (row >> 3)) & 7) << 4) + (c4 & 3) * 4;
+    }
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (AFFINE && a_ok) { sc = *reinterpret_cast<const f32x4*>(g.in_scale + k0 + 4 * c4); sh = *reinterpret_cast<const f32x4*>(g.in_shift + k0 + 4 * c4); }
+    struct Stage { f32x4 va[2], vm[MASK ? 2 : 1], vd[2]; bool ok[2]; };
+    auto load = [&](int s, Stage& sg) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = (s_begin + s) * 32 + ((tid + j * THREADS) >> 5);
+            sg.ok[j] = s < nsteps && m < g.M;
+            const long long r = sg.ok[j] ? m : 0;
+            sg.va[j] = *reinterpret_cast<const f32x4*>(pa + r * g.lda);
+            if (MASK) sg.vm[j] = *reinterpret_cast<const f32x4*>(pm + r * g.lda);
+            sg.vd[j] = *reinterpret_cast<const f32x4*>(pd + r * g.ldb);
+        }
+    };
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    auto commit = [&](const Stage& sg, u16* ls) {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 a = sg.va[j], d = sg.vd[j];
+            if (MODE == PTTS_IN_LRELU) {
+                if (AFFINE) a = a * sc + sh;
+                if (!(sg.ok[j] && a_ok)) a = z4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = max_fast(a[e], g.alpha * a[e]);
+            } else if (MASK) {
+                if (!(sg.ok[j] && a_ok)) a = z4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = a[e] * (sg.vm[j][e] > 0.f ? 1.f : g.alpha);
+            } else {
+                if (!(sg.ok[j] && a_ok)) a = z4;
+            }
+            if (!(sg.ok[j] && d_ok)) d = z4;
+            bsum += d;
+            unsigned a1, a2, a3, b1, b2, b3;
+            split3_pair(a[0], a[1], a1, a2, a3);
+            split3_pair(a[2], a[3], b1, b2, b3);
+            u16* q = ls + dst[j];
+            *reinterpret_cast<u32x2*>(q) = (u32x2){a1, b1};
+            *reinterpret_cast<u32x2*>(q + WPL) = (u32x2){a2, b2};
+            *reinterpret_cast<u32x2*>(q + 2 * WPL) = (u32x2){a3, b3};
+            split3_pair(d[0], d[1], a1, a2, a3);
+            split3_pair(d[2], d[3], b1, b2, b3);
+            q += 3 * WPL;
+            *reinterpret_cast<u32x2*>(q) = (u32x2){a1, b1};
+            *reinterpret_cast<u32x2*>(q + WPL) = (u32x2){a2, b2};
+            *reinterpret_cast<u32x2*>(q + 2 * WPL) = (u32x2){a3, b3};
+        }
+    };
+
+    // ---- MFMA tiles of this wave: A-column tiles 2 (wave & 3) + {0, 1}, dY-column tiles 4 (wave >> 2) + {0..3}
+    // transposed-read address of lane (li, lg) in tile t: row 8 lg + (li >> 2) (+ 4 for the second half), columns 4 (li & 3)
+    auto tr_off = [&](int t, int half) {
+        const int row = 8 * lg + (li >> 2) + 4 * half;
+        return row * WROW + (((t + row + 4 * (row >> 3)) & 7) << 4) + (li & 3) * 4;
+    };
+    int ao[2][2], bo[4][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ao[i][h] = tr_off(2 * (wave & 3) + i, h);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bo[i][h] = 3 * WPL + tr_off(4 * (wave >> 2) + i, h);
+    }
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // one k-step of MFMAs on buffer BUF (a compile-time index: every LDS address is a lane base + an immediate); the dY
+    // fragments are read once and serve both A-column tiles; `stage` (the next step's transform / split / LDS stores and the
+    // loads of the step after) runs between the two tile rows in waves 0-3 and in front of them in waves 4-7
+    auto mfma_tile_row = [&](const u16* ls, int i, const bf16x8 (&bf)[4][3]) {
+        bf16x8 af[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) af[p] = cat8(tr_read(ls + p * WPL + ao[i][0]), tr_read(ls + p * WPL + ao[i][1]));
+#define DNS_MM(PA, PW)                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA], bf[j][PW], acc[i][j], 0, 0, 0);
+        DNS_PRODUCTS(DNS_MM)
+#undef DNS_MM
+    };
+    auto read_bf = [&](const u16* ls, bf16x8 (&bf)[4][3]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bf[j][p] = cat8(tr_read(ls + p * WPL + bo[j][0]), tr_read(ls + p * WPL + bo[j][1]));
+    };
+
+    Stage sg;
+    load(0, sg);
+    commit(sg, lds_w);
+    load(1, sg);
+    __syncthreads();
+    u16* const buf0 = lds_w;
+    u16* const buf1 = lds_w + 6 * WPL;
+    auto step = [&](int s, const u16* cur, u16* nxt, bool stage_first) {
+        bf16x8 bf[4][3];
+        if (stage_first) { commit(sg, nxt); load(s + 2, sg); }       // (rows of a step beyond the share are staged as zeros)
+        read_bf(cur, bf);
+        mfma_tile_row(cur, 0, bf);
+        if (!stage_first) { commit(sg, nxt); load(s + 2, sg); }
+        mfma_tile_row(cur, 1, bf);
+        __syncthreads();
+    };
+    // The two waves of a SIMD leave every barrier together: waves 0-3 run half of their MFMAs before the staging of the next
+    // step, waves 4-7 stage first -- one wave's vector work under the other's matrix work.  Two steps per trip: the
+    // buffers are compile-time.
+    if (wave < 4) {
+        int s = 0;
+        for (; s + 1 < nsteps; s += 2) { step(s, buf0, buf1, false); step(s + 1, buf1, buf0, false); }
+        if (s < nsteps) step(s, buf0, buf1, false);
+    } else {
+        int s = 0;
+        for (; s + 1 < nsteps; s += 2) { step(s, buf0, buf1, true); step(s + 1, buf1, buf0, true); }
+        if (s < nsteps) step(s, buf0, buf1, true);
+    }
+
+    // ---- flush: lane (li, lg) of acc[i][j] holds rows k = k0 + 32 (wave & 3) + 16 i + 4 lg + r, column n0 + 64 (wave >> 2) + 16 j + li
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + 64 * (wave >> 2) + 16 * j + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = k0 + 32 * (wave & 3) + 16 * i + 4 * lg + r;
+                if (k < g.Kin && n < g.N && !g.noflush) atomicAdd(g.C + (long long)k * g.ldc + n, acc[i][j][r]);
+            }
+        }
+    if (g.colsum && tk == 0) {
+        // 16 lanes (tid >> 5) share the column group c4: sum through the LDS (the planes are dead), one atomic per column
+        float* red = reinterpret_cast<float*>(lds_w);
+        *reinterpret_cast<f32x4*>(red + tid * 4) = bsum;
+        __syncthreads();
+        if (tid < WT) {
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v += red[(q * 32 + (tid >> 2)) * 4 + (tid & 3)];
+            if (n0 + tid < g.N) atomicAdd(g.colsum + n0 + tid, v);
+        }
+    }
+}
+
 }  // namespace dns
 }  // namespace ptts
 
@@ -359,4 +563,58 @@ extern "C" int ptts_dense_bf16x6(const float* A, const void* planes, const float
 #undef DNS_M
 #undef DNS_L
     return check_launch("dense_bf16x6");
+}
+
+// 1 when ptts_dense_wgrad_bf16x6 takes the shape
+extern "C" int ptts_dense_wgrad_bf16x6_supported(int Kin, int N, int M, long long lda, long long ldb) {
+    return (Kin > 0 && N > 0 && M > 0 && Kin % 4 == 0 && N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
+            (long long)((Kin + WT - 1) / WT) * ((N + WT - 1) / WT) <= 65535) ? 1 : 0;
+}
+
+// C[Kin,N] += T(A)[M,Kin]^T . dY[M,N] and, with colsum_b, colsum_b[N] += column sums of dY: one weight-gradient product of
+// ptts_gemm_wgrad_grouped (same operand roles: A the layer input as stored with its pending transform, dY the incoming
+// gradient), accumulated with fp32 atomics into the caller's buffers.
+extern "C" int ptts_dense_wgrad_bf16x6(const float* A, const float* dY, const float* mask_src, const float* in_scale,
+                                       const float* in_shift, float* C, float* colsum_b, int Kin, int N, int M,
+                                       long long lda, long long ldb, long long ldc, int in_mode, float alpha, void* stream) {
+    PTTS_REQUIRE(A && dY && C, "dense_wgrad_bf16x6: null matrix");
+    PTTS_REQUIRE(ptts_dense_wgrad_bf16x6_supported(Kin, N, M, lda, ldb), "dense_wgrad_bf16x6: unsupported shape Kin=%d N=%d M=%d lda=%lld ldb=%lld", Kin, N, M, lda, ldb);
+    PTTS_REQUIRE(lda >= Kin && ldb >= N && ldc >= N, "dense_wgrad_bf16x6: bad leading dims");
+    PTTS_REQUIRE(in_mode >= 0 && in_mode <= 2, "dense_wgrad_bf16x6: bad in_mode %d", in_mode);
+    PTTS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "dense_wgrad_bf16x6: scale/shift must come together");
+    PTTS_REQUIRE(in_mode != PTTS_IN_MASKMUL || mask_src, "dense_wgrad_bf16x6: MASKMUL needs mask_src");
+    PTTS_REQUIRE(in_mode == PTTS_IN_LRELU || !in_scale, "dense_wgrad_bf16x6: scale/shift need PTTS_IN_LRELU");
+    PTTS_REQUIRE(alpha >= 0.f && alpha <= 1.f, "dense_wgrad_bf16x6: LeakyReLU slope %g outside [0, 1]", alpha);
+    PTTS_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)dY & 15) == 0 && (!mask_src || ((uintptr_t)mask_src & 15) == 0) &&
+                 (!in_scale || (((uintptr_t)in_scale | (uintptr_t)in_shift) & 15) == 0), "dense_wgrad_bf16x6: operands must be 16-byte aligned");
+    WgradArgs g;
+    g.A = A; g.dY = dY; g.mask_src = mask_src; g.in_scale = in_scale; g.in_shift = in_shift; g.C = C; g.colsum = colsum_b;
+    g.Kin = Kin; g.N = N; g.M = M; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.alpha = alpha;
+    const int tiles_k = (Kin + WT - 1) / WT;
+    g.tiles_n = (N + WT - 1) / WT;
+    g.steps_total = (M + 31) / 32;
+    const int tiles = tiles_k * g.tiles_n;
+    int split = (256 + tiles - 1) / tiles;                 // about one workgroup per CU
+    static int env_split = -1, env_noflush = -1;           // measurement hooks (tools/dense_split_probe.py)
+    if (env_split < 0) { const char* e = getenv("PTTS_DENSE_WGRAD_SPLIT"); env_split = e ? atoi(e) : 0; }
+    if (env_noflush < 0) { const char* e = getenv("PTTS_DENSE_WGRAD_NOFLUSH"); env_noflush = e ? atoi(e) : 0; }
+    if (env_split > 0) split = env_split;
+    g.noflush = env_noflush;
+    if (split > g.steps_total) split = g.steps_total;
+    if (split < 1) split = 1;
+    g.split = split;
+    const dim3 grid((unsigned)split, (unsigned)tiles);
+    hipStream_t st = (hipStream_t)stream;
+    constexpr size_t lds = (size_t)2 * 6 * WPL * sizeof(u16);
+#define DNS_W(MODE, AFF)                                                                                                  \
+    do {                                                                                                                  \
+        static bool attr = false;                                                                                         \
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_wgrad_bf16x6_kernel<MODE, AFF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; } \
+        hipLaunchKernelGGL((dense_wgrad_bf16x6_kernel<MODE, AFF>), grid, dim3(THREADS), lds, st, g);                      \
+    } while (0)
+    if (in_mode == PTTS_IN_LRELU) { if (in_scale) DNS_W(PTTS_IN_LRELU, true); else DNS_W(PTTS_IN_LRELU, false); }
+    else if (in_mode == PTTS_IN_MASKMUL) DNS_W(PTTS_IN_MASKMUL, false);
+    else DNS_W(PTTS_IN_NONE, false);
+#undef DNS_W
+    return check_launch("dense_wgrad_bf16x6");
 }

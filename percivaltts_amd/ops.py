@@ -165,8 +165,34 @@ def _defer_wgrad(x2, dy2, gw, gb, K_in, N, M_rows, mode, scale, shift, mask_src,
             _launch_wgrads(mine)
 
 
+def _wgrad_split_ok(x2, dy2, mask_src, scale, shift, K_in, N, M_rows):
+    """The bf16x6 split weight-gradient kernel (csrc/dense.hip) takes this product: the wide ones (the LSTM input and
+    recurrent projections, N = 1024 / 2048: 188 us against 292 for the fp32 kernel).  At 256 x 256 its 128 x 128 tiles
+    re-read both operands twice and 64 workgroups per tile flush with atomics: 46 us a product, no better than the grouped
+    fp32 launch (60 us a product inside the step), which therefore keeps the Dense layers' gradients."""
+    if not (_DenseSplit.enabled and not _Flags.deterministic and M_rows >= 2048 and N >= _DenseSplit.wgrad_min_n and K_in >= 16):
+        return False
+    if not _hip.lib().ptts_dense_wgrad_bf16x6_supported(K_in, N, M_rows, x2.stride(0), dy2.stride(0)):
+        return False
+    return all(t is None or t.data_ptr() % 16 == 0 for t in (x2, dy2, mask_src, scale, shift))
+
+
 def _launch_wgrads(items):
     cur = torch.cuda.current_stream()
+    rest = []
+    for it in items:
+        (_, x2, dy2, mask_src, scale, shift, gw, gb, K_in, N, M_rows, mode, alpha) = it
+        if _wgrad_split_ok(x2, dy2, mask_src, scale, shift, K_in, N, M_rows):
+            for t in (x2, dy2, mask_src):
+                if t is not None:
+                    t.record_stream(cur)
+            call('ptts_dense_wgrad_bf16x6', ptr(x2), ptr(dy2), ptr(mask_src), ptr(scale), ptr(shift), ptr(gw), ptr(gb),
+                 K_in, N, M_rows, x2.stride(0), dy2.stride(0), gw.stride(0), mode, alpha, stream(), tag=(K_in, N, M_rows))
+        else:
+            rest.append(it)
+    items = rest
+    if not items:
+        return
     descs = (_hip.WGradDesc * len(items))()
     for d, (_, x2, dy2, mask_src, scale, shift, gw, gb, K_in, N, M_rows, mode, alpha) in zip(descs, items):
         for t in (x2, dy2, mask_src):
@@ -430,6 +456,7 @@ class _DenseSplit(object):
     default = os.environ.get('PTTS_DENSE_SPLIT', '1') == '1'
     enabled = default
     planes = {}      # (id(owner), data_ptr, K, N, ldb, transB, stream) -> (owner, version, epoch, planes)
+    wgrad_min_n = int(os.environ.get('PTTS_DENSE_WGRAD_MIN_N', '512'))     # narrowest weight gradient the split kernel takes
 
     @classmethod
     def get(cls, Bm, K, N, ldb, transB):
@@ -482,6 +509,17 @@ def gemm_raw(A, Bm, C, M, N, K, transA=0, lda=None, rows_per_seg=None, seg_strid
         ldb = N if transB == 0 else K
     if ldc is None:
         ldc = N
+    if transA == 1 and transB == 0 and seg_stride == 0 and rows_per_seg == K and out_mask is None and bias is None \
+            and _wgrad_split_ok(A.as_strided((1, 1), (lda, 1)), Bm.as_strided((1, 1), (ldb, 1)), mask_src, scale, shift, M, N, K):
+        # a weight gradient C[M,N] = T(A)[K,M]^T . B[K,N] outside the deferred queue (the LSTM kernels): the split kernel adds
+        # into C, so C (and the bias-gradient row) start from zero
+        if not accumulate:
+            C.zero_()
+        if colsum_b is not None:
+            colsum_b.zero_()
+        call('ptts_dense_wgrad_bf16x6', ptr(A), ptr(Bm), ptr(mask_src), ptr(scale), ptr(shift), ptr(C), ptr(colsum_b),
+             M, N, K, lda, ldb, ldc, mode, alpha, stream(), tag=(M, N, K))
+        return C
     if transA == 0 and seg_stride == 0 and rows_per_seg == M and colsum_b is None:
         # M >> N products against a weight: the bf16x6 split kernel; a few columns beyond a multiple of 256 (the 260-wide
         # spectral part) go to the thin fp32 kernel

@@ -889,3 +889,48 @@ def test_dense_bf16x6_planes_and_products(ops, case):
     finally:
         ops.dense_split(None)
     close(C, A64 @ W64 + 1.0, rtol=2e-4, atol=2e-4, what='accumulate')
+
+
+@pytest.mark.parametrize('case', [(256, 256, 4096), (260, 256, 3001), (256, 2048, 2100), (64, 100, 2500), (516, 32, 2048)])
+def test_dense_weight_gradient_bf16x6(ops, case):
+    """csrc/dense.hip, dW[Kin,N] = T(A)^T . dY and db = column sums of dY as a bf16x6 split product (both operands split in
+    the kernel, read transposed out of the LDS; fp32 atomics over the workgroups that share a tile) against the fp64 oracle
+    at the tolerance of the fp32-MFMA kernel and A/B against it: plain, LeakyReLU, BatchNorm-affine + LeakyReLU and
+    gradient-penalty mask on A; a 260-wide input (three column tiles, the last with 4 columns), a ragged frame count, the LSTM
+    projection width, widths that are no multiples of 16."""
+    Kin, N, M = case
+    g = gen(78)
+    A = torch.randn(M, Kin, generator=g, dtype=torch.float64).float()
+    dY = torch.randn(M, N, generator=g, dtype=torch.float64).float()
+    scale = (torch.rand(Kin, generator=g, dtype=torch.float64) + 0.5).float(); shift = torch.randn(Kin, generator=g, dtype=torch.float64).float()
+    msk = torch.randn(M, Kin, generator=g, dtype=torch.float64).float()
+    Ad, dYd = A.cuda(), dY.cuda()
+    A64, dY64 = A.double(), dY.double()
+    def run(split, **kw):
+        ops.dense_split(split)
+        min_n, ops._DenseSplit.wgrad_min_n = ops._DenseSplit.wgrad_min_n, 16      # (the default routes only wide products here)
+        try:
+            C = torch.full((Kin, N), 7.0, dtype=torch.float32, device='cuda')
+            db = torch.full((N,), 7.0, dtype=torch.float32, device='cuda')
+            with ops._hip.KernelTimer() as kt:
+                ops.gemm_raw(Ad, dYd, C, Kin, N, M, transA=1, lda=Kin, rows_per_seg=M, colsum_b=db, **kw)
+            return C.cpu().double(), db.cpu().double(), [r[0] for r in kt.records]
+        finally:
+            ops.dense_split(None)
+            ops._DenseSplit.wgrad_min_n = min_n
+    variants = [
+        ('plain', dict(), A64),
+        ('lrelu', dict(mode=ops.IN_LRELU, alpha=0.3), O.lrelu(A64)),
+        ('affine+lrelu', dict(mode=ops.IN_LRELU, scale=scale.cuda(), shift=shift.cuda(), alpha=0.3), O.lrelu(A64 * scale.double() + shift.double())),
+        ('maskmul', dict(mode=ops.IN_MASKMUL, mask_src=msk.cuda(), alpha=0.3), A64 * torch.where(msk.double() > 0, 1.0, 0.3)),
+    ]
+    for name, kw, TA in variants:
+        ref = TA.t() @ dY64
+        dw_s, db_s, names = run(True, **kw)
+        dw_f, db_f, names32 = run(False, **kw)
+        assert 'ptts_dense_wgrad_bf16x6' in names and 'ptts_dense_wgrad_bf16x6' not in names32, (name, names, names32)
+        sc = ref.abs().mean()
+        e_s = ((dw_s - ref).abs().max() / sc).item(); e_f = ((dw_f - ref).abs().max() / sc).item()
+        # fp32 accumulation of M terms (see test_dense_bf16x6_planes_and_products)
+        assert e_s < 3e-5 and e_s < max(4 * max(e_f, 2e-6), 8 * 2.0 ** -24 * M ** 0.5), (name, e_s, e_f)
+        close(db_s, dY64.sum(0), rtol=2e-4, atol=2e-3, what='db ' + name)

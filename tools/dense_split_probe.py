@@ -29,3 +29,17 @@ for (M, N, K, tb, mode) in ((25600, 256, 256, 0, ops.IN_LRELU), (25600, 256, 256
     print('M {:6d} N {:5d} K {:5d} tb {} mode {}: fp32 {:7.1f} us ({:5.1f} TF)   bf16x6 {:7.1f} us ({:5.1f} TF)   max diff / mean {:.2e}'.format(
         M, N, K, tb, mode, t32, fl / t32 / 1e6, t6, fl / t6 / 1e6, err))
 ops.dense_split(None)
+print('weight gradients dW[Kin,N] = A^T . dY over M frames:')
+for (Kin, N, M, mode) in ((256, 256, 25600, ops.IN_LRELU), (256, 256, 51200, ops.IN_LRELU), (260, 256, 25600, ops.IN_NONE), (256, 2048, 25600, ops.IN_NONE),
+                          (256, 1024, 25600, ops.IN_NONE), (256, 256, 25600, ops.IN_MASKMUL)):
+    A = torch.randn(M, Kin, generator=g).cuda(); dY = torch.randn(M, N, generator=g).cuda()
+    msk = torch.randn(M, Kin, generator=g).cuda() if mode == ops.IN_MASKMUL else None
+    C = torch.empty(Kin, N, device='cuda'); db = torch.empty(N, device='cuda')
+    def run(): ops.gemm_raw(A, dY, C, Kin, N, M, transA=1, lda=Kin, rows_per_seg=M, mode=mode, mask_src=msk, alpha=0.3, colsum_b=db)
+    ops.dense_split(False); t32 = timeit(run); c32 = C.clone()
+    ops.dense_split(True); t6 = timeit(run)
+    err = float((C - c32).abs().max() / c32.abs().mean())
+    fl = 2.0 * M * N * Kin
+    print('Kin {:5d} N {:5d} M {:6d} mode {}: fp32 {:7.1f} us ({:5.1f} TF)   bf16x6 {:7.1f} us ({:5.1f} TF)   max diff / mean {:.2e}'.format(
+        Kin, N, M, mode, t32, fl / t32 / 1e6, t6, fl / t6 / 1e6, err))
+ops.dense_split(None)
