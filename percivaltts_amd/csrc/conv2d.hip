@@ -2,7 +2,10 @@
 //
 // Role on the hot path: the 8-deep 5x5 Conv2D stacks of the critic (reference
 // networks_critic.py:66-68) and of the generator's spectral branch (modeltts_common.py:97-100,
-// networktts.py:122-126).  Channel counts are tiny (C = 1..4) so this is a vector-ALU stencil,
+// networktts.py:122-126).  Since round 2 the 4 -> 4 channel layers of those stacks run on the bf16 matrix cores
+// (conv2d_mfma.hip); this file keeps the 1 -> 4, 4 -> 1 and gated 4 -> 8 layers, every other shape, the backward of
+// BatchNorm-fused layers, and stays selectable for the 4 -> 4 layers as the fp32 A/B partner (PTTS_CONV2D_MFMA=0).
+// Channel counts are tiny (C = 1..4) so this is a vector-ALU stencil,
 // not a GEMM: one lane owns a strip of KF consecutive frequency bins x all output channels,
 // the input tile (full frequency width + time halo) is staged once in LDS with the
 // BatchNorm-affine/LeakyReLU of the PREVIOUS layer applied on load, weights are wave-uniform
@@ -10,8 +13,10 @@
 //
 // Backward is one kernel per layer: it reads dy (with halo) and x once, produces dx with the
 // LeakyReLU mask of the previous layer already applied, and per-workgroup partial sums of
-// dw / dbias / dscale / dshift that a second tiny kernel reduces in a fixed order
-// (deterministic, no float atomics).
+// dw / dbias / dscale / dshift that a second tiny kernel reduces in a fixed order (ptts_conv2d_bwd:
+// deterministic, no float atomics).  Inside the optimiser's steps the partial rows of all layers are added into the
+// gradient buffers by ptts_conv2d_reduce_grouped instead: one launch per 16 passes, with fp32 atomics between passes
+// that share a buffer -- one descriptor per launch (a fixed order again) when ptts_set_deterministic(1) is in force.
 #include "common.h"
 #include <cstdlib>
 

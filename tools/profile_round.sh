@@ -12,6 +12,9 @@ echo "trace done" > $OUT/progress.txt
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_split -- python3 tools/split_probe.py 3 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_split -- python3 tools/split_probe.py 3 > /dev/null 2>&1
 echo "conv1d pmc done" >> $OUT/progress.txt
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_dense -- python3 tools/dense_split_probe.py > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_dense -- python3 tools/dense_split_probe.py > /dev/null 2>&1
+echo "dense pmc done" >> $OUT/progress.txt
 export C2M_ONLY=1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_conv -- python3 tools/conv2d_mfma_probe.py > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_conv -- python3 tools/conv2d_mfma_probe.py > /dev/null 2>&1

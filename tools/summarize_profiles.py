@@ -45,12 +45,12 @@ def pmc(dirname, counter):
 
 
 traffic = {}
-for fdir, wdir in (('pmc_fetch', 'pmc_write'), ('pmc_fetch_conv', 'pmc_write_conv'), ('pmc_fetch_split', 'pmc_write_split')):
+for fdir, wdir in (('pmc_fetch', 'pmc_write'), ('pmc_fetch_conv', 'pmc_write_conv'), ('pmc_fetch_split', 'pmc_write_split'), ('pmc_fetch_dense', 'pmc_write_dense')):
     if not glob.glob(src + '/' + fdir + '/runc/*_counter_collection.csv'):
         continue
     fe, wr = pmc(fdir, 'FETCH_SIZE'), pmc(wdir, 'WRITE_SIZE')
     for k in fe:
-        if not ('gemm' in k or 'conv2d' in k or 'split3' in k or 'wgrad' in k or 'c2m' in k) or k in traffic:
+        if not ('gemm' in k or 'conv2d' in k or 'split3' in k or 'wgrad' in k or 'c2m' in k or 'dense' in k) or k in traffic:
             continue
         f_kib = sum(fe[k]) / len(fe[k])
         w_kib = sum(wr.get(k, [0.0])) / max(1, len(wr.get(k, [0.0])))
