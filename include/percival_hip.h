@@ -196,13 +196,30 @@ int ptts_gemm_wgrad_grouped(const ptts_wgrad_desc* descs, int n, void* stream);
 size_t ptts_dense_planes_bytes(int N, int K);
 int ptts_split3_dense_weight(const float* w, long long ldw, int K, int N, int transposed, void* planes, void* stream);
 int ptts_dense_bf16x6_supported(int M, int N, int K, long long lda, long long ldc);
-/* One weight-gradient product of ptts_gemm_wgrad_grouped (TF's MatMul gradient w.r.t. the kernel of a kl.Dense / LSTM input
- * projection, plus the bias gradient) as a bf16x6 split product: C[Kin,N] += T(A)[M,Kin]^T . dY[M,N], colsum_b[N] += column
- * sums of dY, both operands split on their way into the LDS and read transposed; fp32 atomics into the caller's buffers. */
+/* One weight-gradient product of ptts_gemm_wgrad_grouped (TF's MatMul gradient w.r.t. the kernel of a kl.Dense / LSTM
+ * projection, plus the bias gradient) as a bf16x6 split product, in two stages without atomics between workgroups:
+ * ptts_dense_wgrad_bf16x6_partials writes every workgroup's partial tile of dW[Kin,N] = T(A)[M,Kin]^T . dY[M,N] (and of the
+ * column sums of dY) as a row of `workspace` (both operands split on their way into the LDS and read transposed);
+ * ptts_dense_wgrad_reduce_grouped sums the rows of up to 16 products per launch in a fixed order and ADDS them into the
+ * caller's gradient buffers (one fp32 atomic per element: products of one backward pass may share a buffer).
+ * ptts_dense_wgrad_bf16x6 runs both stages for one product. */
+typedef struct ptts_dense_wgrad_reduce_desc {
+    const float* partials;                   /* the workspace of ptts_dense_wgrad_bf16x6_partials */
+    int split, Kin, N;                       /* *split_out of that call; the product's dims */
+    long long ldc;
+    float* C; float* colsum_b;               /* C[Kin][ldc] += dW ; colsum_b[N] += column sums of dY (or NULL) */
+} ptts_dense_wgrad_reduce_desc;
 int ptts_dense_wgrad_bf16x6_supported(int Kin, int N, int M, long long lda, long long ldb);
+size_t ptts_dense_wgrad_workspace_bytes(int Kin, int N, int M);
+int ptts_dense_wgrad_bf16x6_partials(const float* A, const float* dY, const float* mask_src, const float* in_scale,
+                                     const float* in_shift, void* workspace, size_t workspace_bytes, int* split_out,
+                                     int Kin, int N, int M, long long lda, long long ldb, int in_mode, float alpha,
+                                     void* stream);
+int ptts_dense_wgrad_reduce_grouped(const ptts_dense_wgrad_reduce_desc* descs, int n, void* stream);
 int ptts_dense_wgrad_bf16x6(const float* A, const float* dY, const float* mask_src, const float* in_scale,
-                            const float* in_shift, float* C, float* colsum_b, int Kin, int N, int M,
-                            long long lda, long long ldb, long long ldc, int in_mode, float alpha, void* stream);
+                            const float* in_shift, float* C, float* colsum_b, void* workspace, size_t workspace_bytes,
+                            int Kin, int N, int M, long long lda, long long ldb, long long ldc, int in_mode, float alpha,
+                            void* stream);
 int ptts_dense_bf16x6(const float* A, const void* planes, const float* bias, float* C, int M, int N, int K,
                       long long lda, long long ldc, int in_mode, const float* in_scale, const float* in_shift,
                       const float* mask_src, float alpha, int accumulate, const float* out_mask, void* stream);

@@ -24,6 +24,11 @@ class WGradDesc(ctypes.Structure):
                 ('M', c_i), ('N', c_i), ('K', c_i), ('lda', c_ll), ('ldb', c_ll), ('ldc', c_ll), ('in_mode', c_i), ('alpha', c_f)]
 
 
+class DenseWgradReduceDesc(ctypes.Structure):
+    """struct ptts_dense_wgrad_reduce_desc of include/percival_hip.h (the partial rows of one weight-gradient product)."""
+    _fields_ = [('partials', c_p), ('split', c_i), ('Kin', c_i), ('N', c_i), ('ldc', c_ll), ('C', c_p), ('colsum_b', c_p)]
+
+
 class Conv2dReduceDesc(ctypes.Structure):
     """struct ptts_conv2d_reduce_desc of include/percival_hip.h (one queued conv2d backward pass)."""
     _fields_ = [('partials', c_p), ('nblocks', c_i), ('npart', c_i), ('nw', c_i), ('cout', c_i), ('dw', c_p), ('dbias', c_p)]
@@ -62,7 +67,10 @@ SIGNATURES = {
     'ptts_dense_bf16x6_supported': (c_i, [c_i, c_i, c_i, c_ll, c_ll]),
     'ptts_dense_bf16x6': (c_i, [c_p] * 4 + [c_i] * 3 + [c_ll, c_ll, c_i, c_p, c_p, c_p, c_f, c_i, c_p, c_p]),
     'ptts_dense_wgrad_bf16x6_supported': (c_i, [c_i, c_i, c_i, c_ll, c_ll]),
-    'ptts_dense_wgrad_bf16x6': (c_i, [c_p] * 7 + [c_i] * 3 + [c_ll] * 3 + [c_i, c_f, c_p]),
+    'ptts_dense_wgrad_workspace_bytes': (c_sz, [c_i, c_i, c_i]),
+    'ptts_dense_wgrad_bf16x6_partials': (c_i, [c_p] * 6 + [c_sz, c_p] + [c_i] * 3 + [c_ll] * 2 + [c_i, c_f, c_p]),
+    'ptts_dense_wgrad_reduce_grouped': (c_i, [c_p, c_i, c_p]),
+    'ptts_dense_wgrad_bf16x6': (c_i, [c_p] * 8 + [c_sz] + [c_i] * 3 + [c_ll] * 3 + [c_i, c_f, c_p]),
     'ptts_colstats_workspace_bytes': (c_sz, [c_ll, c_i]),
     'ptts_colstats': (c_i, [c_p, c_ll, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_sz, c_p]),
     'ptts_bn_finalize': (c_i, [c_p, c_ll, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),

@@ -307,17 +307,17 @@ __device__ __forceinline__ bf16x8 cat8(bf16x4 a, bf16x4 b) { return __builtin_sh
 
 struct WgradArgs {
     const float* A; const float* dY; const float* mask_src; const float* in_scale; const float* in_shift;
-    float* C; float* colsum;
+    float* partials;                         // [tile][split][WPART]: the workgroups' partial tiles (+ 128 bias sums)
     int Kin, N, M;
-    long long lda, ldb, ldc;
+    long long lda, ldb;
     float alpha;
     int tiles_n, steps_total, split;         // 128-column tiles along N; 32-row steps of M; workgroups per tile
-    int noflush;                             // measurement hook: leave out the atomic adds
 };
 
 constexpr int WT = 128;                       // tile edge (columns of A x columns of dY)
 constexpr int WROW = WT;                      // elements per staged row of a plane
 constexpr int WPL = 32 * WROW;                // elements of one plane of one operand
+constexpr int WPART = WT * WT + WT;           // floats of a workgroup's partial row: the tile and the bias sums
 
 template <int MODE, bool AFFINE>
 __global__ __launch_bounds__(THREADS) void dense_wgrad_bf16x6_kernel(WgradArgs g) {
@@ -331,8 +331,7 @@ __global__ __launch_bounds__(THREADS) void dense_wgrad_bf16x6_kernel(WgradArgs g
     // this workgroup's share of the 32-row steps
     const int per = (g.steps_total + g.split - 1) / g.split;
     const int s_begin = blockIdx.x * per, s_end = min(g.steps_total, s_begin + per);
-    const int nsteps = s_end - s_begin;
-    if (nsteps <= 0) return;
+    const int nsteps = max(0, s_end - s_begin);           // (a share without steps still writes its row of zeros)
 
     // ---- staging slots: float4 q = tid + 512 j (j = 0, 1) -> row q >> 5, columns 4 (q & 31) ..; the same columns for both j
     const int c4 = tid & 31;
@@ -464,29 +463,65 @@ __global__ __launch_bounds__(THREADS) void dense_wgrad_bf16x6_kernel(WgradArgs g
         if (s < nsteps) step(s, buf0, buf1, true);
     }
 
-    // ---- flush: lane (li, lg) of acc[i][j] holds rows k = k0 + 32 (wave & 3) + 16 i + 4 lg + r, column n0 + 64 (wave >> 2) + 16 j + li
+    // ---- the workgroup's partial tile, row (tile, split index) of the partials: [128 k][128 n] | 128 column sums of dY.
+    // lane (li, lg) of acc[i][j] holds rows k = 32 (wave & 3) + 16 i + 4 lg + r, column 64 (wave >> 2) + 16 j + li
+    float* out = g.partials + ((size_t)tile * g.split + blockIdx.x) * WPART;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n = n0 + 64 * (wave >> 2) + 16 * j + li;
+            const int n = 64 * (wave >> 2) + 16 * j + li;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int k = k0 + 32 * (wave & 3) + 16 * i + 4 * lg + r;
-                if (k < g.Kin && n < g.N && !g.noflush) atomicAdd(g.C + (long long)k * g.ldc + n, acc[i][j][r]);
+                const int k = 32 * (wave & 3) + 16 * i + 4 * lg + r;
+                out[k * WT + n] = acc[i][j][r];
             }
         }
-    if (g.colsum && tk == 0) {
-        // 16 lanes (tid >> 5) share the column group c4: sum through the LDS (the planes are dead), one atomic per column
+    {
+        // 16 lanes (tid >> 5) share the column group c4: sum through the LDS (the planes are dead)
         float* red = reinterpret_cast<float*>(lds_w);
+        __syncthreads();
         *reinterpret_cast<f32x4*>(red + tid * 4) = bsum;
         __syncthreads();
         if (tid < WT) {
             float v = 0.f;
 #pragma unroll
             for (int q = 0; q < 16; ++q) v += red[(q * 32 + (tid >> 2)) * 4 + (tid & 3)];
-            if (n0 + tid < g.N) atomicAdd(g.colsum + n0 + tid, v);
+            out[WT * WT + tid] = v;
         }
+    }
+}
+
+
+// partial rows -> gradient buffers, several products per launch.  Thread = one element of a tile, summed over the split
+// workgroups in a fixed order; added into C / the bias gradient with one fp32 atomic per element (products of one backward
+// pass share gradient buffers: first- and second-order sweeps of a layer).
+constexpr int DR_MAX = 16;
+struct DwReduceArgs {
+    int n;
+    int blk_begin[DR_MAX + 1];
+    const float* partials[DR_MAX]; float* C[DR_MAX]; float* colsum[DR_MAX];
+    int split[DR_MAX], tiles_n[DR_MAX], Kin[DR_MAX], N[DR_MAX];
+    long long ldc[DR_MAX];
+};
+constexpr int DR_BPT = (WPART + 255) / 256;       // blocks per tile (the last one holds the bias sums)
+__global__ __launch_bounds__(256) void dense_wgrad_reduce_kernel(DwReduceArgs a) {
+    int gi = 0;
+    while ((int)blockIdx.x >= a.blk_begin[gi + 1]) ++gi;
+    const int b = blockIdx.x - a.blk_begin[gi];
+    const int tile = b / DR_BPT, e = (b - tile * DR_BPT) * 256 + threadIdx.x;
+    if (e >= WPART) return;
+    const int S = a.split[gi];
+    const float* p = a.partials[gi] + (size_t)tile * S * WPART + e;
+    float v = 0.f;
+    for (int s = 0; s < S; ++s) v += p[(size_t)s * WPART];
+    const int tk = tile / a.tiles_n[gi], tn = tile - tk * a.tiles_n[gi];
+    if (e < WT * WT) {
+        const int k = tk * WT + (e >> 7), n = tn * WT + (e & (WT - 1));
+        if (k < a.Kin[gi] && n < a.N[gi]) atomicAdd(a.C[gi] + (long long)k * a.ldc[gi] + n, v);
+    } else if (tk == 0 && a.colsum[gi]) {
+        const int n = tn * WT + (e - WT * WT);
+        if (n < a.N[gi]) atomicAdd(a.colsum[gi] + n, v);
     }
 }
 
@@ -571,15 +606,34 @@ extern "C" int ptts_dense_wgrad_bf16x6_supported(int Kin, int N, int M, long lon
             (long long)((Kin + WT - 1) / WT) * ((N + WT - 1) / WT) <= 65535) ? 1 : 0;
 }
 
-// C[Kin,N] += T(A)[M,Kin]^T . dY[M,N] and, with colsum_b, colsum_b[N] += column sums of dY: one weight-gradient product of
-// ptts_gemm_wgrad_grouped (same operand roles: A the layer input as stored with its pending transform, dY the incoming
-// gradient), accumulated with fp32 atomics into the caller's buffers.
-extern "C" int ptts_dense_wgrad_bf16x6(const float* A, const float* dY, const float* mask_src, const float* in_scale,
-                                       const float* in_shift, float* C, float* colsum_b, int Kin, int N, int M,
-                                       long long lda, long long ldb, long long ldc, int in_mode, float alpha, void* stream) {
-    PTTS_REQUIRE(A && dY && C, "dense_wgrad_bf16x6: null matrix");
+namespace {
+int wgrad_split(int Kin, int N, int M) {
+    const int tiles = ((Kin + WT - 1) / WT) * ((N + WT - 1) / WT), steps = (M + 31) / 32;
+    int split = (256 + tiles - 1) / tiles;                 // about one workgroup per CU
+    static int env_split = -1;                              // measurement hook (tools/dense_split_probe.py)
+    if (env_split < 0) { const char* e = getenv("PTTS_DENSE_WGRAD_SPLIT"); env_split = e ? atoi(e) : 0; }
+    if (env_split > 0) split = env_split;
+    if (split > steps) split = steps;
+    return split < 1 ? 1 : split;
+}
+}  // namespace
+
+extern "C" size_t ptts_dense_wgrad_workspace_bytes(int Kin, int N, int M) {
+    if (Kin <= 0 || N <= 0 || M <= 0) return 0;
+    const size_t tiles = (size_t)((Kin + WT - 1) / WT) * ((N + WT - 1) / WT);
+    return tiles * wgrad_split(Kin, N, M) * WPART * sizeof(float);
+}
+
+// Stage 1 of a weight-gradient product dW[Kin,N] = T(A)[M,Kin]^T . dY[M,N] (+ column sums of dY): every workgroup's partial
+// tile as a row of `workspace` ([tile][split][128*128 + 128] floats; *split_out = workgroups per tile).  Stage 2,
+// ptts_dense_wgrad_reduce_grouped, adds the rows of several products into their gradient buffers in one launch.
+extern "C" int ptts_dense_wgrad_bf16x6_partials(const float* A, const float* dY, const float* mask_src, const float* in_scale,
+                                                const float* in_shift, void* workspace, size_t workspace_bytes, int* split_out,
+                                                int Kin, int N, int M, long long lda, long long ldb, int in_mode, float alpha,
+                                                void* stream) {
+    PTTS_REQUIRE(A && dY && workspace && split_out, "dense_wgrad_bf16x6: null pointer");
     PTTS_REQUIRE(ptts_dense_wgrad_bf16x6_supported(Kin, N, M, lda, ldb), "dense_wgrad_bf16x6: unsupported shape Kin=%d N=%d M=%d lda=%lld ldb=%lld", Kin, N, M, lda, ldb);
-    PTTS_REQUIRE(lda >= Kin && ldb >= N && ldc >= N, "dense_wgrad_bf16x6: bad leading dims");
+    PTTS_REQUIRE(lda >= Kin && ldb >= N, "dense_wgrad_bf16x6: bad leading dims");
     PTTS_REQUIRE(in_mode >= 0 && in_mode <= 2, "dense_wgrad_bf16x6: bad in_mode %d", in_mode);
     PTTS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "dense_wgrad_bf16x6: scale/shift must come together");
     PTTS_REQUIRE(in_mode != PTTS_IN_MASKMUL || mask_src, "dense_wgrad_bf16x6: MASKMUL needs mask_src");
@@ -587,23 +641,18 @@ extern "C" int ptts_dense_wgrad_bf16x6(const float* A, const float* dY, const fl
     PTTS_REQUIRE(alpha >= 0.f && alpha <= 1.f, "dense_wgrad_bf16x6: LeakyReLU slope %g outside [0, 1]", alpha);
     PTTS_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)dY & 15) == 0 && (!mask_src || ((uintptr_t)mask_src & 15) == 0) &&
                  (!in_scale || (((uintptr_t)in_scale | (uintptr_t)in_shift) & 15) == 0), "dense_wgrad_bf16x6: operands must be 16-byte aligned");
+    const size_t need = ptts_dense_wgrad_workspace_bytes(Kin, N, M);
+    if (workspace_bytes < need) { set_error("dense_wgrad_bf16x6: workspace %zu < %zu", workspace_bytes, need); return PTTS_EWORKSPACE; }
     WgradArgs g;
-    g.A = A; g.dY = dY; g.mask_src = mask_src; g.in_scale = in_scale; g.in_shift = in_shift; g.C = C; g.colsum = colsum_b;
-    g.Kin = Kin; g.N = N; g.M = M; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.alpha = alpha;
+    g.A = A; g.dY = dY; g.mask_src = mask_src; g.in_scale = in_scale; g.in_shift = in_shift; g.partials = (float*)workspace;
+    g.Kin = Kin; g.N = N; g.M = M; g.lda = lda; g.ldb = ldb; g.alpha = alpha;
     const int tiles_k = (Kin + WT - 1) / WT;
     g.tiles_n = (N + WT - 1) / WT;
     g.steps_total = (M + 31) / 32;
     const int tiles = tiles_k * g.tiles_n;
-    int split = (256 + tiles - 1) / tiles;                 // about one workgroup per CU
-    static int env_split = -1, env_noflush = -1;           // measurement hooks (tools/dense_split_probe.py)
-    if (env_split < 0) { const char* e = getenv("PTTS_DENSE_WGRAD_SPLIT"); env_split = e ? atoi(e) : 0; }
-    if (env_noflush < 0) { const char* e = getenv("PTTS_DENSE_WGRAD_NOFLUSH"); env_noflush = e ? atoi(e) : 0; }
-    if (env_split > 0) split = env_split;
-    g.noflush = env_noflush;
-    if (split > g.steps_total) split = g.steps_total;
-    if (split < 1) split = 1;
-    g.split = split;
-    const dim3 grid((unsigned)split, (unsigned)tiles);
+    g.split = wgrad_split(Kin, N, M);
+    *split_out = g.split;
+    const dim3 grid((unsigned)g.split, (unsigned)tiles);
     hipStream_t st = (hipStream_t)stream;
     constexpr size_t lds = (size_t)2 * 6 * WPL * sizeof(u16);
 #define DNS_W(MODE, AFF)                                                                                                  \
@@ -616,5 +665,42 @@ extern "C" int ptts_dense_wgrad_bf16x6(const float* A, const float* dY, const fl
     else if (in_mode == PTTS_IN_MASKMUL) DNS_W(PTTS_IN_MASKMUL, false);
     else DNS_W(PTTS_IN_NONE, false);
 #undef DNS_W
-    return check_launch("dense_wgrad_bf16x6");
+    return check_launch("dense_wgrad_bf16x6_partials");
+}
+
+extern "C" int ptts_dense_wgrad_reduce_grouped(const ptts_dense_wgrad_reduce_desc* descs, int n, void* stream) {
+    PTTS_REQUIRE(descs && n > 0, "dense_wgrad_reduce_grouped: nothing to reduce");
+    for (int base = 0; base < n; base += DR_MAX) {
+        DwReduceArgs a;
+        a.n = n - base < DR_MAX ? n - base : DR_MAX;
+        int blocks = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const ptts_dense_wgrad_reduce_desc& d = descs[base + i];
+            PTTS_REQUIRE(d.partials && d.C && d.split > 0 && d.Kin > 0 && d.N > 0 && d.ldc >= d.N, "dense_wgrad_reduce_grouped: bad product %d", base + i);
+            a.blk_begin[i] = blocks;
+            a.tiles_n[i] = (d.N + WT - 1) / WT;
+            blocks += ((d.Kin + WT - 1) / WT) * a.tiles_n[i] * DR_BPT;
+            a.partials[i] = d.partials; a.C[i] = d.C; a.colsum[i] = d.colsum_b; a.split[i] = d.split; a.Kin[i] = d.Kin; a.N[i] = d.N; a.ldc[i] = d.ldc;
+        }
+        a.blk_begin[a.n] = blocks;
+        hipLaunchKernelGGL(dense_wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+        int rc = check_launch("dense_wgrad_reduce_grouped");
+        if (rc) return rc;
+    }
+    return PTTS_OK;
+}
+
+// C[Kin,N] += T(A)[M,Kin]^T . dY[M,N] and, with colsum_b, colsum_b[N] += column sums of dY -- both stages for one product.
+extern "C" int ptts_dense_wgrad_bf16x6(const float* A, const float* dY, const float* mask_src, const float* in_scale,
+                                       const float* in_shift, float* C, float* colsum_b, void* workspace, size_t workspace_bytes,
+                                       int Kin, int N, int M, long long lda, long long ldb, long long ldc, int in_mode,
+                                       float alpha, void* stream) {
+    PTTS_REQUIRE(C && ldc >= N, "dense_wgrad_bf16x6: bad output");
+    int split = 0;
+    int rc = ptts_dense_wgrad_bf16x6_partials(A, dY, mask_src, in_scale, in_shift, workspace, workspace_bytes, &split, Kin, N, M,
+                                              lda, ldb, in_mode, alpha, stream);
+    if (rc) return rc;
+    ptts_dense_wgrad_reduce_desc d;
+    d.partials = (const float*)workspace; d.split = split; d.Kin = Kin; d.N = N; d.ldc = ldc; d.C = C; d.colsum_b = colsum_b;
+    return ptts_dense_wgrad_reduce_grouped(&d, 1, stream);
 }

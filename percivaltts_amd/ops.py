@@ -179,17 +179,27 @@ def _wgrad_split_ok(x2, dy2, mask_src, scale, shift, K_in, N, M_rows):
 
 def _launch_wgrads(items):
     cur = torch.cuda.current_stream()
-    rest = []
+    rest, split_items = [], []
     for it in items:
         (_, x2, dy2, mask_src, scale, shift, gw, gb, K_in, N, M_rows, mode, alpha) = it
         if _wgrad_split_ok(x2, dy2, mask_src, scale, shift, K_in, N, M_rows):
             for t in (x2, dy2, mask_src):
                 if t is not None:
                     t.record_stream(cur)
-            call('ptts_dense_wgrad_bf16x6', ptr(x2), ptr(dy2), ptr(mask_src), ptr(scale), ptr(shift), ptr(gw), ptr(gb),
-                 K_in, N, M_rows, x2.stride(0), dy2.stride(0), gw.stride(0), mode, alpha, stream(), tag=(K_in, N, M_rows))
+            # stage 1: the workgroups' partial tiles; stage 2 below, one launch for all products of this batch
+            ws = torch.empty(_hip.lib().ptts_dense_wgrad_workspace_bytes(K_in, N, M_rows), dtype=torch.uint8, device=x2.device)
+            nsplit = ctypes.c_int(0)
+            call('ptts_dense_wgrad_bf16x6_partials', ptr(x2), ptr(dy2), ptr(mask_src), ptr(scale), ptr(shift), ptr(ws), ws.numel(),
+                 ctypes.byref(nsplit), K_in, N, M_rows, x2.stride(0), dy2.stride(0), mode, alpha, stream(), tag=(K_in, N, M_rows))
+            split_items.append((ws, nsplit.value, K_in, N, gw, gb))
         else:
             rest.append(it)
+    if split_items:
+        descs = (_hip.DenseWgradReduceDesc * len(split_items))()
+        for d, (ws, nsplit, K_in, N, gw, gb) in zip(descs, split_items):
+            d.partials, d.split, d.Kin, d.N, d.ldc = ws.data_ptr(), nsplit, K_in, N, gw.stride(0)
+            d.C, d.colsum_b = gw.data_ptr(), (gb.data_ptr() if gb is not None else None)
+        call('ptts_dense_wgrad_reduce_grouped', ctypes.cast(descs, ctypes.c_void_p), len(split_items), stream(), tag=(len(split_items),))
     items = rest
     if not items:
         return
@@ -456,7 +466,7 @@ class _DenseSplit(object):
     default = os.environ.get('PTTS_DENSE_SPLIT', '1') == '1'
     enabled = default
     planes = {}      # (id(owner), data_ptr, K, N, ldb, transB, stream) -> (owner, version, epoch, planes)
-    wgrad_min_n = int(os.environ.get('PTTS_DENSE_WGRAD_MIN_N', '512'))     # narrowest weight gradient the split kernel takes
+    wgrad_min_n = int(os.environ.get('PTTS_DENSE_WGRAD_MIN_N', '16'))      # narrowest weight gradient the split kernel takes
 
     @classmethod
     def get(cls, Bm, K, N, ldb, transB):
@@ -517,8 +527,9 @@ def gemm_raw(A, Bm, C, M, N, K, transA=0, lda=None, rows_per_seg=None, seg_strid
             C.zero_()
         if colsum_b is not None:
             colsum_b.zero_()
+        ws = _workspace(_hip.lib().ptts_dense_wgrad_workspace_bytes(M, N, K), A.device)
         call('ptts_dense_wgrad_bf16x6', ptr(A), ptr(Bm), ptr(mask_src), ptr(scale), ptr(shift), ptr(C), ptr(colsum_b),
-             M, N, K, lda, ldb, ldc, mode, alpha, stream(), tag=(M, N, K))
+             ptr(ws), ws.numel(), M, N, K, lda, ldb, ldc, mode, alpha, stream(), tag=(M, N, K))
         return C
     if transA == 0 and seg_stride == 0 and rows_per_seg == M and colsum_b is None:
         # M >> N products against a weight: the bf16x6 split kernel; a few columns beyond a multiple of 256 (the 260-wide
