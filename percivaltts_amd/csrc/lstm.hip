@@ -9,6 +9,7 @@
 // read coalesced along the unit index (it stays L2-resident: 1 MiB per direction at H = 256).
 // Round-1 form: generic in (B, H); an MFMA 16x16x4 tile version is the planned replacement.
 #include "common.h"
+#include <cstdlib>
 
 namespace ptts {
 
@@ -453,13 +454,144 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_pk_kernel(
 
 static inline bool lstm_pk_ok(int H) { return H % 64 == 0 && ((H / 16) <= 16 ? true : (H / 16) % 16 == 0); }
 
+
+// ------------------------------------------------------------------------------------------------
+// Persistent forward recurrence (H = 256): ONE launch for all T steps.
+//
+// The recurrence of one (direction, 16-sample slice) -- a "group" -- involves 32 workgroups of 8 hidden units each (the
+// tiling of lstm_fwd_step_pk_kernel); nothing couples different groups.  A workgroup keeps its slice of U (32 registers per
+// lane) and its cell state c in registers for the whole sequence; what crosses workgroups per step is h_t: 512 bytes
+// written, the group's 16 KB read.  It travels as DATA-TAGGED GRANULES (MI355X_MICROARCH.md, hand-off rows): every value is
+// one naturally aligned 8-byte {h, step tag} written by ONE sc1 store and read by sc1 loads until the tag is the expected
+// one -- no flag, no counter, no drain, no ordering to get wrong.  (A first version with sc1 payload + drained stores + a
+// barrier + one agent-scope counter add per workgroup + a polled counter measured 7.0 us per step, slower than the 6.3 us of
+// the per-step launches it replaces.)  Two granule buffers by step parity: a workgroup can be one step ahead of the slowest
+// member of its group, never two (it needs that member's h first).  Group = blockIdx % groups, so with groups = 8 (B = 64,
+// both directions) the 32 members of a group sit on one XCD (workgroups go to XCDs round-robin); any other placement is
+// slower, not wrong.  A poll that does not match within ~2^21 rounds (seconds: a workgroup of the group never became
+// resident) gives up for good and lets NaNs through, which the training loop reports as a NaN cost -- no hang.
+// ------------------------------------------------------------------------------------------------
+struct LstmPersistArgs {
+    const float* xproj; const float* Upk; float* h_out; float* gates; float* c_out; unsigned long long* xbuf;
+    int B, T, ndir, reverse, groups;
+};
+
+__global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(LstmPersistArgs a) {
+    constexpr int H = 256, KS = 16;
+    __shared__ float red[2][4][2][256];
+    __shared__ int give_up;
+    const int g = blockIdx.x % a.groups, jt = blockIdx.x / a.groups;        // 32 members per group
+    const int nslices = a.groups / a.ndir;
+    const int d = g / nslices, b0 = (g - d * nslices) * 16, j0 = jt * 8;
+    const bool rev = a.ndir == 2 ? d == 1 : a.reverse != 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int B = a.B, T = a.T, ndir = a.ndir;
+    const long long G4 = 4LL * H, HH = (long long)ndir * H;
+    if (tid == 0) give_up = 0;
+    // this lane's slice of U: k = wave * 64 + q * 16 + st, columns (gate pair, unit) = r16
+    f32x4a uv[KS / 2];
+    {
+        const float* up = a.Upk + ((((long long)d * (H / 8) + jt) * 4 + wave) * 64 + lane) * KS * 2;
+#pragma unroll
+        for (int i = 0; i < KS / 2; ++i) uv[i] = *reinterpret_cast<const f32x4a*>(up + 4 * i);
+    }
+    const int bb = tid >> 3, jj = tid & 7;
+    const int eb = b0 + bb, ej = j0 + jj;
+    const bool epi = tid < 128 && eb < B;
+    const bool feeds = b0 + r16 < B;                                         // the sample whose h this lane feeds to the MFMA exists
+    // granules of the group: [parity][16 samples][256 units]
+    unsigned long long* const xg = a.xbuf + (size_t)g * 16 * H;
+    const size_t xpar = (size_t)a.groups * 16 * H;
+    const unsigned long long* const xin = xg + (size_t)r16 * H + wave * (H / 4) + q * KS;
+    unsigned long long* const xout = xg + (size_t)bb * H + ej;
+    float c = 0.f;
+    bool gave_up = false;
+    __syncthreads();
+    for (int s = 0; s < T; ++s) {
+        const int t = rev ? T - 1 - s : s;
+        float xv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (epi) {
+            const float* xp = a.xproj + (((long long)eb * T + t) * ndir + d) * G4;
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt) xv[gt] = xp[gt * H + ej];
+        }
+        float (*rd)[2][256] = red[s & 1];
+        if (s > 0) {
+            // h of the previous step: 16 granules of this lane's sample, tag = s
+            const unsigned long long* xp = xin + ((s - 1) & 1) * xpar;
+            unsigned long long gr[KS];
+            int rounds = 0;
+            gave_up = gave_up || give_up != 0;
+            for (;;) {
+#pragma unroll
+                for (int i = 0; i < KS; ++i) gr[i] = __hip_atomic_load(xp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bool ok = true;
+#pragma unroll
+                for (int i = 0; i < KS; ++i) ok = ok && (unsigned)(gr[i] >> 32) == (unsigned)s;
+                if (__all(ok || !feeds) || gave_up) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++rounds > (1 << 21)) { gave_up = true; give_up = 1; }
+            }
+            f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < KS; ++i) {
+                float av = feeds ? __builtin_bit_cast(float, (unsigned)gr[i]) : 0.f;
+                if (gave_up) av = __builtin_nanf("");
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, uv[i / 2][(i % 2) * 2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, uv[i / 2][(i % 2) * 2 + 1], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                rd[wave][0][(q * 4 + r) * 16 + r16] = acc0[r];
+                rd[wave][1][(q * 4 + r) * 16 + r16] = acc1[r];
+            }
+            __syncthreads();
+        }
+        if (epi) {
+            float a4[4];
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt) {
+                float v = xv[gt];
+                if (s > 0) {
+                    const int idx = bb * 16 + (gt & 1) * 8 + jj;
+                    v += rd[0][gt >> 1][idx] + rd[1][gt >> 1][idx] + rd[2][gt >> 1][idx] + rd[3][gt >> 1][idx];
+                }
+                a4[gt] = v;
+            }
+            const float gi = sigmoidf_(a4[0]), gf = sigmoidf_(a4[1]), gc = tanhf(a4[2]), go = sigmoidf_(a4[3]);
+            const long long so = ((long long)eb * T + t) * HH + (long long)d * H + ej;
+            c = gf * c + gi * gc;
+            const float h = go * tanhf(c);
+            // the hand-off first: {h, tag s + 1} in one 8-byte sc1 store
+            __hip_atomic_store(xout + (s & 1) * xpar, ((unsigned long long)(unsigned)(s + 1) << 32) | __builtin_bit_cast(unsigned, h),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.c_out[so] = c;
+            a.h_out[so] = h;
+            float* gp = a.gates + (((long long)eb * T + t) * ndir + d) * G4;
+            gp[ej] = gi; gp[H + ej] = gf; gp[2 * H + ej] = gc; gp[3 * H + ej] = go;
+        }
+    }
+}
+
 }  // namespace ptts
 
 using namespace ptts;
 
+// the persistent forward kernel: H = 256, at least two steps, all workgroups resident at once (<= 4 per CU).  OFF by
+// default (PTTS_LSTM_PERSISTENT=1 selects it, read at every call): at [64,400] it measured 10.6 us per step with the
+// data-tagged granules below and 7.0 us with a drained-store + counter hand-off, against 6.3 us for the per-step launches --
+// every sc1 round trip of the hand-off costs about what a kernel boundary does.
+static bool lstm_persistent_ok(int B, int T, int H, int ndir) {
+    const char* e = getenv("PTTS_LSTM_PERSISTENT");
+    const int groups = ((B + 15) / 16) * ndir;
+    return e && atoi(e) != 0 && H == 256 && T >= 2 && groups * 32 <= 1024;
+}
+
 extern "C" size_t ptts_lstm_fwd_workspace_bytes(int B, int T, int H, int ndir) {
-    (void)B; (void)T;
-    return lstm_pk_ok(H) ? (size_t)ndir * 4 * H * H * sizeof(float) : 16;
+    (void)T;
+    const size_t granules = (size_t)2 * ((B + 15) / 16) * ndir * 16 * H * 8;     // the persistent kernel's {h, tag} buffers, behind the packed U
+    return lstm_pk_ok(H) ? (size_t)ndir * 4 * H * H * sizeof(float) + granules : 16;
 }
 
 extern "C" int ptts_lstm_fwd(const float* xproj, const float* U, float* h_out, float* gates, float* c_out,
@@ -474,6 +606,16 @@ extern "C" int ptts_lstm_fwd(const float* xproj, const float* U, float* h_out, f
     if (lstm_pk_ok(H) && workspace && workspace_bytes >= ptts_lstm_fwd_workspace_bytes(B, T, H, ndir)) {
         float* Upk = (float*)workspace;
         hipLaunchKernelGGL(lstm_pack_u_fwd_kernel, dim3(1024), dim3(256), 0, st, U, Upk, H, ndir);
+        if (lstm_persistent_ok(B, T, H, ndir)) {
+            LstmPersistArgs pa;
+            pa.xproj = xproj; pa.Upk = Upk; pa.h_out = h_out; pa.gates = gates; pa.c_out = c_out;
+            pa.xbuf = reinterpret_cast<unsigned long long*>(Upk + (size_t)ndir * 4 * H * H);
+            pa.B = B; pa.T = T; pa.ndir = ndir; pa.reverse = reverse; pa.groups = ((B + 15) / 16) * ndir;
+            int rc = zero_f32(reinterpret_cast<float*>(pa.xbuf), (size_t)2 * pa.groups * 16 * H * 2, st);      // tags 0
+            if (rc) return rc;
+            hipLaunchKernelGGL(lstm_fwd_persistent_kernel, dim3(pa.groups * 32), dim3(256), 0, st, pa);
+            return check_launch("lstm_fwd_persistent");
+        }
         dim3 mgrid(H / 8, (B + 15) / 16, ndir);
         const int KS = H / 16;
         for (int s = 0; s < T; ++s) {

@@ -934,3 +934,25 @@ def test_dense_weight_gradient_bf16x6(ops, case):
         # fp32 accumulation of M terms (see test_dense_bf16x6_planes_and_products)
         assert e_s < 3e-5 and e_s < max(4 * max(e_f, 2e-6), 8 * 2.0 ** -24 * M ** 0.5), (name, e_s, e_f)
         close(db_s, dY64.sum(0), rtol=2e-4, atol=2e-3, what='db ' + name)
+
+
+def test_persistent_lstm_forward_equals_the_per_step_launches(ops, monkeypatch):
+    """csrc/lstm.hip, lstm_fwd_persistent_kernel (one launch for all T steps, h handed from workgroup to workgroup as
+    data-tagged sc1 granules; off by default because it measured slower than the per-step launches): same arithmetic in
+    the same order, so h, c and the gates must be BIT-identical to the per-step kernels -- both directions, a batch that is no
+    multiple of the 16-sample slice, and against the fp64 oracle."""
+    g = gen(13)
+    for (B, T, In, H) in ((64, 9, 12, 256), (20, 33, 8, 256)):
+        x = torch.randn(B, T, In, generator=g, dtype=torch.float64)
+        W = torch.randn(In, 8 * H, generator=g, dtype=torch.float64) / math.sqrt(In)
+        U = torch.randn(2, H, 4 * H, generator=g, dtype=torch.float64) / math.sqrt(H)
+        b = torch.randn(8 * H, generator=g, dtype=torch.float64) * 0.2
+        monkeypatch.delenv('PTTS_LSTM_PERSISTENT', raising=False)
+        with ops._hip.KernelTimer() as kt:
+            h_steps = ops.lstm(dev(x), dev(W), dev(U), dev(b))
+        monkeypatch.setenv('PTTS_LSTM_PERSISTENT', '1')
+        h_pers = ops.lstm(dev(x), dev(W), dev(U), dev(b))
+        monkeypatch.delenv('PTTS_LSTM_PERSISTENT', raising=False)
+        torch.cuda.synchronize()
+        assert torch.equal(h_pers, h_steps), float((h_pers - h_steps).abs().max())
+        close(h_pers, O.blstm(x, W, U, b), rtol=2e-4, atol=2e-5, what='h')
