@@ -84,6 +84,7 @@ __device__ __forceinline__ void split3(f32x4 v, bf16x4& h1, bf16x4& h2, bf16x4& 
     split3_pair(v[2], v[3], b1, b2, b3);
     h1 = __builtin_bit_cast(bf16x4, (u32x2){a1, b1}); h2 = __builtin_bit_cast(bf16x4, (u32x2){a2, b2}); h3 = __builtin_bit_cast(bf16x4, (u32x2){a3, b3});
 }
+__device__ __forceinline__ bf16x8 cat(bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
 // max(a, b) for finite operands in one instruction (fmaxf canonicalises its operands first)
 __device__ __forceinline__ float max_fast(float a, float b) {
     float r;
@@ -92,38 +93,41 @@ __device__ __forceinline__ float max_fast(float a, float b) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Toeplitz tables of a 5x5 4->4 kernel, three bf16 planes: tab[KT][NP][64 lanes][8].
+// Operand tables of a 5x5 4->4 kernel, three bf16 planes.  The MFMA A-operand fragment of kernel row kt is the banded block
 //   transposed == 0 (forward):        A[(so,co)][(j,ci)] = w[kt][j - so][ci][co]
 //   transposed == 1 (backward data):  A[(so,ci)][(j,co)] = w[KT-1-kt][KF-1-(j - so)][ci][co]   (dx = conv(dy, flipped w^T))
-// lane (li = lane & 15, lg = lane >> 4): m = li -> so = li >> 2, oc = li & 3; element e: j = 2 lg + (e >> 2), ic = e & 3.
+// lane (li = lane & 15, lg = lane >> 4): m = li -> so = li >> 2, oc = li & 3; element e: j = 2 lg + (e >> 2), ic = e & 3 --
+// i.e. the eight elements of a lane are TWO consecutive taps kf = 2 lg - so, + 1 of one (kt, oc) row, four ic each.  The
+// table therefore stores every (kt, plane, oc) row once, zero-padded to the taps -3 .. 7:
+//   tab[kt][plane][oc][kf + 3 (11 slots)][ic (4)]          (5280 bytes instead of 15 KB of per-lane fragments)
+// and a lane reads its fragment as 16 bytes at slot 2 lg - so + 3 (8-byte aligned).
 // One launch builds both tables: block 0 the forward one, block 1 the transposed one.
 // ------------------------------------------------------------------------------------------------------------
+constexpr int TSLOTS = 11;                       // taps -3 .. 7
+constexpr int TROW = TSLOTS * C;                 // elements of one (kt, plane, oc) row: 44
+constexpr int TKP = C * TROW;                    // elements per (kt, plane): 176
 __global__ void toeplitz_table_kernel(const float* __restrict__ w, u16* __restrict__ tab_fwd, u16* __restrict__ tab_bwd, int npl) {
     const int transposed = blockIdx.x;
     u16* tab = transposed ? tab_bwd : tab_fwd;
     if (!tab) return;
-    const int lane = threadIdx.x & 63, kt = threadIdx.x >> 6;
-    const int li = lane & 15, lg = lane >> 4, so = li >> 2, oc = li & 3;
-    if (kt >= KT) return;
-    f32x4 v[2];
+    // thread = (kt, oc, slot): four ic values
+    const int idx = threadIdx.x;
+    if (idx >= KT * C * TSLOTS) return;
+    const int slot = idx % TSLOTS, oc = (idx / TSLOTS) % C, kt = idx / (TSLOTS * C);
+    const int kf = slot - 3;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (kf >= 0 && kf < KF) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int j = 2 * lg + (e >> 2), ic = e & 3, kf = j - so;
-        float x = 0.f;
-        if (kf >= 0 && kf < KF)
-            x = transposed ? w[(((KT - 1 - kt) * KF + (KF - 1 - kf)) * C + oc) * C + ic] : w[((kt * KF + kf) * C + ic) * C + oc];
-        v[e >> 2][e & 3] = x;
+        for (int ic = 0; ic < C; ++ic)
+            v[ic] = transposed ? w[(((KT - 1 - kt) * KF + (KF - 1 - kf)) * C + oc) * C + ic] : w[((kt * KF + kf) * C + ic) * C + oc];
     }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        bf16x4 h1, h2, h3;
-        split3(v[h], h1, h2, h3);
-        u16* d = tab + ((size_t)(kt * npl) * 64 + lane) * 8 + 4 * h;
-        *reinterpret_cast<bf16x4*>(d) = h1;
-        if (npl == 3) {
-            *reinterpret_cast<bf16x4*>(d + 64 * 8) = h2;
-            *reinterpret_cast<bf16x4*>(d + 2 * 64 * 8) = h3;
-        }
+    bf16x4 h1, h2, h3;
+    split3(v, h1, h2, h3);
+    u16* d = tab + (kt * npl * C + oc) * TROW + slot * C;
+    *reinterpret_cast<bf16x4*>(d) = h1;
+    if (npl == 3) {
+        *reinterpret_cast<bf16x4*>(d + TKP) = h2;
+        *reinterpret_cast<bf16x4*>(d + 2 * TKP) = h3;
     }
 }
 
@@ -358,21 +362,31 @@ __device__ __forceinline__ void fwd_pass(const u16* __restrict__ planes, const u
     // unit of the lane in group g: 2 g + lg; groups two apart are four units (32 elements) apart
     const u16* b0 = planes + row_of_lane(li) * ST::RS + unit_pos(2 * g0 + lg) * 8;
     const u16* b1 = planes + row_of_lane(li) * ST::RS + unit_pos(2 * g0 + 2 + lg) * 8;
-    const u16* wa = wl + lane * 8;
+    const u16* wa = wl + (li & 3) * TROW + (2 * lg - (li >> 2) + 3) * C;      // row oc, slot of tap 2 lg - so
+    // fragments of kernel row kt: the table's (8-byte aligned: two 8-byte reads) and N x NPL of the activations.  The reads
+    // of row kt + 1 are issued before the MFMAs of row kt (two register sets): a wave does not sit out an LDS round trip
+    // per kernel row.
+    bf16x8 a[2][NPL], bq[2][N][NPL];
+    auto read_row = [&](int kt, bf16x8 (&ar)[NPL], bf16x8 (&br)[N][NPL]) {
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-        bf16x8 a[NPL], bq[N][NPL];
-#pragma unroll
-        for (int q = 0; q < NPL; ++q) a[q] = *reinterpret_cast<const bf16x8*>(wa + (kt * NPL + q) * 64 * 8);
+        for (int q = 0; q < NPL; ++q) {
+            const u16* wp = wa + (kt * NPL + q) * TKP;
+            ar[q] = cat(*reinterpret_cast<const bf16x4*>(wp), *reinterpret_cast<const bf16x4*>(wp + 4));
+        }
 #pragma unroll
         for (int j = 0; j < N; ++j)
 #pragma unroll
             for (int p = 0; p < NPL; ++p)
-                bq[j][p] = *reinterpret_cast<const bf16x8*>(((j & 1) ? b1 : b0) + p * ST::PS + kt * DIL * ST::RS + (j >> 1) * 32);
+                br[j][p] = *reinterpret_cast<const bf16x8*>(((j & 1) ? b1 : b0) + p * ST::PS + kt * DIL * ST::RS + (j >> 1) * 32);
+    };
+    read_row(0, a[0], bq[0]);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) read_row(kt + 1, a[(kt + 1) & 1], bq[(kt + 1) & 1]);
         // product-major: consecutive MFMAs go to different accumulators
 #define C2M_MM(PA, PW)                                                                                  \
         _Pragma("unroll") for (int j = 0; j < N; ++j)                                                   \
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PW < NPL ? PW : 0], bq[j][PA < NPL ? PA : 0], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kt & 1][PW < NPL ? PW : 0], bq[kt & 1][j][PA < NPL ? PA : 0], acc[j], 0, 0, 0);
         C2M_PRODUCTS_NPL(NPL, C2M_MM);
 #undef C2M_MM
     }
@@ -391,8 +405,46 @@ __device__ __forceinline__ void fwd_pass(const u16* __restrict__ planes, const u
     }
 }
 
-template <int DIL, int MODE, bool OUTMASK, int NPL>
-__global__ __launch_bounds__(THREADS, DIL == 1 ? 3 : (DIL == 2 ? 2 : 1)) void fwd_kernel(
+// the MFMA phase of one staged piece: the wave's share of its bin groups, a contiguous run, in passes of at most NMAX groups
+// of nearly equal size (register budget: a pass keeps N x 3 activation fragments).  The wave that takes the odd group
+// changes from piece to piece: the waves of a workgroup sit on different SIMDs.
+template <class ST, int DIL, bool OUTMASK, bool MASK, int NPL>
+__device__ __forceinline__ void fwd_piece(const u16* __restrict__ planes, const u16* __restrict__ wl, const TilePos& cur, const Shape& s,
+                                          int wave, int lane, int it, f32x4 bv, const void* __restrict__ out_mask, void* __restrict__ y,
+                                          bool out_bf16, float alpha, bool store, bool nomfma) {
+    const int per = cur.ng >> 2, rem = cur.ng & 3, wr = (wave + it) & 3;
+    int gl = wr * per + min(wr, rem);
+    int n = per + (wr < rem ? 1 : 0);
+    if (nomfma) n = 0;
+    constexpr int NMAX = (OUTMASK || MASK) ? 4 : 5;
+    int npass = (n + NMAX - 1) / NMAX;
+    const int t = cur.t0 + row_of_lane(lane & 15);
+    const bool rowok = t < s.T;
+    const long long rowoff = (cur.img + (long long)t * s.F) * C;
+    void* yrow = const_cast<void*>(ptr_at(y, rowoff, out_bf16));
+    const void* mrow = OUTMASK ? ptr_at(out_mask, rowoff, out_bf16) : nullptr;
+    const int fbase = 4 * cur.g_base;
+    while (n > 0) {
+        const int m = (n + npass - 1) / npass;
+#define C2M_PASS(NN) fwd_pass<ST, DIL, NN, OUTMASK, NPL>(planes, wl, gl, lane, bv, mrow, yrow, out_bf16, fbase, s.F, rowok, alpha, store)
+        switch (m) {
+            case 1: C2M_PASS(1); break;
+            case 2: C2M_PASS(2); break;
+            case 3: C2M_PASS(3); break;
+            case 4: C2M_PASS(4); break;
+            default: if (NMAX >= 5) C2M_PASS(NMAX >= 5 ? 5 : 4); break;
+        }
+#undef C2M_PASS
+        gl += m; n -= m; --npass;
+    }
+}
+
+// NBUF == 1: stage -> barrier -> multiply -> barrier per piece (the long stages of the dilated layers fill the LDS).
+// NBUF == 2 (dilation 1): the planes are double-buffered -- the piece i+1 is activated, split and written to the other
+// buffer by the same waves that multiply piece i, ONE barrier per piece, and the two workgroups of a CU (86 -> 76 KB of LDS
+// each with the compact table) drift against each other, so that one's vector work runs under the other's MFMAs.
+template <int DIL, int MODE, bool OUTMASK, int NPL, int NBUF>
+__global__ __launch_bounds__(THREADS, NBUF == 2 ? 2 : (DIL == 1 ? 3 : (DIL == 2 ? 2 : 1))) void fwd_kernel(
     const void* __restrict__ x, const u16* __restrict__ tab, const float* __restrict__ bias,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, const void* __restrict__ mask_src,
     const void* __restrict__ out_mask, void* __restrict__ y, int dt, Shape s, Sched sc, float alpha, int dbg, unsigned long long* dbg_buf) {
@@ -400,7 +452,7 @@ __global__ __launch_bounds__(THREADS, DIL == 1 ? 3 : (DIL == 2 ? 2 : 1)) void fw
     extern __shared__ __attribute__((aligned(16))) u16 lds[];
     stamp(dbg_buf, dbg, 0);
     u16* planes = lds;
-    u16* wl = lds + NPL * ST::PS;
+    u16* wl = lds + NBUF * NPL * ST::PS;
     const bool in_bf16 = NPL == 1 && (dt & DT_IN) != 0, out_bf16 = NPL == 1 && (dt & DT_OUT) != 0;   // three planes: fp32 maps
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -413,62 +465,82 @@ __global__ __launch_bounds__(THREADS, DIL == 1 ? 3 : (DIL == 2 ? 2 : 1)) void fw
     Work work = next_work(s, sc, wg, item, nitems);
     Pref<ST::NB, MASK> pf;
     TilePos pos = work_pos(s, work);
-    if (work.ng > 0 && !(dbg & DBG_NOSTAGE))
+    const bool stage = !(dbg & DBG_NOSTAGE), nomfma = (dbg & DBG_NOMFMA) != 0;
+    if (work.ng > 0 && stage)
         pref_load<ST, MASK>(pf, sl, x, mask_src, in_bf16, pos.img, pos.t0 - s.pad_t, 4 * pos.g_base - 2, s.T, s.F, s.F, 4 * pos.ng + 4);
     stamp(dbg_buf, dbg, 5);
-    // the table: KT*NPL KB, 16 bytes per lane and copy, once per workgroup
-    for (int i = tid; i < KT * NPL * 64; i += THREADS)
+    // the table: KT * NPL * 352 bytes, once per workgroup
+    for (int i = tid; i < KT * NPL * TKP / 8; i += THREADS)
         *reinterpret_cast<bf16x8*>(wl + (size_t)i * 8) = *reinterpret_cast<const bf16x8*>(tab + (size_t)i * 8);
     stamp(dbg_buf, dbg, 6);
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias) bv = *reinterpret_cast<const f32x4*>(bias);
     const bool store = !(dbg & DBG_NOSTORE);
-    const int myrow = row_of_lane(lane & 15);
     int it = 0;
-    while (work.ng > 0) {
-        if (!(dbg & DBG_NOSTAGE))
+    if (NBUF == 1) {
+        while (work.ng > 0) {
+            if (stage)
+                pref_commit<ST, MODE, NPL>(pf, sl, planes, pos.t0 - s.pad_t, 4 * pos.g_base - 2, s.T, s.F, in_scale, in_shift, alpha, 0, 0, nullptr);
+            if (it == 0) stamp(dbg_buf, dbg, 1);
+            __syncthreads();
+            if (it == 0) stamp(dbg_buf, dbg, 2);
+            const TilePos cur = pos;
+            work = next_work(s, sc, wg, item, nitems);
+            if (work.ng > 0) {
+                pos = work_pos(s, work);
+                if (stage)
+                    pref_load<ST, MASK>(pf, sl, x, mask_src, in_bf16, pos.img, pos.t0 - s.pad_t, 4 * pos.g_base - 2, s.T, s.F, s.F, 4 * pos.ng + 4);
+            }
+            fwd_piece<ST, DIL, OUTMASK, MASK, NPL>(planes, wl, cur, s, wave, lane, it, bv, out_mask, y, out_bf16, alpha, store, nomfma);
+            if (it == 0) stamp(dbg_buf, dbg, 3);
+            __syncthreads();       // the planes are free again
+            ++it;
+        }
+    } else {
+        // piece 0 into buffer 0, the loads of piece 1 in flight
+        if (work.ng > 0 && stage)
             pref_commit<ST, MODE, NPL>(pf, sl, planes, pos.t0 - s.pad_t, 4 * pos.g_base - 2, s.T, s.F, in_scale, in_shift, alpha, 0, 0, nullptr);
-        if (it == 0) stamp(dbg_buf, dbg, 1);
-        __syncthreads();
-        if (it == 0) stamp(dbg_buf, dbg, 2);
-        const TilePos cur = pos;
+        TilePos cur = pos;
+        bool have = work.ng > 0;
         work = next_work(s, sc, wg, item, nitems);
         if (work.ng > 0) {
             pos = work_pos(s, work);
-            if (!(dbg & DBG_NOSTAGE))
+            if (stage)
                 pref_load<ST, MASK>(pf, sl, x, mask_src, in_bf16, pos.img, pos.t0 - s.pad_t, 4 * pos.g_base - 2, s.T, s.F, s.F, 4 * pos.ng + 4);
         }
-        // the wave's share of the piece's bin groups: a contiguous run, in passes of at most NMAX groups of nearly equal
-        // size (register budget: a pass keeps N x 3 activation fragments)
-        // (the wave that takes the odd group changes from piece to piece: the waves of a workgroup sit on different SIMDs)
-        const int per = cur.ng >> 2, rem = cur.ng & 3, wr = (wave + it) & 3;
-        int gl = wr * per + min(wr, rem);
-        int n = per + (wr < rem ? 1 : 0);
-        if (dbg & DBG_NOMFMA) n = 0;
-        constexpr int NMAX = (OUTMASK || MASK) ? 4 : 5;
-        int npass = (n + NMAX - 1) / NMAX;
-        const int t = cur.t0 + myrow;
-        const bool rowok = t < s.T;
-        const long long rowoff = (cur.img + (long long)t * s.F) * C;
-        void* yrow = const_cast<void*>(ptr_at(y, rowoff, out_bf16));
-        const void* mrow = OUTMASK ? ptr_at(out_mask, rowoff, out_bf16) : nullptr;
-        const int fbase = 4 * cur.g_base;
-        while (n > 0) {
-            const int m = (n + npass - 1) / npass;
-#define C2M_PASS(NN) fwd_pass<ST, DIL, NN, OUTMASK, NPL>(planes, wl, gl, lane, bv, mrow, yrow, out_bf16, fbase, s.F, rowok, alpha, store)
-            switch (m) {
-                case 1: C2M_PASS(1); break;
-                case 2: C2M_PASS(2); break;
-                case 3: C2M_PASS(3); break;
-                case 4: C2M_PASS(4); break;
-                default: if (NMAX >= 5) C2M_PASS(NMAX >= 5 ? 5 : 4); break;
-            }
-#undef C2M_PASS
-            gl += m; n -= m; --npass;
+        stamp(dbg_buf, dbg, 1);
+        __syncthreads();
+        stamp(dbg_buf, dbg, 2);
+        const bool late = ((blockIdx.x >> 8) & 1) != 0;
+        while (have) {
+            const u16* pcur = planes + (it & 1) * NPL * ST::PS;
+            u16* pnxt = planes + ((it + 1) & 1) * NPL * ST::PS;
+            const bool more = work.ng > 0;
+            const TilePos nxt = pos;
+            // the next piece: registers -> the other buffer (every wave left it at the last barrier), then the loads of the piece
+            // after.  The two workgroups of a CU (blockIdx i and i + 256 where the dispatcher fills the CUs round-robin) start
+            // together and would stay in lockstep -- vector phases together, then matrix phases together: one of them stages
+            // BEFORE its MFMAs, the other AFTER.
+            auto stage_next = [&]() {
+                if (more && stage)
+                    pref_commit<ST, MODE, NPL>(pf, sl, pnxt, nxt.t0 - s.pad_t, 4 * nxt.g_base - 2, s.T, s.F, in_scale, in_shift, alpha, 0, 0, nullptr);
+                if (more) {
+                    work = next_work(s, sc, wg, item, nitems);
+                    if (work.ng > 0) {
+                        pos = work_pos(s, work);
+                        if (stage)
+                            pref_load<ST, MASK>(pf, sl, x, mask_src, in_bf16, pos.img, pos.t0 - s.pad_t, 4 * pos.g_base - 2, s.T, s.F, s.F, 4 * pos.ng + 4);
+                    }
+                }
+            };
+            if (!late) stage_next();
+            fwd_piece<ST, DIL, OUTMASK, MASK, NPL>(pcur, wl, cur, s, wave, lane, it, bv, out_mask, y, out_bf16, alpha, store, nomfma);
+            if (late) stage_next();
+            if (it == 0) stamp(dbg_buf, dbg, 3);
+            __syncthreads();
+            cur = nxt; have = more;
+            ++it;
         }
-        if (it == 0) stamp(dbg_buf, dbg, 3);
-        __syncthreads();       // the planes are free again
-        ++it;
     }
     stamp(dbg_buf, dbg, 4);
 }
@@ -490,7 +562,6 @@ __device__ __forceinline__ bf16x4 tr_read(const u16* p) {
     // columns 4p..4p+3 lane 4q+p of the group points at (EXEC must be full: every caller is wave-uniform)
     return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p)));
 }
-__device__ __forceinline__ bf16x8 cat(bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
 
 template <int DIL, int MODE, int NPL>
 __global__ __launch_bounds__(THREADS, DIL <= 2 ? 2 : 1) void wgrad_kernel(
@@ -636,7 +707,7 @@ extern "C" int ptts_conv2d_mfma_debug(int flags, void* stamp_buf) {
     return PTTS_OK;
 }
 
-extern "C" size_t ptts_conv2d_mfma_table_bytes(int KT_) { return (size_t)KT_ * NP * 64 * 8 * sizeof(u16); }
+extern "C" size_t ptts_conv2d_mfma_table_bytes(int KT_) { return (size_t)KT_ * NP * TKP * sizeof(u16); }
 
 // planes: 3 = fp32 arithmetic (three-way split), 1 = bf16 arithmetic (the kernel rounded to bf16: the "weights copy in bf16")
 extern "C" int ptts_conv2d_mfma_tables(const float* w, void* table_fwd, void* table_bwd, int KT_, int KF_, int Cin, int Cout,
@@ -644,7 +715,7 @@ extern "C" int ptts_conv2d_mfma_tables(const float* w, void* table_fwd, void* ta
     PTTS_REQUIRE(w && (table_fwd || table_bwd), "conv2d_mfma_tables: null pointer");
     PTTS_REQUIRE(KT_ == 5 && KF_ == 5 && Cin == 4 && Cout == 4, "conv2d_mfma_tables: only 5x5, 4 -> 4 channels (got %dx%d, %d -> %d)", KT_, KF_, Cin, Cout);
     PTTS_REQUIRE(planes == 1 || planes == 3, "conv2d_mfma_tables: planes must be 1 (bf16) or 3 (fp32 split), got %d", planes);
-    hipLaunchKernelGGL(toeplitz_table_kernel, dim3(2), dim3(64 * KT), 0, (hipStream_t)stream, w, (u16*)table_fwd, (u16*)table_bwd, planes);
+    hipLaunchKernelGGL(toeplitz_table_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, w, (u16*)table_fwd, (u16*)table_bwd, planes);
     return check_launch("conv2d_mfma_tables");
 }
 
@@ -667,7 +738,16 @@ Shape make_shape(int B, int T, int F, int pad_t) {
 }
 bool shape_ok(const Shape& s) { return s.ntiles > 0 && s.ntiles < (1 << 20) && s.nfb < 4096 && s.ntt < 4096; }
 
-template <int DIL, int NPL> constexpr size_t lds_fwd() { return ((size_t)NPL * Stage<4 * GPB + 4, 16 + (KT - 1) * DIL>::PS + (size_t)KT * NPL * 64 * 8) * sizeof(u16); }
+// stage buffers of the dilation-1 forward kernel: 2 (the default: two workgroups per CU, one barrier per piece) or 1
+// (PTTS_C2M_DOUBLE=0: three per CU).  Launched back to back the two forms take the same time per layer (20-22 us); inside
+// the critic step, where the three evaluations run on three streams, the double-buffered form leaves a third of the
+// register file to the other streams' kernels and the step is 3 % shorter (7.00 against 7.23 ms, same box).
+bool fwd_double_buffered() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PTTS_C2M_DOUBLE"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
+template <int DIL, int NPL, int NB> constexpr size_t lds_fwd() { return ((size_t)NB * NPL * Stage<4 * GPB + 4, 16 + (KT - 1) * DIL>::PS + (size_t)KT * NPL * TKP) * sizeof(u16); }
 template <int DIL, int NPL> constexpr size_t lds_wgrad() {
     const size_t planes = (size_t)NPL * (Stage<4 * (GPB + 1) + 4, 16 + (KT - 1) * DIL>::PS + Stage<4 * (GPB + 1) + 4, 16>::PS) * sizeof(u16);
     const size_t red = (size_t)(4 * KT * 2 * 4 * 64 + THREADS * 4) * sizeof(float);
@@ -730,16 +810,18 @@ extern "C" int ptts_conv2d_mfma_fwd(const void* x, const void* table, const floa
     hipStream_t st = (hipStream_t)stream;
     const bool om = out_mask != nullptr;
     const int dt = (in_bf16 ? DT_IN : 0) | (out_bf16 ? DT_OUT : 0);
-#define C2M_L(DIL, MODE, OM, NPL)                                                                                        \
+#define C2M_LB(DIL, MODE, OM, NPL, NB)                                                                                   \
     do {                                                                                                                 \
-        constexpr size_t lds = lds_fwd<DIL, NPL>();                                                                      \
+        constexpr size_t lds = lds_fwd<DIL, NPL, NB>();                                                                  \
         static_assert(lds <= LDS_MAX, "tile does not fit the LDS");                                                      \
         static bool attr = false;                                                                                        \
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_kernel<DIL, MODE, OM, NPL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX); attr = true; } \
-        const Sched sc = sched_for(s.ntiles, lds, DIL == 1 ? 3 : (DIL == 2 ? 2 : 1), 1);                                 \
-        hipLaunchKernelGGL((fwd_kernel<DIL, MODE, OM, NPL>), dim3(sc.G), dim3(THREADS), lds, st, x, (const u16*)table, bias, \
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_kernel<DIL, MODE, OM, NPL, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX); attr = true; } \
+        const Sched sc = sched_for(s.ntiles, lds, NB == 2 ? 2 : (DIL == 1 ? 3 : (DIL == 2 ? 2 : 1)), 1);                  \
+        hipLaunchKernelGGL((fwd_kernel<DIL, MODE, OM, NPL, NB>), dim3(sc.G), dim3(THREADS), lds, st, x, (const u16*)table, bias, \
                            in_scale, in_shift, mask_src, out_mask, y, dt, s, sc, alpha, g_dbg, g_dbg_buf);               \
     } while (0)
+#define C2M_L(DIL, MODE, OM, NPL)                                                                                        \
+    do { if (DIL == 1 && fwd_double_buffered()) C2M_LB(1, MODE, OM, NPL, 2); else C2M_LB(DIL, MODE, OM, NPL, 1); } while (0)
 #define C2M_M(DIL, NPL)                                                                                                  \
     do {                                                                                                                 \
         if (in_mode == PTTS_IN_LRELU) { if (om) C2M_L(DIL, PTTS_IN_LRELU, true, NPL); else C2M_L(DIL, PTTS_IN_LRELU, false, NPL); } \

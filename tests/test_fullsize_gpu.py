@@ -195,7 +195,7 @@ def test_grouped_weight_gradients_equal_per_layer_products(setup):
             total.backward()
     assert not ops._Deferred.items
     grouped = [tag[0] for (name, tag, _) in kt.durations_ms() if name == 'ptts_gemm_wgrad_grouped']
-    split = [1 for (name, tag, _) in kt.durations_ms() if name == 'ptts_dense_wgrad_bf16x6']     # the bf16x6 kernel takes its products one by one
+    split = [1 for (name, tag, _) in kt.durations_ms() if name == 'ptts_dense_wgrad_bf16x6_partials']     # the split kernel: one launch per product, grouped reduce
     assert sum(grouped) + sum(split) >= 8             # the critic's Dense layers, first and second order
     assert not any(name == 'ptts_gemm' and tag[3] == 1 and tag[1] > 4 and tag[5] == 0 for (name, tag, _) in kt.durations_ms())
     torch.cuda.synchronize()

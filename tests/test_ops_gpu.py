@@ -108,35 +108,46 @@ def test_conv2d_forward_backward(ops, case, mode):
 
 
 def test_conv2d_mfma_tables_are_the_split_of_the_toeplitz_blocks(ops):
-    """csrc/conv2d_mfma.hip: the operand tables of a 5x5 4->4 kernel -- per kernel row the banded block
+    """csrc/conv2d_mfma.hip: the operand tables of a 5x5 4->4 kernel.  Per kernel row the MFMA A operand is the banded block
     A[(so,co)][(j,ci)] = w[kt][j-so][ci][co] (forward) resp. w[4-kt][4-(j-so)][ci][co] with the channel roles swapped
-    (backward data) -- hold the three bf16 planes of oracle.np_split3_bf16, bit for bit, in the lane layout
-    [kt][plane][lane = 16 lg + li][e]: m = li -> (so, oc), k = 8 lg + e -> (j = 2 lg + e // 4, ic = e % 4).  The same device
-    function (split3) splits the activations on their way into the LDS, where they cannot be read back."""
+    (backward data); lane (li, lg) holds m = li -> (so, oc), k = 8 lg + e -> (j = 2 lg + e // 4, ic = e % 4), i.e. two
+    consecutive taps kf = 2 lg - so, + 1 of the (kt, oc) row.  The table stores every row once, zero-padded to the taps -3..7:
+    tab[kt][plane][oc][kf + 3][ic].  Checked here: the planes are oracle.np_split3_bf16 of that, bit for bit, and the
+    fragment every lane reads out of it (16 bytes at slot 2 lg - so + 3) is the Toeplitz block.  The same device function
+    (split3) splits the activations on their way into the LDS, where they cannot be read back."""
     from percivaltts_amd.ops import call, ptr, stream
     g = gen(51)
     w = (torch.randn(5, 5, 4, 4, generator=g) * torch.exp(2 * torch.randn(5, 5, 4, 4, generator=g))).float()
     nb = ops._hip.lib().ptts_conv2d_mfma_table_bytes(5)
-    assert nb == 5 * 3 * 64 * 8 * 2
+    assert nb == 5 * 3 * 4 * 11 * 4 * 2
     tf = torch.zeros(nb, dtype=torch.uint8, device='cuda'); tb = torch.zeros(nb, dtype=torch.uint8, device='cuda')
     call('ptts_conv2d_mfma_tables', ptr(w.cuda()), ptr(tf), ptr(tb), 5, 5, 4, 4, 3, stream())
     wn = w.numpy()
     for tab, transposed in ((tf, False), (tb, True)):
-        got = tab.view(torch.bfloat16).float().cpu().numpy().reshape(5, 3, 64, 8)
-        want = O.np.zeros((5, 64, 8), dtype=O.np.float32)
+        got = tab.view(torch.bfloat16).float().cpu().numpy().reshape(5, 3, 4, 11, 4)          # [kt][plane][oc][slot][ic]
+        rows = O.np.zeros((5, 4, 11, 4), dtype=O.np.float32)
+        for kt in range(5):
+            for oc in range(4):
+                for kf in range(5):
+                    for ic in range(4):
+                        rows[kt, oc, kf + 3, ic] = wn[4 - kt, 4 - kf, oc, ic] if transposed else wn[kt, kf, ic, oc]
+        planes = O.np_split3_bf16(rows)
+        for p in range(3):
+            assert (got[:, p] == planes[p]).all(), 'plane {} of the {} table'.format(p, 'transposed' if transposed else 'forward')
+        assert (got.sum(1) == rows).all()
+        # the fragment of lane (li, lg): elements e = 0..7 at slot 2 lg - so + 3 + e // 4
         for kt in range(5):
             for lane in range(64):
                 li, lg = lane & 15, lane >> 4
                 so, oc = li >> 2, li & 3
+                frag = got.sum(1)[kt, oc].reshape(-1)[(2 * lg - so + 3) * 4:(2 * lg - so + 3) * 4 + 8]
                 for e in range(8):
                     j, ic = 2 * lg + e // 4, e % 4
                     kf = j - so
+                    want = 0.0
                     if 0 <= kf < 5:
-                        want[kt, lane, e] = wn[4 - kt, 4 - kf, oc, ic] if transposed else wn[kt, kf, ic, oc]
-        planes = O.np_split3_bf16(want)
-        for p in range(3):
-            assert (got[:, p] == planes[p]).all(), 'plane {} of the {} table'.format(p, 'transposed' if transposed else 'forward')
-        assert (got.sum(1) == want).all()
+                        want = wn[4 - kt, 4 - kf, oc, ic] if transposed else wn[kt, kf, ic, oc]
+                    assert frag[e] == want, (kt, lane, e)
 
 
 @pytest.mark.parametrize('case', [
