@@ -90,7 +90,7 @@ struct DenseArgs {
     int M, N, K, NT, KS;
     long long lda, ldc;
     float alpha, out_alpha;
-    int accumulate, has_affine;
+    int accumulate, has_affine, vec_out;
 };
 
 template <int MODE, bool AFFINE, int MT>
@@ -225,6 +225,27 @@ __global__ __launch_bounds__(THREADS) void dense_bf16x6_kernel(DenseArgs g) {
     if (!wave_live) return;
     // ---- store: lane (li, lg) of acc[i][j] holds row m0 + 16 i + li, columns n0 + 32 wave + 16 j + 4 lg .. + 3
     const bool interior = m0 + TBM <= g.M;                    // no row guards: the mask / old-value loads go out together
+    if (!g.vec_out) {
+        // N or ldc no multiple of 4 (the 65-bin spectral head): element-wise stores
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int m = m0 + 16 * i + li;
+                if (m >= g.M) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = n0 + 32 * wave + 16 * j + 4 * lg + e;
+                    if (n >= g.N) continue;
+                    const long long off = (long long)m * g.ldc + n;
+                    float v = acc[i][j][e] + (g.bias ? g.bias[n] : 0.f);
+                    if (g.out_mask) v *= g.out_mask[off] > 0.f ? 1.f : g.out_alpha;
+                    if (g.accumulate) v += g.C[off];
+                    g.C[off] = v;
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + 32 * wave + 16 * j + 4 * lg;
@@ -551,7 +572,8 @@ extern "C" int ptts_split3_dense_weight(const float* w, long long ldw, int K, in
 
 // 1 when ptts_dense_bf16x6 takes the shape
 extern "C" int ptts_dense_bf16x6_supported(int M, int N, int K, long long lda, long long ldc) {
-    return (M > 0 && N > 0 && K > 0 && N % 4 == 0 && K % 4 == 0 && lda % 4 == 0 && ldc % 4 == 0 && K <= 65536 &&
+    (void)ldc;                                    // any N / ldc: rows that are no multiple of 4 floats are stored element-wise
+    return (M > 0 && N > 0 && K > 0 && K % 4 == 0 && lda % 4 == 0 && K <= 65536 &&
             (long long)((N + NBLK - 1) / NBLK) <= 65535) ? 1 : 0;
 }
 
@@ -561,7 +583,7 @@ extern "C" int ptts_dense_bf16x6(const float* A, const void* planes, const float
                                  long long lda, long long ldc, int in_mode, const float* in_scale, const float* in_shift,
                                  const float* mask_src, float alpha, int accumulate, const float* out_mask, void* stream) {
     PTTS_REQUIRE(A && planes && C, "dense_bf16x6: null matrix");
-    PTTS_REQUIRE(ptts_dense_bf16x6_supported(M, N, K, lda, ldc), "dense_bf16x6: unsupported shape M=%d N=%d K=%d lda=%lld ldc=%lld (N, K, lda, ldc must be multiples of 4)", M, N, K, lda, ldc);
+    PTTS_REQUIRE(ptts_dense_bf16x6_supported(M, N, K, lda, ldc), "dense_bf16x6: unsupported shape M=%d N=%d K=%d lda=%lld ldc=%lld (K and lda must be multiples of 4)", M, N, K, lda, ldc);
     PTTS_REQUIRE(lda >= K && ldc >= N, "dense_bf16x6: bad leading dims");
     PTTS_REQUIRE(in_mode >= 0 && in_mode <= 2, "dense_bf16x6: bad in_mode %d", in_mode);
     PTTS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "dense_bf16x6: scale/shift must come together");
@@ -569,14 +591,15 @@ extern "C" int ptts_dense_bf16x6(const float* A, const void* planes, const float
     PTTS_REQUIRE(in_mode == PTTS_IN_LRELU || !in_scale, "dense_bf16x6: scale/shift need PTTS_IN_LRELU");
     PTTS_REQUIRE(!(out_mask && bias), "dense_bf16x6: out_mask with bias is not defined");
     PTTS_REQUIRE(alpha >= 0.f && alpha <= 1.f, "dense_bf16x6: LeakyReLU slope %g outside [0, 1]", alpha);
-    PTTS_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)C & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0) &&
-                 (!out_mask || ((uintptr_t)out_mask & 15) == 0) && (!mask_src || ((uintptr_t)mask_src & 15) == 0) &&
-                 (!in_scale || (((uintptr_t)in_scale | (uintptr_t)in_shift) & 15) == 0), "dense_bf16x6: operands must be 16-byte aligned");
+    const bool vec_out = N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0) &&
+                         (!out_mask || ((uintptr_t)out_mask & 15) == 0);
+    PTTS_REQUIRE(((uintptr_t)A & 15) == 0 && (!mask_src || ((uintptr_t)mask_src & 15) == 0) &&
+                 (!in_scale || (((uintptr_t)in_scale | (uintptr_t)in_shift) & 15) == 0), "dense_bf16x6: A, its mask and scale/shift must be 16-byte aligned");
     DenseArgs g;
     g.A = A; g.mask_src = mask_src; g.in_scale = in_scale; g.in_shift = in_shift; g.planes = (const u16*)planes; g.bias = bias;
     g.out_mask = out_mask; g.C = C; g.M = M; g.N = N; g.K = K;
     g.NT = (N + NBLK - 1) / NBLK * (NBLK / 16); g.KS = (K + BK - 1) / BK;
-    g.lda = lda; g.ldc = ldc; g.alpha = alpha; g.out_alpha = alpha; g.accumulate = accumulate; g.has_affine = in_scale != nullptr;
+    g.lda = lda; g.ldc = ldc; g.alpha = alpha; g.out_alpha = alpha; g.accumulate = accumulate; g.has_affine = in_scale != nullptr; g.vec_out = vec_out;
     const int cb = (N + NBLK - 1) / NBLK;
     const int mt = pick_mt(M, cb);
     const dim3 grid((unsigned)((M + 16 * mt - 1) / (16 * mt)), (unsigned)cb);

@@ -488,10 +488,12 @@ class _DenseSplit(object):
         return ent[3]
 
     @classmethod
-    def eligible(cls, A, C, M, N, K, lda, ldc, others):
-        if not (cls.enabled and M >= 1024 and N >= 16 and K >= 16 and N % 4 == 0 and K % 4 == 0 and lda % 4 == 0 and ldc % 4 == 0):
+    def eligible(cls, A, C, M, N, K, lda, ldc, in_side):
+        """in_side: the tensors read beside A in 16-byte pieces (mask_src, scale, shift); C, bias and out_mask may be
+        unaligned or N / ldc no multiple of 4 (the 65-bin spectral head): the kernel then stores element-wise."""
+        if not (cls.enabled and M >= 1024 and N >= 16 and K >= 16 and K % 4 == 0 and lda % 4 == 0):
             return False
-        return all(t is None or t.data_ptr() % 16 == 0 for t in (A, C) + tuple(others))
+        return all(t is None or t.data_ptr() % 16 == 0 for t in (A,) + tuple(in_side))
 
 
 def dense_split(on):
@@ -535,7 +537,7 @@ def gemm_raw(A, Bm, C, M, N, K, transA=0, lda=None, rows_per_seg=None, seg_strid
         # M >> N products against a weight: the bf16x6 split kernel; a few columns beyond a multiple of 256 (the 260-wide
         # spectral part) go to the thin fp32 kernel
         N1 = N if (N <= 256 or N % 256 == 0 or N % 256 > 32) else N - N % 256
-        if _DenseSplit.eligible(A, C, M, N1, K, lda, ldc, (bias, scale, shift, mask_src, out_mask)):
+        if _DenseSplit.eligible(A, C, M, N1, K, lda, ldc, (scale, shift, mask_src)):
             planes = _DenseSplit.get(Bm, K, N1, ldb, transB)
             if planes is not None:
                 call('ptts_dense_bf16x6', ptr(A), ptr(planes), ptr(bias), ptr(C), M, N1, K, lda, ldc, mode, ptr(scale), ptr(shift),

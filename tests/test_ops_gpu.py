@@ -822,12 +822,13 @@ def test_cpu_tensor_is_refused(ops):
 
 
 @pytest.mark.parametrize('case', [(2048, 256, 256, 0), (1500, 260, 256, 1), (1024, 64, 100, 0), (1100, 2048, 256, 0), (1024, 20, 256, 0),
-                                  (1200, 256, 2048, 1)])
+                                  (1200, 256, 2048, 1), (1111, 65, 256, 0), (1030, 70, 64, 1)])
 def test_dense_bf16x6_planes_and_products(ops, case):
     """csrc/dense.hip: (i) the fragment-ordered weight planes BIT FOR BIT against oracle.np_split3_bf16; (ii) forward
     (LeakyReLU / BatchNorm-affine on load, bias), backward-data (W^T, output mask) and the masked forward of the second-order
     sweep against the fp64 oracle at the tolerance of the fp32-MFMA kernel, and A/B against that kernel.  Cases: the critic's
-    shape, a 260-wide output (256 + thin remainder), ragged K, the LSTM projection width, a narrow head, a deep K."""
+    shape, a 260-wide output (256 + thin remainder), ragged K, the LSTM projection width, a narrow head, a deep K, and widths that
+    are no multiples of 4 (the 65-bin spectral head: element-wise stores)."""
     import ctypes
     M, N, K, transposed = case
     g = gen(77)
