@@ -335,7 +335,7 @@ __device__ __forceinline__ void pref_commit(const Pref<ST::NB, MODE == PTTS_IN_M
 // ------------------------------------------------------------------------------------------------------------
 // forward / masked forward / backward data.  Persistent workgroups (256 threads) walk the tiles blockIdx.x, + gridDim.x,
 // ...: the Toeplitz table is fetched once per workgroup and the global loads of tile i+1 are in flight (registers) while
-// tile i is multiplied.  LDS: planes [NP][ROWS][RS] | table [KT][NP][64][8]
+// tile i is multiplied.  LDS: planes [NBUF][NP][ROWS][RS] | operand table [KT][NP][oc][11 taps][ic]
 // out = bias + conv(transform(x)) ; OUTMASK: out *= (out_mask > 0 ? 1 : alpha)
 // ------------------------------------------------------------------------------------------------------------
 // one pass of a wave over N consecutive bin groups g0 .. g0+N-1 of the staged block: straight-line code (a branch around

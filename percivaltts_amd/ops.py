@@ -262,7 +262,7 @@ class _C2M(object):
     """The 4 -> 4 channel 5x5 Conv2D layers on the bf16 matrix cores (csrc/conv2d_mfma.hip): fp32 arithmetic by the
     three-way bf16 split of both operands (six products, fp32 accumulation), like the context Conv1D's split kernels.
     PTTS_CONV2D_MFMA=0 or conv2d_mfma(False) select the packed-FMA stencil of csrc/conv2d.hip.  The Toeplitz tables of a
-    kernel (forward and transposed, 15 KB each) are rebuilt when the kernel changes (tensor version / flat-buffer epoch)."""
+    kernel (forward and transposed, 5.3 KB each) are rebuilt when the kernel changes (tensor version / flat-buffer epoch)."""
     default = os.environ.get('PTTS_CONV2D_MFMA', '1') == '1'
     enabled = default
     tables = {}         # (id(w), stream) -> (w, version, epoch, fwd table, bwd table)
