@@ -96,6 +96,46 @@ def test_conv2d_full_size_against_oracle_crops_and_linearity():
     close(br_.grad, db64, 2e-4, 1e-4 * float(db64.abs().mean()), 'conv2d db, full size')
 
 
+def test_dense_split_products_full_size():
+    """The DEFAULT Dense path at BASELINE size (csrc/dense.hip: bf16x6 split products against a weight of a flat parameter
+    buffer; the test below exercises the fp32-MFMA kernel, which plain tensors select): forward with LeakyReLU + bias and
+    backward-data with the output mask on rows at the 112-row workgroup borders against the fp64 oracle, linearity, and the
+    two-stage weight gradient + bias gradient of all 25 600 frames against an fp64 product."""
+    from percivaltts_amd import ops, layers, _hip
+    g = torch.Generator().manual_seed(21)
+    M, K, N = B * T, 256, 256
+    A1 = torch.randn(M, K, generator=g).cuda(); A2 = torch.randn(M, K, generator=g).cuda()
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.randn(K, N, generator=g) / 16)
+    h = Holder(); layers.FlatParams(h, 'cuda'); W = h.w
+    bias = torch.randn(N, generator=g).cuda()
+    C1 = torch.empty(M, N, device='cuda'); C2 = torch.empty(M, N, device='cuda'); C3 = torch.empty(M, N, device='cuda')
+    with _hip.KernelTimer() as kt:
+        ops.gemm_raw(A1, W, C1, M, N, K, bias=bias, mode=ops.IN_LRELU)
+    assert [r[0] for r in kt.records] == ['ptts_split3_dense_weight', 'ptts_dense_bf16x6'], [r[0] for r in kt.records]
+    rows = torch.tensor([0, 1, 111, 112, 113, 12799, 25487, 25599])      # tile borders of the 112-row workgroups
+    W64 = W.detach().double().cpu()
+    close(C1[rows], O.lrelu(A1[rows].double().cpu()) @ W64 + bias.double().cpu(), 2e-4, 2e-4, 'dense rows')
+    ops.gemm_raw(A1, W, C1, M, N, K); ops.gemm_raw(A2, W, C2, M, N, K); ops.gemm_raw(0.5 * A1 + 3 * A2, W, C3, M, N, K)
+    assert rel_l2(C3, 0.5 * C1 + 3 * C2) < 2e-6
+    # backward data: dX = (dY . W^T) * lrelu'(x), the mask in the epilogue
+    dY = torch.randn(M, N, generator=g).cuda(); Xm = torch.randn(M, K, generator=g).cuda()
+    dX = torch.empty(M, K, device='cuda')
+    ops.gemm_raw(dY, W, dX, M, K, N, transB=1, ldb=N, alpha=0.3, out_mask=Xm)
+    want = (dY[rows].double().cpu() @ W64.t()) * torch.where(Xm[rows].double().cpu() > 0, 1.0, 0.3)
+    close(dX[rows], want, 2e-4, 2e-4, 'dense backward-data rows')
+    # weight gradient over all frames (two stages: partial tiles, grouped reduce) and the bias gradient
+    dW = torch.empty(K, N, device='cuda'); db = torch.empty(N, device='cuda')
+    with _hip.KernelTimer() as kt:
+        ops.gemm_raw(A1, dY, dW, K, N, M, transA=1, lda=K, rows_per_seg=M, mode=ops.IN_LRELU, alpha=0.3, colsum_b=db)
+    assert 'ptts_dense_wgrad_bf16x6' in [r[0] for r in kt.records]
+    ref = O.lrelu(A1.double().cpu()).t() @ dY.double().cpu()
+    assert float((dW.double().cpu() - ref).abs().max()) < 3e-5 * float(ref.abs().mean()), float((dW.double().cpu() - ref).abs().max() / ref.abs().mean())
+    close(db, dY.double().cpu().sum(0), 2e-4, 2e-3, 'dense db, full size')
+
+
 def test_gemm_full_size_rows_and_linearity():
     from percivaltts_amd import ops
     g = torch.Generator().manual_seed(2)
