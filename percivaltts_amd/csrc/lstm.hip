@@ -389,11 +389,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_pk_kernel(
     gp[ej] = gi; gp[H + ej] = gf; gp[2 * H + ej] = gc; gp[3 * H + ej] = go;
 }
 
-__global__ __launch_bounds__(256) void lstm_bwd_step_pk_kernel(
+template <int NW>   // waves per workgroup: 4, or 8 (H = 256: the K = 4H reduction over eight waves -- half the dependent MFMA chain and
+                    // half the load rounds per wave of this latency-bound step)
+__global__ __launch_bounds__(64 * NW) void lstm_bwd_step_pk_kernel(
     const float* __restrict__ dh_out, const float* __restrict__ UTpk, const float* __restrict__ gates,
     const float* __restrict__ c_out, float* __restrict__ dgates, float* __restrict__ dc_state, int B, int T,
     int H, int ndir, int reverse, int s) {
-    __shared__ float red[4][256];
+    __shared__ float red[NW][256];
     const int d = blockIdx.z;
     const bool rev = ndir == 2 ? d == 1 : reverse != 0;
     const int t = rev ? T - 1 - s : s;
@@ -401,14 +403,15 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_pk_kernel(
     const int tn = rev ? t - 1 : t + 1;
     const int jt = blockIdx.x, j0 = jt * 16, b0 = blockIdx.y * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gate = wave & 3, part = wave >> 2;            // NW == 8: the two halves of a gate's quarter rows
     const int r16 = lane & 15, q = lane >> 4;
     const long long G4 = 4LL * H, HH = (long long)ndir * H;
     const bool has_next = s < T - 1;
-    const int NS = H / 4;
+    const int NS = H / 4, NSW = NS / (NW / 4);
     // epilogue inputs first
     const int bb = tid >> 4, jj = tid & 15;
     const int eb = b0 + bb, ej = j0 + jj;
-    const bool epi = eb < B;
+    const bool epi = tid < 256 && eb < B;
     float dh = 0.f, gi = 0.f, gf = 0.f, gc = 0.f, go = 0.f, c = 0.f, cp = 0.f, dcs = 0.f;
     const long long si = ((long long)d * B + eb) * H + ej;
     if (epi) {
@@ -421,10 +424,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_pk_kernel(
     }
     if (has_next) {
         const int b = b0 + r16;
-        const float* ap = dgates + (((long long)(b < B ? b : 0) * T + tn) * ndir + d) * G4 + wave * H + q * NS;
-        const float* bp = UTpk + ((((long long)d * (H / 16) + jt) * 4 + wave) * 64 + lane) * NS;
+        const float* ap = dgates + (((long long)(b < B ? b : 0) * T + tn) * ndir + d) * G4 + gate * H + q * NS + part * NSW;
+        const float* bp = UTpk + ((((long long)d * (H / 16) + jt) * 4 + gate) * 64 + lane) * NS + part * NSW;
         f32x4v acc = {0.f, 0.f, 0.f, 0.f};
-        for (int s0 = 0; s0 < NS; s0 += 16) {
+        for (int s0 = 0; s0 < NSW; s0 += 16) {
             f32x4a av[4], bv[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -440,7 +443,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_pk_kernel(
         __syncthreads();
     }
     if (!epi) return;
-    if (has_next) dh += red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    if (has_next) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) dh += red[w][tid];
+    }
     const float tc = tanhf(c);
     float dc = dh * go * (1.f - tc * tc);
     if (has_next) dc += dcs;
@@ -639,6 +645,12 @@ extern "C" int ptts_lstm_fwd(const float* xproj, const float* U, float* h_out, f
     return check_launch("lstm_fwd");
 }
 
+static int lstm_bwd_waves() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PTTS_LSTM_BWD_WAVES"); v = e ? atoi(e) : 8; }
+    return v;
+}
+
 extern "C" size_t ptts_lstm_bwd_workspace_bytes(int B, int T, int H, int ndir) {
     (void)T;
     return ((size_t)2 * ndir * 4 * H * H + (size_t)ndir * B * H) * sizeof(float);
@@ -663,8 +675,12 @@ extern "C" int ptts_lstm_bwd(const float* dh_out, const float* U, const float* g
         hipLaunchKernelGGL(lstm_pack_u_bwd_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, U, UTpk, H, ndir);
         dim3 pgrid(H / 16, (B + 15) / 16, ndir);
         for (int s = T - 1; s >= 0; --s)
-            hipLaunchKernelGGL(lstm_bwd_step_pk_kernel, pgrid, dim3(256), 0, (hipStream_t)stream, dh_out,
-                               (const float*)UTpk, gates, c_out, dgates, dc_state, B, T, H, ndir, reverse, s);
+            if (H == 256 && lstm_bwd_waves() == 8)
+                hipLaunchKernelGGL(lstm_bwd_step_pk_kernel<8>, pgrid, dim3(512), 0, (hipStream_t)stream, dh_out,
+                                   (const float*)UTpk, gates, c_out, dgates, dc_state, B, T, H, ndir, reverse, s);
+            else
+                hipLaunchKernelGGL(lstm_bwd_step_pk_kernel<4>, pgrid, dim3(256), 0, (hipStream_t)stream, dh_out,
+                                   (const float*)UTpk, gates, c_out, dgates, dc_state, B, T, H, ndir, reverse, s);
         return check_launch("lstm_bwd_pk");
     }
     const long long tot = (long long)ndir * 4 * H * H;
