@@ -145,6 +145,42 @@ int ptts_conv2d_mfma_wgrad_partials(const void* dy, const void* x, const void* m
 int ptts_conv2d_mfma_debug(int flags, void* stamp_buf);
 
 /* ---------------------------------------------------------------------------------------
+ * The critic's WHOLE Conv2D stack per launch (csrc/conv2d_chain.hip; BASELINE configs[2]: bf16 storage, bf16 products,
+ * fp32 accumulation, fp32 master weights and weight gradients).  Replaces the L x (kl.Conv2D 5x5 + kl.LeakyReLU) of
+ * networks_critic.py:64-70 -- forward, TF's Conv2DBackpropInput / Conv2DBackpropFilter chains behind it, and the
+ * second-order sweep of K.gradients(K.gradients(...)) (optimizertts_wgan.py:53-68) -- with the maps between the layers
+ * held in the LDS: a workgroup carries a tile of 32 time rows x all F <= 68 bins through all L <= 8 layers (two halo rows
+ * per layer and side, recomputed).  Channels: cin0 (1) -> 4 -> ... -> 4.
+ *   maps     a_1 .. a_{L-1} = lrelu(z_l), POST-activation, [L-1][B][T][FP][4] bf16, FP = F rounded up to even, pad bin zero
+ *            (ptts_conv2d_chain_map_elems(B, T, F) elements each);   a_last = a_L [B][T][F][4] bf16 (what the dense layers read)
+ *   tables   ptts_conv2d_chain_tables_bytes() bytes: the banded operand tables of all layers, both directions (bf16 copies
+ *            of the kernels) and the biases; rebuild when a kernel changes.  w / b are HOST arrays of L device pointers.
+ *   _fwd       x0 [B][T][ldx] fp32 (the first F values of a row are the spectrum) -> maps, a_last
+ *   _bwd       d_last = dL/da_L [B][T][F][4] (fp32, or bf16 when d_bf16) -> per-workgroup partial sums of dW_l / db_l as rows
+ *              [L][*nblocks_out][*npart_out] (a row of layer l: KT*KF*Cin_l*4 kernel entries, then 4 bias entries) for
+ *              ptts_conv2d_reduce_grouped; fixed summation order (no atomics)
+ *   _bwd_data  the backward-data chain alone: g0 = d/dx0 [B][T][F] fp32 (may be NULL) and, when gmaps is given, the masked
+ *              gradient maps gamma_l = lrelu'(a_l) . dL/da_l, l = 1 .. L, [L][B][T][FP][4] bf16 (operands of _second)
+ *   _second    the backward of _bwd_data w.r.t. d_last and the kernels: u0 = d/d(g0) [B][T][F] fp32 -> out = d/d(d_last)
+ *              [B][T][F][4] (fp32 / bf16) and the partial sums of dW_l (rows as _bwd, bias entries zero)
+ * ------------------------------------------------------------------------------------- */
+int ptts_conv2d_chain_supported(int F, int L, int Cin0, int C, int KT, int KF);
+size_t ptts_conv2d_chain_tables_bytes(void);
+size_t ptts_conv2d_chain_partials_bytes(int L);
+long long ptts_conv2d_chain_map_elems(int B, int T, int F);
+int ptts_conv2d_chain_tables(const float* const* w, const float* const* b, void* tables, int L, int cin0, void* stream);
+int ptts_conv2d_chain_fwd(const float* x0, long long ldx, const void* tables, void* maps, void* a_last,
+                          int B, int T, int F, int L, float alpha, void* stream);
+int ptts_conv2d_chain_bwd(const void* d_last, int d_bf16, const float* x0, long long ldx, const void* maps, const void* a_last,
+                          const void* tables, float* partials, size_t partials_bytes, int* nblocks_out, int* npart_out,
+                          int B, int T, int F, int L, int cin0, float alpha, void* stream);
+int ptts_conv2d_chain_bwd_data(const void* d_last, int d_bf16, const void* maps, const void* a_last, const void* tables,
+                               void* gmaps, float* g0, int B, int T, int F, int L, float alpha, void* stream);
+int ptts_conv2d_chain_second(const float* u0, const void* gmaps, const void* maps, const void* a_last, const void* tables,
+                             void* out, int out_bf16, float* partials, size_t partials_bytes, int* nblocks_out, int* npart_out,
+                             int B, int T, int F, int L, int cin0, float alpha, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * fp32 GEMM on the MFMA pipe (v_mfma_f32_32x32x2_f32), with implicit-convolution row
  * addressing for the context Conv1D.  Replaces keras Dense (networktts.py:60; heads at
  * modeltts_common.py:84,95,121; networks_critic.py:96) and kl.Conv1D (networktts.py:117).

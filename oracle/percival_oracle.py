@@ -358,14 +358,23 @@ def bf16_st(x):
 
 def critic_forward(weights, a, features, ctx, bf16_stack=False):
     """D(features [B,T,out], ctx [B,T,ctxsize]) -> [B,T,1].
-    bf16_stack (build extension, BASELINE configs[2]; the reference is fp32 throughout): the 4 -> 4 channel layers of the
-    Conv2D stack multiply in bf16 -- activation rounded to bf16 after the LeakyReLU, the kernel's bf16 copy, exact products,
-    wide accumulation -- and the maps between them are stored as bf16; the first layer, the map handed on to the dense
-    layers, the biases and the master weights stay fp32."""
+    bf16_stack (build extension, BASELINE configs[2]; the reference is fp32 throughout):
+      True / 'layers'  the 4 -> 4 channel layers of the Conv2D stack multiply in bf16 -- activation rounded to bf16 after the
+                       LeakyReLU, the kernel's bf16 copy, exact products, wide accumulation -- and the maps between them are
+                       stored as bf16; the first layer, the map handed on to the dense layers, the biases and the master
+                       weights stay fp32 (csrc/conv2d_mfma.hip with one plane);
+      'chain'          the whole stack per launch (csrc/conv2d_chain.hip): the spectrum and EVERY kernel rounded to bf16, every
+                       layer's output stored as bf16 AFTER the LeakyReLU (a_l = bf16(lrelu(z_l)), z_l never rounded), biases fp32."""
     take = _Take(weights)
     B, T = features.shape[0], features.shape[1]
     spec = features[:, :, 1:1 + a.specsize]                        # networks_critic.py:58
-    if a.L > 0:
+    if a.L > 0 and bf16_stack == 'chain':
+        h = bf16_st(spec.reshape(B, T, a.specsize, 1))
+        for li in range(a.L):
+            w, b = take(2)
+            h = bf16_st(lrelu(conv2d_nhwc(h, bf16_st(w), b)))
+        h = h.reshape(B, T, a.specsize * a.C)
+    elif a.L > 0:
         h = spec.reshape(B, T, a.specsize, 1)
         z = None
         for li in range(a.L):

@@ -62,6 +62,15 @@ SIGNATURES = {
     'ptts_conv2d_mfma_fwd': (c_i, [c_p] * 8 + [c_i] * 7 + [c_f] + [c_i] * 3 + [c_p]),
     'ptts_conv2d_mfma_wgrad_workspace_bytes': (c_sz, [c_i, c_i]),
     'ptts_conv2d_mfma_wgrad_partials': (c_i, [c_p] * 4 + [c_sz, c_p, c_p] + [c_i] * 7 + [c_f] + [c_i] * 3 + [c_p]),
+    'ptts_conv2d_chain_supported': (c_i, [c_i] * 6),
+    'ptts_conv2d_chain_tables_bytes': (c_sz, []),
+    'ptts_conv2d_chain_partials_bytes': (c_sz, [c_i]),
+    'ptts_conv2d_chain_map_elems': (c_ll, [c_i] * 3),
+    'ptts_conv2d_chain_tables': (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),
+    'ptts_conv2d_chain_fwd': (c_i, [c_p, c_ll, c_p, c_p, c_p] + [c_i] * 4 + [c_f, c_p]),
+    'ptts_conv2d_chain_bwd': (c_i, [c_p, c_i, c_p, c_ll, c_p, c_p, c_p, c_p, c_sz, c_p, c_p] + [c_i] * 5 + [c_f, c_p]),
+    'ptts_conv2d_chain_bwd_data': (c_i, [c_p, c_i, c_p, c_p, c_p, c_p, c_p] + [c_i] * 4 + [c_f, c_p]),
+    'ptts_conv2d_chain_second': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_sz, c_p, c_p] + [c_i] * 5 + [c_f, c_p]),
     'ptts_dense_planes_bytes': (c_sz, [c_i, c_i]),
     'ptts_split3_dense_weight': (c_i, [c_p, c_ll, c_i, c_i, c_i, c_p, c_p]),
     'ptts_dense_bf16x6_supported': (c_i, [c_i, c_i, c_i, c_ll, c_ll]),

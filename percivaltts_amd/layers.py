@@ -273,6 +273,46 @@ class Conv2D(Layer):
         return _apply_activation(z, self.activation)
 
 
+class Conv2DStack(Layer):
+    """L x (kl.Conv2D(filters, [kt,kf], 'same', bias) -> kl.LeakyReLU(alpha)) of the critic (networks_critic.py:66-68) as ONE
+    layer: the bf16-storage path of BASELINE configs[2] runs the whole stack per launch with the maps between the layers in
+    the LDS (ops.conv2d_chain, csrc/conv2d_chain.hip).  Input [B,T,F] (the Reshape to one channel is implied), output
+    [B,T,F,filters] with the last LeakyReLU applied.  The parameters are the L kernels and biases in Keras order
+    (kernel_0, bias_0, kernel_1, ...), so weight lists, counts and checkpoints match the layer-by-layer graph."""
+    def __init__(self, nlayers, filters, kernel_size, alpha=0.3, name=None):
+        super(Conv2DStack, self).__init__(name)
+        self.nlayers, self.filters, self.alpha = int(nlayers), int(filters), float(alpha)
+        self.kt, self.kf = int(kernel_size[0]), int(kernel_size[1])
+
+    def build(self, in_shapes):
+        cin = 1
+        for li in range(self.nlayers):
+            setattr(self, 'kernel_{}'.format(li), nn.Parameter(glorot_uniform((self.kt, self.kf, cin, self.filters))))
+            setattr(self, 'bias_{}'.format(li), nn.Parameter(torch.zeros(self.filters)))
+            cin = self.filters
+
+    def out_shape(self, in_shapes):
+        return (in_shapes[0][0], self.filters)
+
+    def kernels(self):
+        return [getattr(self, 'kernel_{}'.format(li)) for li in range(self.nlayers)], [getattr(self, 'bias_{}'.format(li)) for li in range(self.nlayers)]
+
+    def compute(self, vals, training, memo):
+        x0 = to_tensor(vals[0])
+        ws, bs = self.kernels()
+        if x0.is_cuda and ops._C2C.supported(x0.shape[-1], ws):
+            return ops.conv2d_chain(x0, ws, bs, self.alpha)
+        # shapes without a chain kernel (F > 68): layer by layer on the one-plane matrix-core / stencil kernels
+        v = x0.reshape(x0.shape[0], x0.shape[1], x0.shape[2], 1)
+        for li, (w, b) in enumerate(zip(ws, bs)):
+            z = ops.conv2d(v, w, b)
+            v = Lazy(z, None, None, lrelu=True, alpha=self.alpha)
+        return v
+
+    def config(self):
+        return {'nlayers': self.nlayers, 'filters': self.filters, 'kernel_size': [self.kt, self.kf], 'alpha': self.alpha}
+
+
 class LSTM(Layer):
     """kl.LSTM(units, tanh, recurrent sigmoid, return_sequences=True), optionally kl.Bidirectional(concat).
     Weights are held combined: kernel [In, ndir*4H] = [fwd | bwd], recurrent_kernel [ndir,H,4H], bias [ndir*4H]."""

@@ -31,18 +31,26 @@ class Critic:
         l_spec = kl.SliceLast(1, 1 + vocoder.specsize())(self.input_features)
 
         if cfgarch.arch_gen_nbcnnlayers > 0:
-            l_spec = kl.Reshape([vocoder.specsize(), 1])(l_spec)
-            # build extension (BASELINE configs[2]): cfgarch.arch_critic_bf16 stores the maps between the 4 -> 4 channel layers
-            # (and their gradients) as bf16 and multiplies in bf16 with fp32 accumulation; the first layer (1 -> 4) and the
-            # map handed to the dense layers stay fp32, like the master weights and every weight gradient
-            bf16 = bool(getattr(cfgarch, 'arch_critic_bf16', False))
+            # build extension (BASELINE configs[2]; the reference is fp32): cfgarch.arch_critic_bf16
+            #   True      the whole stack in bf16 storage / bf16 products / fp32 accumulation, ONE launch per pass with the maps
+            #             between the layers in the LDS (kl.Conv2DStack -> csrc/conv2d_chain.hip); 4 filters of 5x5, <= 8 layers,
+            #             <= 68 bins -- other geometries take the layer-wise form below
+            #   'layers'  the round-2 form: the maps between the 4 -> 4 channel layers (and their gradients) as bf16, one launch
+            #             per layer and pass; the first layer (1 -> 4) and the map handed to the dense layers stay fp32
+            # master weights and every weight gradient are fp32 either way
+            bf16 = getattr(cfgarch, 'arch_critic_bf16', False)
             L = cfgarch.arch_gen_nbcnnlayers
-            for li in range(L):
-                conv = kl.Conv2D(cfgarch.arch_gen_nbfilters, [cfgarch.arch_gen_winlen, cfgarch.arch_spec_freqlen])
-                if bf16 and li >= 1 and cfgarch.arch_gen_nbfilters == 4 and cfgarch.arch_gen_winlen == 5 and cfgarch.arch_spec_freqlen == 5:
-                    conv.bf16 = 'out16' if li < L - 1 else 'out32'
-                l_spec = conv(l_spec)
-                l_spec = kl.LeakyReLU(alpha=0.3)(l_spec)
+            std = cfgarch.arch_gen_nbfilters == 4 and cfgarch.arch_gen_winlen == 5 and cfgarch.arch_spec_freqlen == 5
+            if bf16 and bf16 != 'layers' and std and L <= 8 and vocoder.specsize() <= 68:
+                l_spec = kl.Conv2DStack(L, cfgarch.arch_gen_nbfilters, [cfgarch.arch_gen_winlen, cfgarch.arch_spec_freqlen], alpha=0.3)(l_spec)
+            else:
+                l_spec = kl.Reshape([vocoder.specsize(), 1])(l_spec)
+                for li in range(L):
+                    conv = kl.Conv2D(cfgarch.arch_gen_nbfilters, [cfgarch.arch_gen_winlen, cfgarch.arch_spec_freqlen])
+                    if bf16 and li >= 1 and std:
+                        conv.bf16 = 'out16' if li < L - 1 else 'out32'
+                    l_spec = conv(l_spec)
+                    l_spec = kl.LeakyReLU(alpha=0.3)(l_spec)
             l_spec = kl.Reshape([l_spec.shape[-2] * l_spec.shape[-1]])(l_spec)
         else:
             for _ in range(3):

@@ -115,7 +115,7 @@ def input_grad_only():
 class _Deferred(object):
     active = False
     items = []          # (x2, dy2, mask, scale, shift, gw, gb, M_out, N, K_rows, mode, alpha)
-    conv_items = []     # (partials buffer, nblocks, npart, nw, cout, gw, gb): conv2d backward passes awaiting their reduction
+    conv_items = []     # (partials buffer, byte offset of the rows, nblocks, npart, nw, cout, gw, gb): conv2d backward passes awaiting their reduction
     streams = []
 
 
@@ -230,9 +230,9 @@ def flush_weight_grads():
         _launch_wgrads(items)
     if conv_items:
         descs = (_hip.Conv2dReduceDesc * len(conv_items))()
-        for d, (buf, nblocks, npart, nw, cout, gw, gb) in zip(descs, conv_items):
+        for d, (buf, off, nblocks, npart, nw, cout, gw, gb) in zip(descs, conv_items):
             buf.record_stream(cur)
-            d.partials = buf.data_ptr() + 4096
+            d.partials = buf.data_ptr() + off
             d.nblocks, d.npart, d.nw, d.cout = nblocks, npart, nw, cout
             d.dw = gw.data_ptr() if gw is not None else None
             d.dbias = gb.data_ptr() if gb is not None else None
@@ -438,7 +438,7 @@ def _conv2d_bwd_deferred(dy, x, w, mask_src, mode, alpha, dil_t, pad_mode, want_
         cur = torch.cuda.current_stream()
         if all(cur.cuda_stream != st.cuda_stream for st in _Deferred.streams):
             _Deferred.streams.append(cur)
-        _Deferred.conv_items.append((buf, nblocks, npart, KT * KF * Cin * Cout, Cout, gw, gb))
+        _Deferred.conv_items.append((buf, 4096, nblocks, npart, KT * KF * Cin * Cout, Cout, gw, gb))
         return dx
     nws = _hip.lib().ptts_conv2d_bwd_workspace_bytes(B, T, F, Cin, Cout, KT, KF, dil_t)
     if nws <= 16:
@@ -454,7 +454,7 @@ def _conv2d_bwd_deferred(dy, x, w, mask_src, mode, alpha, dil_t, pad_mode, want_
     if all(cur.cuda_stream != s.cuda_stream for s in _Deferred.streams):
         _Deferred.streams.append(cur)
     nw = KT * KF * Cin * Cout
-    _Deferred.conv_items.append((buf, nblocks.value, nw + Cout + 2 * Cin, nw, Cout, gw, gb))
+    _Deferred.conv_items.append((buf, 4096, nblocks.value, nw + Cout + 2 * Cin, nw, Cout, gw, gb))
     return dx
 
 
@@ -675,6 +675,192 @@ def conv2d(v, w, b=None, dil_t=1, pad_mode=PAD_SAME, bf16=None):
     """z_out = conv2d(act(v), w) + b on [B,T,F,Cin]; `v` is a tensor or a Lazy.  bf16: see Conv2dFn."""
     z, mode, scale, shift, alpha = _prep(v)
     return Conv2dFn.apply(z, w, b, scale, shift, mode, alpha, dil_t, pad_mode, bf16)
+
+
+# ----------------------------------------------------------------------------------------------
+# The critic's whole Conv2D stack per launch (csrc/conv2d_chain.hip; networks_critic.py:64-70): bf16 storage path of
+# BASELINE configs[2].  L x (Conv2D 5x5, 4 filters, bias, LeakyReLU) with the maps between the layers held in the LDS;
+# the stored maps are POST-activation (they serve as operands and as LeakyReLU masks: slope > 0 keeps the sign).
+# ----------------------------------------------------------------------------------------------
+class _C2C(object):
+    tables = {}         # (ids of the kernels, stream) -> (kernels, biases, versions, epoch, table buffer)
+
+    @staticmethod
+    def supported(F, ws):
+        if not ws:
+            return False
+        KT, KF, cin0, Cc = ws[0].shape
+        if any(tuple(w.shape) != (KT, KF, 4, Cc) for w in ws[1:]):
+            return False
+        return bool(_hip.lib().ptts_conv2d_chain_supported(int(F), len(ws), int(cin0), int(Cc), int(KT), int(KF)))
+
+    @classmethod
+    def table(cls, ws, bs):
+        flat = getattr(ws[0], '_ptts_flat', None)
+        epoch = None if flat is None else flat.epoch
+        sid = torch.cuda.current_stream().cuda_stream
+        key = (tuple(id(w) for w in ws), sid)
+        vers = tuple(w._version for w in ws) + tuple(-1 if b is None else b._version for b in bs)
+        ent = cls.tables.get(key)
+        if ent is None or any(a is not b for a, b in zip(ent[0], ws)) or ent[2] != vers or ent[3] != epoch or flat is None:
+            tab = ent[4] if ent is not None else torch.empty(_hip.lib().ptts_conv2d_chain_tables_bytes(), dtype=torch.uint8, device=ws[0].device)
+            for w in ws:
+                f32c(w, 'conv2d_chain.w')
+            wp = (ctypes.c_void_p * len(ws))(*[w.data_ptr() for w in ws])
+            bp = (ctypes.c_void_p * len(ws))(*[None if b is None else f32c(b, 'conv2d_chain.b').data_ptr() for b in bs])
+            call('ptts_conv2d_chain_tables', wp, bp, ptr(tab), len(ws), int(ws[0].shape[2]), stream(), tag=(len(ws),))
+            ent = (tuple(ws), tuple(bs), vers, epoch, tab)
+            if len(cls.tables) > 64:
+                cls.tables = {}
+            cls.tables[key] = ent
+        return ent[4]
+
+    @classmethod
+    def clear(cls):
+        cls.tables = {}
+
+
+def _chain_x0(x0):
+    """[B,T,F] fp32 with unit stride along F and whole rows between frames (a column slice of [B,T,D] qualifies)."""
+    if not (x0.is_cuda and x0.dtype == torch.float32 and x0.dim() == 3 and x0.stride(2) == 1 and x0.stride(0) == x0.shape[1] * x0.stride(1)):
+        x0 = x0.contiguous()
+        if not (x0.is_cuda and x0.dtype == torch.float32):
+            raise _hip.HipLibraryError('conv2d_chain: expected a float32 device tensor [B,T,F], got {} {}'.format(x0.device, x0.dtype))
+    return x0
+
+
+def _chain_reduce(parts, nblocks, npart, ws, gws, gbs, want_b):
+    """Partial rows [L][nblocks][npart] -> the gradient buffers: queued for the grouped launch inside deferred_weight_grads()
+    (gws / gbs: the parameters' .grad views), else reduced now into fresh tensors, which are returned."""
+    L = len(ws)
+    deferred = gws is not None and all(g is not None for g in gws) and (not want_b or all(g is not None for g in gbs))
+    if deferred:
+        cur = torch.cuda.current_stream()
+        if all(cur.cuda_stream != st.cuda_stream for st in _Deferred.streams):
+            _Deferred.streams.append(cur)
+        for l, w in enumerate(ws):
+            _Deferred.conv_items.append((parts, l * nblocks * npart * 4, nblocks, npart, w.numel(), w.shape[3], gws[l], gbs[l] if want_b else None))
+        return None, None
+    dws = [torch.zeros_like(w) for w in ws]
+    dbs = [torch.zeros(w.shape[3], dtype=torch.float32, device=w.device) for w in ws] if want_b else [None] * L
+    descs = (_hip.Conv2dReduceDesc * L)()
+    for l, (d, w) in enumerate(zip(descs, ws)):
+        d.partials = parts.data_ptr() + l * nblocks * npart * 4
+        d.nblocks, d.npart, d.nw, d.cout = nblocks, npart, w.numel(), w.shape[3]
+        d.dw = dws[l].data_ptr()
+        d.dbias = dbs[l].data_ptr() if want_b else None
+    call('ptts_conv2d_reduce_grouped', ctypes.cast(descs, ctypes.c_void_p), L, stream(), tag=(L,))
+    return dws, dbs
+
+
+def _chain_defer_targets(ws, bs):
+    if not (_Deferred.active and not _Flags.deterministic):
+        return None, None
+    return [grad_target(w) for w in ws], [None if b is None else grad_target(b) for b in bs]
+
+
+class Conv2dChainFn(torch.autograd.Function):
+    """a_L = stack(x0): x0 [B,T,F] fp32 -> [B,T,F,4] bf16 (post-activation).  Arguments after alpha: w_1, b_1, ..., w_L, b_L."""
+    @staticmethod
+    def forward(ctx, x0, alpha, *wb):
+        ws, bs = list(wb[0::2]), list(wb[1::2])
+        x0 = _chain_x0(x0)
+        B, T, F = x0.shape
+        L = len(ws)
+        tab = _C2C.table(ws, bs)
+        FP = (F + 1) & ~1
+        maps = torch.empty((max(L - 1, 1), B, T, FP, 4), dtype=torch.bfloat16, device=x0.device)
+        a_last = torch.empty((B, T, F, 4), dtype=torch.bfloat16, device=x0.device)
+        call('ptts_conv2d_chain_fwd', ptr(x0), x0.stride(1), ptr(tab), ptr(maps), ptr(a_last), B, T, F, L, alpha, stream(), tag=(B, T, F, L))
+        ctx.save_for_backward(x0, maps, a_last, tab, *ws)
+        ctx.alpha, ctx.L, ctx.has_b = alpha, L, [b is not None for b in bs]
+        ctx.gws, ctx.gbs = _chain_defer_targets(ws, bs)
+        return a_last
+
+    @staticmethod
+    def backward(ctx, d_last):
+        x0, maps, a_last, tab = ctx.saved_tensors[:4]
+        ws = list(ctx.saved_tensors[4:])
+        L, alpha = ctx.L, ctx.alpha
+        B, T, F = x0.shape
+        need_x = ctx.needs_input_grad[0]
+        need_w = any(ctx.needs_input_grad[2 + 2 * l] or (ctx.has_b[l] and ctx.needs_input_grad[3 + 2 * l]) for l in range(L))
+        if _Flags.skip_param_grads:
+            need_w = False
+        d_last = _st(d_last.contiguous(), 'conv2d_chain.d_last')
+        g0 = None
+        grads = [None] * (2 * L)
+        if need_x:
+            if torch.is_grad_enabled():
+                # differentiable backward (gradient penalty): its own backward is the second-order sweep
+                g0 = Conv2dChainBwdDataFn.apply(d_last, maps, a_last, tab, alpha, (ctx.gws, int(ws[0].shape[2])), *ws)
+            else:
+                g0 = torch.empty((B, T, F), dtype=torch.float32, device=x0.device)
+                call('ptts_conv2d_chain_bwd_data', ptr(d_last), int(_is16(d_last)), ptr(maps), ptr(a_last), ptr(tab), None, ptr(g0),
+                     B, T, F, L, alpha, stream(), tag=(B, T, F, L, 0))
+        if need_w:
+            with torch.no_grad():
+                parts = torch.empty(_hip.lib().ptts_conv2d_chain_partials_bytes(L), dtype=torch.uint8, device=x0.device)
+                nblocks, npart = ctypes.c_int(0), ctypes.c_int(0)
+                call('ptts_conv2d_chain_bwd', ptr(d_last), int(_is16(d_last)), ptr(x0), x0.stride(1), ptr(maps), ptr(a_last), ptr(tab),
+                     ptr(parts), parts.numel(), ctypes.byref(nblocks), ctypes.byref(npart), B, T, F, L, int(ws[0].shape[2]), alpha, stream(),
+                     tag=(B, T, F, L))
+                want_b = any(ctx.has_b)
+                dws, dbs = _chain_reduce(parts, nblocks.value, npart.value, ws, ctx.gws, ctx.gbs, want_b)
+                if dws is not None:
+                    for l in range(L):
+                        grads[2 * l] = dws[l]
+                        grads[2 * l + 1] = dbs[l] if ctx.has_b[l] else None
+        return (g0, None) + tuple(grads)
+
+
+class Conv2dChainBwdDataFn(torch.autograd.Function):
+    """g0 = d(sum d_last . a_L)/d(x0) through the stack; linear in d_last and in every kernel.  Its backward is the second-order
+    sweep of the gradient penalty (optimizertts_wgan.py:53-68)."""
+    @staticmethod
+    def forward(ctx, d_last, maps, a_last, tab, alpha, extra, *ws):
+        gws, cin0 = extra
+        B, T, F, _ = a_last.shape
+        L = len(ws)
+        FP = (F + 1) & ~1
+        gmaps = torch.empty((L, B, T, FP, 4), dtype=torch.bfloat16, device=a_last.device)
+        g0 = torch.empty((B, T, F), dtype=torch.float32, device=a_last.device)
+        call('ptts_conv2d_chain_bwd_data', ptr(d_last), int(_is16(d_last)), ptr(maps), ptr(a_last), ptr(tab), ptr(gmaps), ptr(g0),
+             B, T, F, L, alpha, stream(), tag=(B, T, F, L, 1))
+        ctx.save_for_backward(gmaps, maps, a_last, tab, *ws)
+        ctx.cfg = (alpha, L, cin0, d_last.dtype)
+        ctx.gws = gws
+        return g0
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, u0):
+        gmaps, maps, a_last, tab = ctx.saved_tensors[:4]
+        ws = list(ctx.saved_tensors[4:])
+        alpha, L, cin0, d_dtype = ctx.cfg
+        B, T, F, _ = a_last.shape
+        u0 = f32c(u0.contiguous(), 'conv2d_chain.u0')
+        out = torch.empty((B, T, F, 4), dtype=d_dtype, device=u0.device)
+        parts = torch.empty(_hip.lib().ptts_conv2d_chain_partials_bytes(L), dtype=torch.uint8, device=u0.device)
+        nblocks, npart = ctypes.c_int(0), ctypes.c_int(0)
+        call('ptts_conv2d_chain_second', ptr(u0), ptr(gmaps), ptr(maps), ptr(a_last), ptr(tab), ptr(out), int(d_dtype == torch.bfloat16),
+             ptr(parts), parts.numel(), ctypes.byref(nblocks), ctypes.byref(npart), B, T, F, L, cin0, alpha, stream(), tag=(B, T, F, L))
+        need_w = any(ctx.needs_input_grad[6 + l] for l in range(L))
+        grads = [None] * L
+        if need_w:
+            gws = ctx.gws if (_Deferred.active and not _Flags.deterministic) else None
+            dws, _ = _chain_reduce(parts, nblocks.value, npart.value, ws, gws, [None] * L, False)
+            if dws is not None:
+                grads = dws
+        return (out if ctx.needs_input_grad[0] else None, None, None, None, None, None) + tuple(grads)
+
+
+def conv2d_chain(x0, ws, bs, alpha=0.3):
+    """The whole stack: x0 [B,T,F] fp32 -> a_L [B,T,F,4] bf16 (LeakyReLU applied)."""
+    wb = []
+    for w, b in zip(ws, bs):
+        wb += [w, b]
+    return Conv2dChainFn.apply(x0, float(alpha), *wb)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -960,6 +1146,7 @@ def clear_caches():
     _C1Split.clear()
     _C1WgradT.clear()
     _C2M.clear()
+    _C2C.clear()
     _DenseSplit.planes = {}
     _C1Cache.key = _C1Cache.ap = _C1Cache.y = None
 

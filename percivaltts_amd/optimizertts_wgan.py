@@ -84,7 +84,9 @@ class _DeviceCosts(list):
         self._pending = []
 
     def append_device(self, t):
-        self._pending.append(t.detach().reshape(()))
+        # a copy, not a view: under cfg.train_wgan_hipgraph every replay returns the SAME static output tensor of the
+        # captured graph, and pending views of it would all read the last batch's loss
+        self._pending.append(t.detach().reshape(()).clone())
 
     def _sync(self):
         if self._pending:
@@ -389,7 +391,10 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
                 for _ in range(2):     # warm-up outside capture (allocator, workspace growth)
                     fn()
                     if not whole:
-                        self._update(kind); self.wait_updates()
+                        self._update(kind)
+                    # an asynchronous update of the warm-up must not be left pending: a wait recorded outside the capture
+                    # would be popped by the first _wait_update() inside it and be no dependency of the graph
+                    self.wait_updates()
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
             ops.clear_caches()         # every derived operand (bf16 planes, Toeplitz tables) must be rebuilt inside the graph
