@@ -165,6 +165,7 @@ int ptts_conv2d_mfma_debug(int flags, void* stamp_buf);
  *              [B][T][F][4] (fp32 / bf16) and the partial sums of dW_l (rows as _bwd, bias entries zero)
  * ------------------------------------------------------------------------------------- */
 int ptts_conv2d_chain_supported(int F, int L, int Cin0, int C, int KT, int KF);
+int ptts_conv2d_chain_debug(void* stamp_buf);   /* measurement hook of tools/chain_probe.py: 256 x 32 uint64 phase stamps, NULL = off */
 size_t ptts_conv2d_chain_tables_bytes(void);
 size_t ptts_conv2d_chain_partials_bytes(int L);
 long long ptts_conv2d_chain_map_elems(int B, int T, int F);

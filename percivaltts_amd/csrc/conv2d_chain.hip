@@ -75,6 +75,15 @@ __device__ __forceinline__ bf16x4 tr_read(const u16* p) {
 __device__ __forceinline__ bf16x4 to_bf16(f32x4 v) { return __builtin_convertvector(v, bf16x4); }
 __device__ __forceinline__ f32x4 to_f32(bf16x4 v) { return __builtin_convertvector(v, f32x4); }
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+// workgroup barrier that orders the LDS only: __syncthreads() also waits for every global store of the wave to be acknowledged
+// (vmcnt counts stores on gfx950) -- the maps a step writes to HBM would be drained at every layer boundary
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// measurement hook (tools/chain_probe.py): 100 MHz time stamps of the phases of every workgroup's first tile, dbg[block][32]
+__device__ __forceinline__ void stamp(unsigned long long* dbg, int slot) {
+    if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 32 + slot] = __builtin_amdgcn_s_memrealtime();
+}
+static unsigned long long* g_dbg = nullptr;
 
 // ------------------------------------------------------------------------------------------------------------
 // operand tables of all layers, both directions (layout of conv2d_mfma.hip with one plane):
@@ -110,7 +119,6 @@ __global__ void chain_tables_kernel(TabArgs a, u16* __restrict__ tab, float* __r
 struct Geo {
     int B, T, F, FP, L, ng;            // FP: padded bins of the internal maps; ng: bin groups
     int ntt, ntiles;                   // time tiles per utterance, all tiles
-    unsigned magic_ng;                 // ceil(2^16 / ng)
     unsigned magic_fp2;                // ceil(2^32 / (FP / 2))
     float alpha;
     long long map_stride;              // elements between the internal maps of consecutive layers: B * T * FP * 4
@@ -167,18 +175,33 @@ struct X0Pref {
     }
 };
 
-// own rows of an LDS tile -> a padded map in HBM: whole rows of FP / 2 units (the pad bin is zero in the tile)
+// own rows of an LDS tile -> a padded map in HBM: whole rows of FP / 2 units (the pad bin is zero in the tile).  The slots of a
+// thread (tile-independent) are worked out once per kernel; all reads are issued before the first store.
 template <int NT>
-__device__ __forceinline__ void store_rows_padded(const u16* tile, int tile_torg, u16* __restrict__ map, const Geo& g, int b, int t0) {
-    const int upr = g.FP >> 1, total = TR * upr;
-    for (int idx = threadIdx.x; idx < total; idx += NT) {
-        const int r = (int)__umulhi((unsigned)idx, g.magic_fp2), u = idx - r * upr + 1;
-        const int t = t0 + r;
-        if (t < g.T)
-            *reinterpret_cast<bf16x8*>(map + ((long long)(b * g.T + t) * g.FP + (2 * u - 2)) * C) =
-                *reinterpret_cast<const bf16x8*>(tile + (t - tile_torg) * RS + unit_pos(u) * 8);
+struct RowStore {
+    static constexpr int NS = (TR * (4 * NGMAX / 2) + NT - 1) / NT;
+    int lo_[NS];       // LDS element offset relative to the own rows' first row
+    int go_[NS];       // element offset in the map relative to the own rows' first row, or -1
+    int r_[NS];
+    __device__ __forceinline__ void init(const Geo& g) {
+        const int upr = g.FP >> 1, total = TR * upr;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int idx = threadIdx.x + k * NT;
+            const int r = upr > 1 ? (int)__umulhi((unsigned)idx, g.magic_fp2) : idx, u = idx - r * upr + 1;
+            r_[k] = idx < total ? r : (1 << 20);
+            lo_[k] = r * RS + unit_pos(u) * 8;
+            go_[k] = (r * g.FP + (2 * u - 2)) * C;
+        }
     }
-}
+    __device__ __forceinline__ void run(const u16* tile_own, u16* __restrict__ map_own, int nrows) const {
+        bf16x8 v[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) if (r_[k] < nrows) v[k] = *reinterpret_cast<const bf16x8*>(tile_own + lo_[k]);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) if (r_[k] < nrows) *reinterpret_cast<bf16x8*>(map_own + go_[k]) = v[k];
+    }
+};
 // ... -> the unpadded last map [B][T][F][4]: eight bytes per lane, consecutive lanes consecutive pixels
 template <int NT>
 __device__ __forceinline__ void store_rows_plain(const u16* tile, int tile_torg, u16* __restrict__ map, const Geo& g, int b, int t0) {
@@ -192,12 +215,9 @@ __device__ __forceinline__ void store_rows_plain(const u16* tile, int tile_torg,
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// one layer on LDS tiles: out[t][f][:] = acc0 + sum_kt A_kt . in[t - 2 + kt][f - 2 .. f + 5][:] for t in [ta, tb), all bin groups.
-// Units = (chunk of 16 rows, bin group) of five MFMAs; a wave takes the units first, first + stride, ... < end, two at a time
-// (ten fragment reads in flight).  The last chunk ends at tb: it overlaps its predecessor when tb - ta is no multiple of 16
-// (same values written twice); `fresh` tells the epilogue which of its rows are new.
-//   pre(t, f)                 -> what the epilogue wants fetched before the MFMAs (a mask source)
-//   epi(t, f, acc, pre, fresh)
+// one layer on LDS tiles: out[t][f][:] = acc0 + sum_kt A_kt . in[t - 2 + kt][f - 2 .. f + 5][:] for t in [ta, tb), all bin groups:
+// five MFMAs per (chunk of 16 rows, bin group).  The last chunk ends at tb: it overlaps its predecessor when tb - ta is no
+// multiple of 16 (same values written twice); `fresh` tells the epilogue which of its rows are new.
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void load_afrag(const u16* tabl, int lane, bf16x8 (&a)[KT]) {
     const int li = lane & 15, lg = lane >> 4;
@@ -207,33 +227,100 @@ __device__ __forceinline__ void load_afrag(const u16* tabl, int lane, bf16x8 (&a
         a[kt] = cat(*reinterpret_cast<const bf16x4*>(wa + kt * TKP), *reinterpret_cast<const bf16x4*>(wa + kt * TKP + 4));
 }
 
-template <class Pre, class Epi>
-__device__ __forceinline__ void conv_units(const u16* in, int in_torg, const bf16x8 (&a)[KT], int ta, int tb, const Geo& g,
-                                           int first, int end, int stride, int lane, f32x4 acc0, Pre&& pre, Epi&& epi) {
-    const int li = lane & 15, lg = lane >> 4, rl = row_of_lane(li);
-    for (int u = first; u < end; u += 2 * stride) {
-        const int u1 = u + stride;
-        const bool two = u1 < end;                                     // wave-uniform
-        const int c0 = (int)(((unsigned)u * g.magic_ng) >> 16), g0 = u - c0 * g.ng;
-        const int uu = two ? u1 : u;
-        const int c1 = (int)(((unsigned)uu * g.magic_ng) >> 16), g1 = uu - c1 * g.ng;
-        const int t0 = min(ta + 16 * c0, tb - 16) + rl, t1 = min(ta + 16 * c1, tb - 16) + rl;
-        const u16* bp0 = in + (t0 - 2 - in_torg) * RS + unit_pos(2 * g0 + lg) * 8;
-        const u16* bp1 = in + (t1 - 2 - in_torg) * RS + unit_pos(2 * g1 + lg) * 8;
-        const int f0 = 4 * g0 + lg, f1 = 4 * g1 + lg;
-        auto p0 = pre(t0, f0);
-        auto p1 = pre(t1, f1);
-        bf16x8 b0[KT], b1[KT];
+// per-lane element offsets inside a 16-row chunk, relative to the chunk's first row and to bin-group pair 0
+struct LaneOff {
+    int rdA, rdB;      // B-operand fragment of the even / odd group of a pair: row of the lane, unit 2 g + lg
+    int pxA, pxB;      // the lane's output pixel: row of the lane, staged bin 4 g + lg + 2
+    int rl, lg;
+    __device__ __forceinline__ void init(int lane) {
+        const int li = lane & 15;
+        lg = lane >> 4; rl = row_of_lane(li);
+        rdA = rl * RS + unit_pos(lg) * 8; rdB = rl * RS + unit_pos(2 + lg) * 8;
+        pxA = rl * RS + bin_off(lg + 2); pxB = rl * RS + bin_off(lg + 6);
+    }
+};
+
+// Work of a step = (chunk of 16 rows, PAIR of bin groups): the even and the odd group of a pair differ in their unit positions
+// only by per-lane constants (LaneOff); a wave owns fixed pairs for all chunks of a step, so everything else of an address is a
+// scalar and the loop carries no per-item index arithmetic (the first version spent 16 instructions per MFMA: rocprofv3
+// SQ_INSTS_VALU / SQ_INSTS_SALU, gpurun_out/chain_pmc).
+// pair_of: the bin-group pair of slot j (0, 1) of this wave at chunk c, or -1.
+//   all waves alike (WG = false):   pairs 0 .. NW-1 fixed on slot 0, pair NW (the ninth of a 17-group row) goes round the waves
+//   waves 0 .. KT-1 also run weight-gradient products (WG = true): waves KT .. NW-1 own pairs 0 .. 2 (NW-KT) - 1 (two each),
+//                                   the remaining three pairs go round waves 0 .. KT-1
+template <int NW, bool WG>
+__device__ __forceinline__ int pair_of(int j, int c, int wave, int ng2, int rot) {
+    int gp;
+    if (!WG) gp = j == 0 ? wave : ((((c + rot) & (NW - 1)) == wave) ? NW : -1);
+    else if (wave >= KT) gp = (wave - KT) + j * (NW - KT);
+    else {
+        if (j) return -1;
+        const int k = (c + rot + wave) % KT;
+        gp = k < 3 ? 2 * (NW - KT) + k : -1;
+    }
+    return gp < ng2 ? gp : -1;
+}
+
+// SEQ: the two groups of a pair one after the other (the kernels that carry the weight-gradient accumulators: register budget),
+// else both groups' ten fragment reads are in flight together.  More than eight waves: wave & 7 owns the pairs, wave >> 3 the
+// chunks c = wave >> 3, + NW / 8, ...
+//   pre(tc, t, f, px)                      -> what the epilogue wants fetched before the MFMAs (a mask source); px = the
+//                                             pixel's element offset relative to tile row tc
+//   epi(tc, t, f, px, acc, pre, ok, fresh)    ok: the pixel lies inside the image; fresh: not produced by the previous chunk
+// (A hand-pipelined stream of single units -- reads of unit i + 1 before the MFMAs of unit i -- was built and measured 1.7 x
+// SLOWER: a wave issues one instruction per four cycles, and the scalar bookkeeping of the stream cost more than the LDS latency
+// it hid.  What counts here is the number of instructions per wave and step.)
+template <int NW, bool WG, bool SEQ, class Pre, class Epi>
+__device__ __forceinline__ void conv_chunks(const u16* in, int in_torg, const bf16x8 (&a)[KT], int ta, int tb, const Geo& g,
+                                            int wave_, int rot, const LaneOff& lo, f32x4 acc0, Pre&& pre, Epi&& epi) {
+    constexpr int NWP = NW > 8 ? 8 : NW, CST = NW / NWP;
+    const int wave = wave_ & (NWP - 1), c0 = wave_ / NWP;
+    const int ng2 = (g.ng + 1) >> 1, nch = (tb - ta + 15) >> 4;
+    for (int c = c0; c < nch; c += CST) {
+        const int tc = min(ta + 16 * c, tb - 16);
+        const int t = tc + lo.rl;
+        const bool tin = (unsigned)t < (unsigned)g.T, fresh = t >= ta + 16 * c;
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) { b0[kt] = *reinterpret_cast<const bf16x8*>(bp0 + kt * RS); b1[kt] = *reinterpret_cast<const bf16x8*>(bp1 + kt * RS); }
-        f32x4 x0 = acc0, x1 = acc0;
+        for (int j = 0; j < 2; ++j) {
+            const int gp = pair_of<NWP, WG>(j, c, wave, ng2, rot);
+            if (gp < 0) continue;                                              // wave-uniform
+            const bool hasB = 2 * gp + 1 < g.ng;
+            const u16* bp = in + (tc - 2 - in_torg) * RS + 32 * gp;
+            const int fA = 8 * gp + lo.lg, fB = fA + 4;
+            const int pxA = lo.pxA + 32 * gp, pxB = lo.pxB + 32 * gp;
+            const bool okA = tin && fA < g.F, okB = tin && fB < g.F;
+            auto pA = pre(tc, t, fA, pxA);
+            bf16x8 bA[KT], bB[KT];
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            x0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kt], b0[kt], x0, 0, 0, 0);
-            x1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kt], b1[kt], x1, 0, 0, 0);
+            for (int kt = 0; kt < KT; ++kt) bA[kt] = *reinterpret_cast<const bf16x8*>(bp + lo.rdA + kt * RS);
+            if (!SEQ && hasB) {
+                auto pB = pre(tc, t, fB, pxB);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) bB[kt] = *reinterpret_cast<const bf16x8*>(bp + lo.rdB + kt * RS);
+                f32x4 xA = acc0, xB = acc0;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    xA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kt], bA[kt], xA, 0, 0, 0);
+                    xB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kt], bB[kt], xB, 0, 0, 0);
+                }
+                epi(tc, t, fA, pxA, xA, pA, okA, fresh);
+                epi(tc, t, fB, pxB, xB, pB, okB, fresh);
+            } else {
+                f32x4 xA = acc0;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) xA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kt], bA[kt], xA, 0, 0, 0);
+                epi(tc, t, fA, pxA, xA, pA, okA, fresh);
+                if (hasB) {
+                    auto pB = pre(tc, t, fB, pxB);
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) bB[kt] = *reinterpret_cast<const bf16x8*>(bp + lo.rdB + kt * RS);
+                    f32x4 xB = acc0;
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) xB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kt], bB[kt], xB, 0, 0, 0);
+                    epi(tc, t, fB, pxB, xB, pB, okB, fresh);
+                }
+            }
         }
-        epi(t0, f0, x0, p0, t0 >= ta + 16 * c0);
-        if (two) epi(t1, f1, x1, p1, t1 >= ta + 16 * c1);
     }
 }
 
@@ -244,40 +331,49 @@ __device__ __forceinline__ void conv_units(const u16* in, int in_torg, const bf1
 __device__ __forceinline__ void dw_step(f32x4& c0, f32x4& c1, const u16* at, const u16* dt, int ng, const u16* zero, int lane) {
     const int li = lane & 15, lg = lane >> 4;
     const int trow = 4 * lg + (li >> 2), fb = li & 3;
-    const int ng2 = (ng + 1) >> 1;
+    const int ng2 = (ng + 1) >> 1, nk = (TR / 16) * ng2;
     const bool odd = (ng & 1) != 0;
-#pragma unroll
-    for (int rc = 0; rc < TR / 16; ++rc) {
-        const u16* ab = at + (16 * rc + trow) * RS;
-        const u16* db = dt + (16 * rc + trow) * RS;
-        const u16* a0 = ab + bin_off(2 + fb);
-        const u16* a1 = ab + bin_off(6 + fb);
-        const u16* d0 = db + bin_off(0 + fb);
-        const u16* d1 = db + bin_off(4 + fb);
-        const u16* d2 = db + bin_off(8 + fb);
-        for (int gp = 0; gp < ng2; ++gp) {
-            const bool ph = odd && gp == ng2 - 1;                         // wave-uniform
-            const bf16x4 va0 = tr_read(a0 + 32 * gp), va1 = tr_read(ph ? zero : a1 + 32 * gp);
-            const bf16x4 vd0 = tr_read(d0 + 32 * gp), vd1 = tr_read(d1 + 32 * gp), vd2 = tr_read(ph ? zero : d2 + 32 * gp);
-            const bf16x8 af = cat(va0, va1);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, cat(vd0, vd1), c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, cat(vd1, vd2), c1, 0, 0, 0);
-        }
+    const u16* ab = at + trow * RS;
+    const u16* db = dt + trow * RS;
+    const int oa0 = bin_off(2 + fb), oa1 = bin_off(6 + fb), od0 = bin_off(fb), od1 = bin_off(4 + fb), od2 = bin_off(8 + fb);
+    // K step k = (row chunk rc, bin group pair gp); the five fragment reads of step k + 1 are issued before the MFMAs of step k
+    auto rd = [&](int k, bf16x4 (&v)[5]) {
+        const int rc = k >= ng2 ? 1 : 0, gp = k - rc * ng2;              // TR / 16 == 2
+        const bool ph = odd && gp == ng2 - 1;                            // wave-uniform
+        const int o = rc * 16 * RS + 32 * gp;
+        v[0] = tr_read(ab + o + oa0);
+        v[1] = tr_read(ph ? zero : ab + o + oa1);
+        v[2] = tr_read(db + o + od0);
+        v[3] = tr_read(db + o + od1);
+        v[4] = tr_read(ph ? zero : db + o + od2);
+    };
+    auto mm = [&](const bf16x4 (&v)[5]) {
+        const bf16x8 af = cat(v[0], v[1]);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, cat(v[2], v[3]), c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, cat(v[3], v[4]), c1, 0, 0, 0);
+    };
+    static_assert(TR == 32, "dw_step: two row chunks");
+    bf16x4 va[5], vb[5];
+    rd(0, va);
+    for (int k = 0; k < nk; k += 2) {          // nk is even
+        rd(k + 1, vb);
+        mm(va);
+        if (k + 2 < nk) rd(k + 2, va);
+        mm(vb);
     }
 }
 
-// share of the conv units of a step between the waves that also run weight-gradient products (0 .. KT-1) and the others: the
-// first `nh` units go to waves KT .. NW-1, the rest to waves 0 .. KT-1, so that every wave issues about the same number of MFMAs
-template <int NW>
-__device__ __forceinline__ void split_units(int nunits, int wave, int& first, int& end, int& stride) {
-    constexpr int DW = (TR / 16) * ((NGMAX + 1) / 2) * 2;            // weight-gradient MFMAs of a wave and step
-    constexpr int NHI = NW - KT;
-    // units x of a low wave, y of a high one: KT x + NHI y = n, DW + 5 x = 5 y
-    int nh = (NHI * (5 * nunits + KT * DW)) / (5 * NW);
-    nh = max(0, min(nunits, nh));
-    if (wave >= KT) { first = wave - KT; end = nh; stride = NHI; }
-    else { first = nh + wave; end = nunits; stride = KT; }
+// acc[s] += (c0, c1) for a run-time step index: the accumulators keep static register names behind a wave-uniform switch, so
+// the step loop itself need not be unrolled (unrolled eight-fold it drove the kernel past its register budget)
+__device__ __forceinline__ void acc_add(f32x4 (&acc)[LMAX][2], int s, f32x4 c0, f32x4 c1) {
+    switch (s) {
+#define C2C_CASE(S) case S: acc[S][0] += c0; acc[S][1] += c1; break;
+        C2C_CASE(0) C2C_CASE(1) C2C_CASE(2) C2C_CASE(3) C2C_CASE(4) C2C_CASE(5) C2C_CASE(6) C2C_CASE(7)
+#undef C2C_CASE
+        default: break;
+    }
 }
+static_assert(LMAX == 8, "acc_add: eight cases");
 
 __device__ __forceinline__ void wave_add4(float* dst, f32x4 v, int lane) {
 #pragma unroll
@@ -311,6 +407,7 @@ struct FwdArgs {
     const u16* tab; const float* bias;
     u16* maps; u16* a_last;
     Geo g; size_t lds_bytes;
+    unsigned long long* dbg;
 };
 
 template <int NT>
@@ -321,7 +418,13 @@ __global__ __launch_bounds__(NT) void chain_fwd_kernel(FwdArgs a) {
     const int L = g.L;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    stamp(a.dbg, 0);
     lds_init<NT>(lds, a.lds_bytes, a.tab, a.bias, L, 0);
+    stamp(a.dbg, 1);
+    LaneOff lo;
+    lo.init(lane);
+    RowStore<NT> rs;
+    rs.init(g);
     const float* biasl = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds) + HDR_BIAS);
     const int RB = TR + 4 * L;
     u16* P0 = lds + HDR_BYTES / 2;
@@ -342,29 +445,32 @@ __global__ __launch_bounds__(NT) void chain_fwd_kernel(FwdArgs a) {
             const int nb = nxt / g.ntt, nt0 = (nxt - nb * g.ntt) * TR;
             xp.load(a.x0, a.ldx, g, nb, nt0 - 2 * L, RB);
         }
-        __syncthreads();
+        lds_barrier();
+        stamp(a.dbg, 2);
         for (int l = 1; l <= L; ++l) {
             const u16* in = (l & 1) ? P0 : P1;
             u16* out = (l & 1) ? P1 : P0;
             bf16x8 af[KT];
             load_afrag(lds + (l - 1) * TLAY, lane, af);
             const f32x4 bv = *reinterpret_cast<const f32x4*>(biasl + (l - 1) * C);
-            if (l >= 2) store_rows_padded<NT>(in, torg, a.maps + (long long)(l - 2) * g.map_stride, g, b, t0);
+            if (l >= 2) rs.run(in + (t0 - torg) * RS, a.maps + (long long)(l - 2) * g.map_stride + (long long)(b * g.T + t0) * g.FP * C, min(TR, g.T - t0));
             const int ext = 2 * (L - l);
             const int ta = t0 - ext, tb = t0 + TR + ext;
-            const int nunits = ((tb - ta + 15) >> 4) * g.ng;
-            conv_units(in, torg, af, ta, tb, g, wave, nunits, NW, lane, bv,
-                       [](int, int) { return 0; },
-                       [&](int t, int f, f32x4 v, int, bool) {
+            conv_chunks<NW, false, false>(in, torg, af, ta, tb, g, wave, l, lo, bv,
+                       [](int, int, int, int) { return 0; },
+                       [&](int tc, int, int, int px, f32x4 v, int, bool ok, bool) {
 #pragma unroll
                            for (int e = 0; e < 4; ++e) v[e] = max_fast(v[e], g.alpha * v[e]);       // LeakyReLU, 0 <= alpha <= 1
-                           if ((unsigned)t >= (unsigned)g.T || f >= g.F) v = zero4();               // zero padding of the next layer
-                           *reinterpret_cast<bf16x4*>(out + (t - torg) * RS + bin_off(f + 2)) = to_bf16(v);
+                           if (!ok) v = zero4();                                                    // zero padding of the next layer
+                           *reinterpret_cast<bf16x4*>(out + (tc - torg) * RS + px) = to_bf16(v);
                        });
-            __syncthreads();
+            stamp(a.dbg, 2 + l);
+            lds_barrier();
         }
         store_rows_plain<NT>((L & 1) ? P1 : P0, torg, a.a_last, g, b, t0);
-        __syncthreads();
+        lds_barrier();
+        stamp(a.dbg, 12);
+        a.dbg = nullptr;           // stamps: the first tile of a workgroup only
     }
 }
 
@@ -383,6 +489,7 @@ struct BwdArgs {
     float* partials;                           // MODE_BWD: [L][gridDim][NPART]
     int cin0;                                  // input channels of the first layer (1)
     Geo g; size_t lds_bytes;
+    unsigned long long* dbg;
 };
 
 constexpr int MODE_BWD = 0, MODE_DATA = 1;
@@ -430,7 +537,13 @@ __global__ __launch_bounds__(NT) void chain_bwd_kernel(BwdArgs a) {
     const int L = g.L;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    stamp(a.dbg, 0);
     lds_init<NT>(lds, a.lds_bytes, a.tab, nullptr, L, 1);
+    stamp(a.dbg, 1);
+    LaneOff lo;
+    lo.init(lane);
+    RowStore<WG ? NT * 64 : NT> rs;         // (the weight-gradient kernel stores no rows: no slots)
+    if (!WG) rs.init(g);
     const u16* zero = lds + HDR_ZERO / 2;
     float* bsl = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + HDR_BS);      // [LMAX][NW][4]
     // d_l valid on t0 -+ ext(l): MODE_BWD 2 (l - 1), MODE_DATA 2 l
@@ -466,11 +579,12 @@ __global__ __launch_bounds__(NT) void chain_bwd_kernel(BwdArgs a) {
                 xp.commit(A0, RA);
             }
         }
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < LMAX; ++s) {
+        lds_barrier();
+        stamp(a.dbg, 2);
+#pragma unroll 1
+        for (int s = 0; s < L; ++s) {
             const int l = L - s;                       // this step's layer
-            if (l >= 1) {
+            {
                 const u16* Dc = (s & 1) ? D1 : D0;
                 u16* Dn = (s & 1) ? D0 : D1;
                 const u16* Ac = (s & 1) ? A1 : A0;
@@ -478,44 +592,46 @@ __global__ __launch_bounds__(NT) void chain_bwd_kernel(BwdArgs a) {
                 // the map of the next step: a_{l-2} (l - 2 >= 1: a padded map; l == 2: the stack's input, for the first layer's dW)
                 if (l >= 3) mp.load(a.maps + (long long)(l - 3) * g.map_stride, g, b, aorg, RA);
                 else if (l == 2 && WG) xp.load(a.x0, a.ldx, g, b, t0 - 2, TR + 4);        // rows t0 - 2 .. t0 + TR + 2 of the input
-                if (!WG && a.gmaps) store_rows_padded<NT>(Dc, dorg, a.gmaps + (long long)(l - 1) * g.map_stride, g, b, t0);
-                if (WG && wave < KT)
-                    dw_step(acc[s][0], acc[s][1], Ac + (t0 + wave - 2 - aorg) * RS, Dc + (t0 - dorg) * RS, g.ng, zero, lane);
+                if (!WG && a.gmaps) rs.run(Dc + (t0 - dorg) * RS, a.gmaps + (long long)(l - 1) * g.map_stride + (long long)(b * g.T + t0) * g.FP * C, min(TR, g.T - t0));
+                if (WG && wave < KT) {
+                    f32x4 c0 = zero4(), c1 = zero4();
+                    dw_step(c0, c1, Ac + (t0 + wave - 2 - aorg) * RS, Dc + (t0 - dorg) * RS, g.ng, zero, lane);
+                    acc_add(acc, s, c0, c1);
+                }
                 if (l >= 2 || !WG) {
                     bf16x8 af[KT];
                     load_afrag(lds + (l - 1) * TLAY, lane, af);
                     const int ext = WG ? 2 * (l - 2) : 2 * (l - 1);
                     const int ta = t0 - ext, tb = t0 + TR + ext;
-                    const int nunits = ((tb - ta + 15) >> 4) * g.ng;
-                    int first = wave, end = nunits, stride = NW;
-                    if (WG) split_units<NW>(nunits, wave, first, end, stride);
                     if (l >= 2) {
                         f32x4 bs = zero4();
-                        conv_units(Dc, dorg, af, ta, tb, g, first, end, stride, lane, zero4(),
-                                   [&](int t, int f) { return *reinterpret_cast<const bf16x4*>(Ac + (t - aorg) * RS + bin_off(f + 2)); },
-                                   [&](int t, int f, f32x4 v, bf16x4 mk, bool fresh) {
+                        conv_chunks<NW, WG, WG>(Dc, dorg, af, ta, tb, g, wave, s, lo, zero4(),
+                                   [&](int tc, int, int, int px) { return *reinterpret_cast<const bf16x4*>(Ac + (tc - aorg) * RS + px); },
+                                   [&](int tc, int t, int, int px, f32x4 v, bf16x4 mk, bool ok, bool fresh) {
                                        const f32x4 m = to_f32(mk);
 #pragma unroll
                                        for (int e = 0; e < 4; ++e) v[e] = v[e] * (m[e] > 0.f ? 1.f : g.alpha);
-                                       if ((unsigned)t >= (unsigned)g.T || f >= g.F) v = zero4();
+                                       if (!ok) v = zero4();
                                        if (WG && fresh && t >= t0 && t < t0 + TR) bs += v;
-                                       *reinterpret_cast<bf16x4*>(Dn + (t - dorg) * RS + bin_off(f + 2)) = to_bf16(v);
+                                       *reinterpret_cast<bf16x4*>(Dn + (tc - dorg) * RS + px) = to_bf16(v);
                                    });
                         if (WG) wave_add4(bsl + ((l - 2) * NW + wave) * 4, bs, lane);
                     } else if (a.g0) {
                         // d/dx0: channel 0 of the transposed first layer, own rows, straight to HBM
-                        conv_units(Dc, dorg, af, t0, t0 + TR, g, first, end, stride, lane, zero4(),
-                                   [](int, int) { return 0; },
-                                   [&](int t, int f, f32x4 v, int, bool) {
-                                       if (t < g.T && f < g.F) a.g0[(long long)(b * g.T + t) * g.F + f] = v[0];
+                        conv_chunks<NW, false, false>(Dc, dorg, af, t0, t0 + TR, g, wave, s, lo, zero4(),
+                                   [](int, int, int, int) { return 0; },
+                                   [&](int, int t, int f, int, f32x4 v, int, bool ok, bool) {
+                                       if (ok) a.g0[(long long)(b * g.T + t) * g.F + f] = v[0];
                                    });
                     }
                 }
                 if (l >= 3) mp.commit(An, RA);
                 else if (l == 2 && WG) xp.commit(An + (EXTA - 2) * RS, TR + 4);
-                __syncthreads();
+                lds_barrier();
+                stamp(a.dbg, 3 + s);
             }
         }
+        a.dbg = nullptr;
     }
     if (!WG) return;
     // ---- one reduction per workgroup, fixed order: red[s][kt][hb][r][lane]
@@ -569,6 +685,7 @@ struct SecArgs {
     float* partials;
     int cin0;
     Geo g; size_t lds_bytes;
+    unsigned long long* dbg;
 };
 
 template <int NT>
@@ -579,7 +696,11 @@ __global__ __launch_bounds__(NT) void chain_second_kernel(SecArgs a) {
     const int L = g.L;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    stamp(a.dbg, 0);
     lds_init<NT>(lds, a.lds_bytes, a.tab, nullptr, L, 0);
+    stamp(a.dbg, 1);
+    LaneOff lo;
+    lo.init(lane);
     const u16* zero = lds + HDR_ZERO / 2;
     const int RU = TR + 4 * L;
     u16* U0 = lds + HDR_BYTES / 2;
@@ -603,50 +724,53 @@ __global__ __launch_bounds__(NT) void chain_second_kernel(SecArgs a) {
             xp.commit(U0, RU);
             mp.commit(G0, TR);
         }
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < LMAX; ++s) {
+        lds_barrier();
+        stamp(a.dbg, 2);
+#pragma unroll 1
+        for (int s = 0; s < L; ++s) {
             const int l = s + 1;
-            if (l <= L) {
+            {
                 const u16* Uc = (s & 1) ? U1 : U0;
                 u16* Un = (s & 1) ? U0 : U1;
                 const u16* Gc = (s & 1) ? G1 : G0;
                 u16* Gn = (s & 1) ? G0 : G1;
                 if (l < L) mp.load(a.gmaps + (long long)l * g.map_stride, g, b, t0, TR);
-                if (wave < KT) dw_step(acc[s][0], acc[s][1], Uc + (t0 + wave - 2 - uorg) * RS, Gc, g.ng, zero, lane);
+                if (wave < KT) {
+                    f32x4 c0 = zero4(), c1 = zero4();
+                    dw_step(c0, c1, Uc + (t0 + wave - 2 - uorg) * RS, Gc, g.ng, zero, lane);
+                    acc_add(acc, s, c0, c1);
+                }
                 bf16x8 af[KT];
                 load_afrag(lds + (l - 1) * TLAY, lane, af);
                 const int ext = 2 * (L - l);
                 const int ta = t0 - ext, tb = t0 + TR + ext;
-                const int nunits = ((tb - ta + 15) >> 4) * g.ng;
-                int first, end, stride;
-                split_units<NW>(nunits, wave, first, end, stride);
                 const bool last = l == L;
                 const u16* am = last ? a.a_last : a.maps + (long long)(l - 1) * g.map_stride;
                 const int apitch = last ? g.F : g.FP;
-                conv_units(Uc, uorg, af, ta, tb, g, first, end, stride, lane, zero4(),
-                           [&](int t, int f) {
+                conv_chunks<NW, true, true>(Uc, uorg, af, ta, tb, g, wave, s, lo, zero4(),
+                           [&](int, int t, int f, int) {
                                bf16x4 m = to_bf16(zero4());
                                if ((unsigned)t < (unsigned)g.T && f < g.F) m = *reinterpret_cast<const bf16x4*>(am + ((long long)(b * g.T + t) * apitch + f) * C);
                                return m;
                            },
-                           [&](int t, int f, f32x4 v, bf16x4 mk, bool) {
+                           [&](int tc, int t, int f, int px, f32x4 v, bf16x4 mk, bool ok, bool) {
                                const f32x4 m = to_f32(mk);
 #pragma unroll
                                for (int e = 0; e < 4; ++e) v[e] = v[e] * (m[e] > 0.f ? 1.f : g.alpha);
-                               const bool in = (unsigned)t < (unsigned)g.T && f < g.F;
-                               if (!in) v = zero4();
-                               if (!last) *reinterpret_cast<bf16x4*>(Un + (t - uorg) * RS + bin_off(f + 2)) = to_bf16(v);
-                               else if (in) {
+                               if (!ok) v = zero4();
+                               if (!last) *reinterpret_cast<bf16x4*>(Un + (tc - uorg) * RS + px) = to_bf16(v);
+                               else if (ok) {
                                    const long long off = ((long long)(b * g.T + t) * g.F + f) * C;
                                    if (a.out_bf16) *reinterpret_cast<bf16x4*>(reinterpret_cast<u16*>(a.out) + off) = to_bf16(v);
                                    else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + off) = v;
                                }
                            });
                 if (l < L) mp.commit(Gn, TR);
-                __syncthreads();
+                lds_barrier();
+                stamp(a.dbg, 3 + s);
             }
         }
+        a.dbg = nullptr;
     }
     float* red = reinterpret_cast<float*>(lds + HDR_BYTES / 2);
     if (wave < KT) {
@@ -688,12 +812,17 @@ using namespace ptts::c2c;
 
 namespace {
 constexpr int NT = 512;
+// threads of the kernels without weight-gradient accumulators (forward, backward data): 512 or 1024 (PTTS_CHAIN_NT)
+int wide_nt() {
+    static int nt = -1;
+    if (nt < 0) { const char* e = getenv("PTTS_CHAIN_NT"); nt = (e && atoi(e) == 1024) ? 1024 : 512; }
+    return nt;
+}
 
 bool make_geo(Geo& g, int B, int T, int F, int L, float alpha) {
     g.B = B; g.T = T; g.F = F; g.FP = (F + 1) & ~1; g.L = L; g.ng = (F + 3) / 4;
     g.ntt = (T + TR - 1) / TR;
     g.ntiles = B * g.ntt;
-    g.magic_ng = (65536u + (unsigned)g.ng - 1) / (unsigned)g.ng;
     const unsigned upr = (unsigned)(g.FP / 2);
     g.magic_fp2 = upr > 1 ? (unsigned)(((1ULL << 32) + upr - 1) / upr) : 0u;
     g.alpha = alpha;
@@ -721,6 +850,9 @@ void set_lds(K kernel) {
 extern "C" int ptts_conv2d_chain_supported(int F, int L, int Cin0, int Cc, int KT_, int KF_) {
     return (F >= 2 && F <= 4 * NGMAX && L >= 1 && L <= LMAX && Cin0 >= 1 && Cin0 <= 4 && Cc == 4 && KT_ == 5 && KF_ == 5) ? 1 : 0;
 }
+
+// measurement hook: a buffer of 256 x 32 uint64 that receives the phase stamps of the next launches (NULL: off)
+extern "C" int ptts_conv2d_chain_debug(void* stamp_buf) { g_dbg = (unsigned long long*)stamp_buf; return PTTS_OK; }
 
 extern "C" size_t ptts_conv2d_chain_tables_bytes(void) { return TAB_BYTES; }
 extern "C" size_t ptts_conv2d_chain_partials_bytes(int L) { return (size_t)L * NCU * NPART * sizeof(float); }
@@ -751,13 +883,14 @@ extern "C" int ptts_conv2d_chain_fwd(const float* x0, long long ldx, const void*
     FwdArgs a;
     make_geo(a.g, B, T, F, L, alpha);
     a.x0 = x0; a.ldx = ldx; a.tab = (const u16*)tables; a.bias = reinterpret_cast<const float*>((const char*)tables + TAB_BIAS_OFF);
-    a.maps = (u16*)maps; a.a_last = (u16*)a_last;
+    a.maps = (u16*)maps; a.a_last = (u16*)a_last; a.dbg = g_dbg;
     a.lds_bytes = HDR_BYTES + (size_t)2 * (TR + 4 * L) * RS * sizeof(u16);
     PTTS_REQUIRE(a.lds_bytes <= LDS_MAX, "conv2d_chain_fwd: tiles do not fit the LDS");
     static bool attr = false;
-    if (!attr) { set_lds(&chain_fwd_kernel<NT>); attr = true; }
+    if (!attr) { set_lds(&chain_fwd_kernel<512>); set_lds(&chain_fwd_kernel<1024>); attr = true; }
     const int grid = std::min(a.g.ntiles, NCU);
-    hipLaunchKernelGGL(chain_fwd_kernel<NT>, dim3(grid), dim3(NT), a.lds_bytes, (hipStream_t)stream, a);
+    if (wide_nt() == 1024) hipLaunchKernelGGL(chain_fwd_kernel<1024>, dim3(grid), dim3(1024), a.lds_bytes, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(chain_fwd_kernel<512>, dim3(grid), dim3(512), a.lds_bytes, (hipStream_t)stream, a);
     return check_launch("conv2d_chain_fwd");
 }
 
@@ -776,7 +909,7 @@ extern "C" int ptts_conv2d_chain_bwd(const void* d_last, int d_bf16, const float
     const int grid = std::min(a.g.ntiles, NCU);
     if (partials_bytes < (size_t)L * grid * NPART * sizeof(float)) { set_error("conv2d_chain_bwd: partials buffer too small"); return PTTS_EWORKSPACE; }
     a.d_last = d_last; a.d_bf16 = d_bf16; a.x0 = x0; a.ldx = ldx; a.maps = (const u16*)maps; a.a_last = (const u16*)a_last;
-    a.tab = (const u16*)tables; a.gmaps = nullptr; a.g0 = nullptr; a.partials = partials; a.cin0 = cin0;
+    a.tab = (const u16*)tables; a.gmaps = nullptr; a.g0 = nullptr; a.partials = partials; a.cin0 = cin0; a.dbg = g_dbg;
     const int EXTD = 2 * (L - 1), EXTA = std::max(2 * (L - 2), 2);
     a.lds_bytes = HDR_BYTES + (size_t)(2 * (TR + 2 * EXTD) + 2 * (TR + 2 * EXTA)) * RS * sizeof(u16);
     a.lds_bytes = std::max(a.lds_bytes, (size_t)HDR_BYTES + (size_t)LMAX * KT * 2 * 4 * 64 * sizeof(float));
@@ -798,14 +931,15 @@ extern "C" int ptts_conv2d_chain_bwd_data(const void* d_last, int d_bf16, const 
     BwdArgs a;
     make_geo(a.g, B, T, F, L, alpha);
     a.d_last = d_last; a.d_bf16 = d_bf16; a.x0 = nullptr; a.ldx = 0; a.maps = (const u16*)maps; a.a_last = (const u16*)a_last;
-    a.tab = (const u16*)tables; a.gmaps = (u16*)gmaps; a.g0 = g0; a.partials = nullptr; a.cin0 = 1;
+    a.tab = (const u16*)tables; a.gmaps = (u16*)gmaps; a.g0 = g0; a.partials = nullptr; a.cin0 = 1; a.dbg = g_dbg;
     const int EXTD = 2 * L, EXTA = 2 * (L - 1);
     a.lds_bytes = HDR_BYTES + (size_t)(2 * (TR + 2 * EXTD) + 2 * (TR + 2 * EXTA)) * RS * sizeof(u16);
     PTTS_REQUIRE(a.lds_bytes <= LDS_MAX, "conv2d_chain_bwd_data: tiles do not fit the LDS");
     static bool attr = false;
-    if (!attr) { set_lds(&chain_bwd_kernel<NT, MODE_DATA>); attr = true; }
+    if (!attr) { set_lds(&chain_bwd_kernel<512, MODE_DATA>); set_lds(&chain_bwd_kernel<1024, MODE_DATA>); attr = true; }
     const int grid = std::min(a.g.ntiles, NCU);
-    hipLaunchKernelGGL((chain_bwd_kernel<NT, MODE_DATA>), dim3(grid), dim3(NT), a.lds_bytes, (hipStream_t)stream, a);
+    if (wide_nt() == 1024) hipLaunchKernelGGL((chain_bwd_kernel<1024, MODE_DATA>), dim3(grid), dim3(1024), a.lds_bytes, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((chain_bwd_kernel<512, MODE_DATA>), dim3(grid), dim3(512), a.lds_bytes, (hipStream_t)stream, a);
     return check_launch("conv2d_chain_bwd_data");
 }
 
@@ -823,7 +957,7 @@ extern "C" int ptts_conv2d_chain_second(const float* u0, const void* gmaps, cons
     const int grid = std::min(a.g.ntiles, NCU);
     if (partials_bytes < (size_t)L * grid * NPART * sizeof(float)) { set_error("conv2d_chain_second: partials buffer too small"); return PTTS_EWORKSPACE; }
     a.u0 = u0; a.gmaps = (const u16*)gmaps; a.maps = (const u16*)maps; a.a_last = (const u16*)a_last; a.tab = (const u16*)tables;
-    a.out = out; a.out_bf16 = out_bf16; a.partials = partials; a.cin0 = cin0;
+    a.out = out; a.out_bf16 = out_bf16; a.partials = partials; a.cin0 = cin0; a.dbg = g_dbg;
     a.lds_bytes = HDR_BYTES + (size_t)(2 * (TR + 4 * L) + 2 * TR) * RS * sizeof(u16);
     a.lds_bytes = std::max(a.lds_bytes, (size_t)HDR_BYTES + (size_t)LMAX * KT * 2 * 4 * 64 * sizeof(float));
     PTTS_REQUIRE(a.lds_bytes <= LDS_MAX, "conv2d_chain_second: tiles do not fit the LDS");
