@@ -301,7 +301,7 @@ class Conv2DStack(Layer):
         x0 = to_tensor(vals[0])
         ws, bs = self.kernels()
         if x0.is_cuda and ops._C2C.supported(x0.shape[-1], ws):
-            return ops.conv2d_chain(x0, ws, bs, self.alpha)
+            return ops.conv2d_chain(x0, ws, bs, self.alpha).float()
         # shapes without a chain kernel (F > 68): layer by layer on the one-plane matrix-core / stencil kernels
         v = x0.reshape(x0.shape[0], x0.shape[1], x0.shape[2], 1)
         for li, (w, b) in enumerate(zip(ws, bs)):

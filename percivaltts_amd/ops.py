@@ -598,10 +598,16 @@ class Conv2dFn(torch.autograd.Function):
         # persistent gradient buffers of kernel / bias (deferred, grouped reduction of the backward's partial sums)
         ctx.gw = grad_target(w) if _Deferred.active else None
         ctx.gb = grad_target(b) if (_Deferred.active and b is not None) else None
+        ctx.set_materialize_grads(False)
         return _conv2d_fwd_raw(x, w, b, scale, shift, None, mode, alpha, dil_t, pad_mode, ctx.planes, bf16 == 'out16')
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            # no gradient arrives: the node is reachable only as the MASK operand of a backward-data Function of the gradient
+            # penalty (x_hat's evaluation, whose own output is not part of the loss).  Materialised zeros would run this
+            # layer's whole first-order backward -- dx and dW launches that add zeros -- once per critic step.
+            return (None,) * 10
         x, w, scale, shift = ctx.saved_tensors
         mode, alpha, dil_t, pad_mode = ctx.cfg
         planes = ctx.planes
@@ -647,6 +653,7 @@ class Conv2dBwdDataFn(torch.autograd.Function):
         ctx.cfg = (mode, alpha, dil_t, pad_mode)
         ctx.gw = gw
         ctx.planes = planes
+        ctx.set_materialize_grads(False)
         dx, _, _, _, _ = _conv2d_bwd_raw(dy, x, w, None, None, None, mode, alpha, dil_t, pad_mode,
                                          True, False, False, False, planes)
         return dx
@@ -654,6 +661,8 @@ class Conv2dBwdDataFn(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, u):
+        if u is None:
+            return (None,) * 9
         dy, x, w = ctx.saved_tensors
         mode, alpha, dil_t, pad_mode = ctx.cfg
         planes = ctx.planes
@@ -775,11 +784,15 @@ class Conv2dChainFn(torch.autograd.Function):
         ctx.save_for_backward(x0, maps, a_last, tab, *ws)
         ctx.alpha, ctx.L, ctx.has_b = alpha, L, [b is not None for b in bs]
         ctx.gws, ctx.gbs = _chain_defer_targets(ws, bs)
+        ctx.set_materialize_grads(False)
         return a_last
 
     @staticmethod
     def backward(ctx, d_last):
+        if d_last is None:           # nothing flows back (e.g. the node is reachable only through a mask operand)
+            return (None,) * (2 + 2 * ctx.L)
         x0, maps, a_last, tab = ctx.saved_tensors[:4]
+        a_last = a_last.detach()     # an operand of the backward kernels, not a path of the graph: piecewise-constant masks
         ws = list(ctx.saved_tensors[4:])
         L, alpha = ctx.L, ctx.alpha
         B, T, F = x0.shape
@@ -830,11 +843,14 @@ class Conv2dChainBwdDataFn(torch.autograd.Function):
         ctx.save_for_backward(gmaps, maps, a_last, tab, *ws)
         ctx.cfg = (alpha, L, cin0, d_last.dtype)
         ctx.gws = gws
+        ctx.set_materialize_grads(False)
         return g0
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, u0):
+        if u0 is None:
+            return (None,) * (6 + len(ctx.saved_tensors) - 4)
         gmaps, maps, a_last, tab = ctx.saved_tensors[:4]
         ws = list(ctx.saved_tensors[4:])
         alpha, L, cin0, d_dtype = ctx.cfg
@@ -899,10 +915,13 @@ class DenseFn(torch.autograd.Function):
         # persistent gradient buffers of the kernel / bias (for the deferred, grouped weight-gradient launch)
         ctx.gw = grad_target(w) if _Deferred.active else None
         ctx.gb = grad_target(b) if (_Deferred.active and b is not None) else None
+        ctx.set_materialize_grads(False)
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:               # see Conv2dFn.backward
+            return (None,) * 7
         x, w, scale, shift = ctx.saved_tensors
         mode, alpha = ctx.cfg
         K, N = w.shape
@@ -951,12 +970,15 @@ class DenseBwdDataFn(torch.autograd.Function):
         ctx.save_for_backward(dy, x, w)
         ctx.cfg = (mode, alpha)
         ctx.gw = gw                      # the kernel's persistent gradient buffer (deferred grouped launch), or None
+        ctx.set_materialize_grads(False)
         dx2, _, _ = _dense_bwd_data(dy.view(M, N), x.view(M, K), w, mode, None, None, alpha, False)
         return dx2.view(x.shape)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, u):
+        if u is None:
+            return (None,) * 6
         dy, x, w = ctx.saved_tensors
         mode, alpha = ctx.cfg
         K, N = w.shape

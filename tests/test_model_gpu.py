@@ -387,8 +387,12 @@ def test_split_hipgraph_recomputes_every_weight_derived_operand():
         ops.deterministic(False)
 
 
-def test_bf16_storage_critic_conv_stack():
-    """BASELINE configs[2] (build extension; the reference is fp32, README.md:166): cfg.arch_critic_bf16 keeps the maps between
+@pytest.mark.parametrize('form', ['chain', 'layers'])
+def test_bf16_storage_critic_conv_stack(form):
+    """BASELINE configs[2] (build extension; the reference is fp32, README.md:166).  form 'chain' (cfg.arch_critic_bf16 = True):
+    the WHOLE Conv2D stack per launch with the maps between the layers in the LDS (kl.Conv2DStack -> csrc/conv2d_chain.hip),
+    every kernel and every layer's post-activation map in bf16; oracle.critic_forward(bf16_stack='chain') has those roundings.
+    form 'layers' (cfg.arch_critic_bf16 = 'layers', the round-2 path): cfg.arch_critic_bf16 keeps the maps between
     the critic's 4 -> 4 channel Conv2D layers, and their gradients, as bf16 in HBM and multiplies in bf16 on the matrix cores
     with fp32 accumulation; master weights, weight gradients, the first layer and everything outside the stack stay fp32.
     Oracle: fp64 with the same roundings (oracle.bf16_st: activation after the LeakyReLU, the kernel's bf16 copy, the stored
@@ -404,7 +408,8 @@ def test_bf16_storage_critic_conv_stack():
     cfg.arch_hiddenwidth = g['H']; cfg.arch_ctx_nbcnnlayers = g['nctx']; cfg.arch_ctx_winlen = g['kctx']
     cfg.arch_gen_nbcnnlayers = g['L']; cfg.arch_gen_nbfilters = g['C']; cfg.arch_gen_winlen = g['kt']
     cfg.arch_spec_freqlen = g['kf']; cfg.train_batch_size = g['B']
-    cfg.arch_critic_bf16 = True
+    cfg.arch_critic_bf16 = True if form == 'chain' else 'layers'
+    omode = 'chain' if form == 'chain' else True
     voc = vocoders.VocoderPML(16000, 0.005, g['spec'], g['nm'])
     mod = modeltts_common.DCNNF0SpecNoiseFeatures(g['ctx'], voc, cfg)
     crit = networks_critic.Critic(voc, g['ctx'], cfg)
@@ -419,15 +424,22 @@ def test_bf16_storage_critic_conv_stack():
     opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype='WLSWGAN', critic=crit)
     opt.prepare()
     from percivaltts_amd import layers as kl
-    modes = [l.bf16 for l in crit.model.layers_list if isinstance(l, kl.Conv2D)]
-    assert modes == [None] + ['out16'] * 6 + ['out32'], modes
+    if form == 'layers':
+        modes = [l.bf16 for l in crit.model.layers_list if isinstance(l, kl.Conv2D)]
+        assert modes == [None] + ['out16'] * 6 + ['out32'], modes
+    else:
+        assert sum(isinstance(l, kl.Conv2DStack) for l in crit.model.layers_list) == 1
+        assert [tuple(w.shape) for w in crit.model.get_weights()] == [tuple(w.shape) for w in cw]
     Xd, Yd, ald = f32(X), f32(Y), f32(al)
 
     # ---- forward
     with torch.no_grad(), ops._hip.KernelTimer() as kt:
         v = crit.model(Yd, Xd, training=False)
-    assert sum(1 for r in kt.records if r[0] == 'ptts_conv2d_mfma_fwd' and r[1][-1] == 1) == 7      # one-plane kernels
-    v16 = O.critic_forward(cw, a, Y, X, bf16_stack=True)
+    if form == 'layers':
+        assert sum(1 for r in kt.records if r[0] == 'ptts_conv2d_mfma_fwd' and r[1][-1] == 1) == 7      # one-plane kernels
+    else:
+        assert [r[0] for r in kt.records if r[0].startswith('ptts_conv2d')] in (['ptts_conv2d_chain_fwd'], ['ptts_conv2d_chain_tables', 'ptts_conv2d_chain_fwd'])
+    v16 = O.critic_forward(cw, a, Y, X, bf16_stack=omode)
     v32 = O.critic_forward(cw, a, Y, X)
     scale = float(v16.abs().mean())
     assert float((v.double().cpu() - v16).abs().max()) < 2.0 ** -7 * max(scale, float(v16.abs().max())), 'critic forward vs bf16 oracle'
@@ -436,12 +448,17 @@ def test_bf16_storage_critic_conv_stack():
 
     # ---- critic step: loss parts and gradients (first and second order through the bf16 maps)
     for w in cw: w.requires_grad_(True)
-    total, parts = O.critic_step_loss(cw, gw, a, X, Y, al, gp_lambda=10.0, bf16_stack=True)
+    total, parts = O.critic_step_loss(cw, gw, a, X, Y, al, gp_lambda=10.0, bf16_stack=omode)
     grads = torch.autograd.grad(total, cw)
     opt.critic_opti.zero_grad()
-    with ops.deferred_weight_grads():
+    with ops.deferred_weight_grads(), ops._hip.KernelTimer() as kt2:
         tot_d, (lv, lf, gp) = opt.critic_loss(Xd, Yd, ald, training=True)
         tot_d.backward()
+    if form == 'chain':
+        names = [r[0] for r in kt2.records if r[0].startswith('ptts_conv2d_chain')]
+        # forward of the stacked real+fake pass and of x_hat, backward-data + gamma maps of the gradient penalty, its second-order
+        # sweep, and ONE weight-gradient chain for the stacked pass
+        assert sorted(n for n in names if n != 'ptts_conv2d_chain_tables') == sorted(['ptts_conv2d_chain_fwd'] * 2 + ['ptts_conv2d_chain_bwd_data', 'ptts_conv2d_chain_second', 'ptts_conv2d_chain_bwd']), names
     close(lv, parts['valid'], 5e-3, 1e-4, 'L valid (bf16)')
     close(lf, parts['fake'], 5e-3, 1e-4, 'L fake (bf16)')
     close(gp, parts['gp'], 2e-2, 1e-4, 'gradient penalty (bf16)')
