@@ -8,7 +8,7 @@ Workload at N=1 is BASELINE.json configs[1]: [64,400,601] -> [64,400,86] (f0 1 +
 64-sample shard (weak scaling, global batch 64*N) and the flat gradients are all-reduced over RCCL.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline       dominant kernel (the context-Conv1D implicit GEMM on the fp32 MFMA pipe), HIP-event timed here
+  roofline       dominant kernel (the context Conv1D as a bf16x6 split product on the bf16 matrix cores: gemm_bf16x6_kernel), HIP-event timed here
   roofline_conv2d the critic's 2D-conv stack against the HBM roofline, algorithmic bytes of SURVEY.md 8(d)
   cpu_baseline   the CPU oracle (PyTorch-CPU fp32 restatement of the reference path) on a bounded sample
 """
@@ -59,6 +59,7 @@ def parse():
     ap.add_argument('--no-variants', action='store_true', help='skip the extra timed loop of the fp32-MFMA context-Conv1D variant')
     ap.add_argument('--no-host-leg', action='store_true', help='skip the PCIe-inclusive leg (host batches through the prefetcher)')
     ap.add_argument('--cpu-batch', type=int, default=32)
+    ap.add_argument('--side-legs', action='store_true', help='with --gpus N > 1: also run the side legs (variants, reference shape, bf16, gated, host-fed); by default a multi-GPU run prints the headline loop, the two step times and the all-reduce times only')
     return ap.parse_args()
 
 
@@ -205,7 +206,7 @@ def roofline_leg(opt, X, Y, args):
     # (summed per repetition: the call list of the first one may hold a refresh of cached operands the others do not)
     t_conv2d = sum(sum(d for (nm, _, d) in r if nm.startswith('ptts_conv2d')) for r in crit_recs) / reps * 1e-3
     n_conv2d = sum(1 for (nm, _, _) in crit_recs[-1] if nm.startswith('ptts_conv2d'))
-    bf16_stack = bool(getattr(opt.cfg, 'arch_critic_bf16', False))
+    bf16_stack = getattr(opt.cfg, 'arch_critic_bf16', False)
     # (149 C + 3) B T F s bytes per critic step, s = 4 (configs[1], fp32) or 2 (configs[2], every map bf16)
     alg_bytes = (149.0 * C + 3.0) * B * T * F * (2.0 if bf16_stack else 4.0) if L == 8 else None
     if alg_bytes and t_conv2d > 0:
@@ -213,7 +214,9 @@ def roofline_leg(opt, X, Y, args):
                                   'achieved': alg_bytes / t_conv2d / 1e9, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
                                   'frac': alg_bytes / t_conv2d / 1e9 / PEAK_HBM_GBPS, 'traffic': None,
                                   'algorithmic_bytes_per_critic_step': alg_bytes, 'time_ms': t_conv2d * 1e3,
-                                  'maps': ('bf16 between the 4->4 layers (6 of 8 maps and their gradients), fp32 at both ends of the stack' if bf16_stack else 'fp32')}
+                                  'maps': (('bf16, every layer (post-activation), held in the LDS between the layers of a launch: conv2d_chain kernels' if bf16_stack is True else
+                                            'bf16 between the 4->4 layers (6 of 8 maps and their gradients), fp32 at both ends of the stack') if bf16_stack else 'fp32'),
+                                  'launches': sorted(set(nm for (nm, _, _) in crit_recs[-1] if nm.startswith('ptts_conv2d')))}
     out['critic_step_kernel_ms'] = {k: round(v, 4) for k, v in sorted(classes.items(), key=lambda kv: -kv[1])}
     # HBM(+Infinity-Cache) bytes per launch from the separate rocprofv3 PMC passes of the same kernels
     # (tools/profile_round.sh -> tools/summarize_profiles.py -> profiles/<round>_traffic.json; FETCH_SIZE x2 + WRITE_SIZE)
@@ -243,6 +246,7 @@ def build_optimizer(args, ctx, spec, nm, batch, errtype, gated=False, bf16=None)
     cfg = make_cfg(args)
     cfg.train_batch_size = batch
     cfg.arch_critic_bf16 = (args.dtype == 'bf16') if bf16 is None else bool(bf16)
+    cfg.train_wgan_bf16_products = bool(cfg.arch_critic_bf16)      # configs[2]: bf16 products in the GEMM-shaped layers as well
     if gated:       # BASELINE configs[4]: pGCNN2D spectral branch, time dilations 1,2,4,8,1,2,4,8, causal padding
         cfg.arch_gen_gated = True; cfg.arch_gen_dilations = [1, 2, 4, 8]; cfg.arch_gen_causal = True
     cfg.train_wgan_hipgraph = bool(args.graph) and int(os.environ.get('WORLD_SIZE', '1')) <= 1
@@ -314,6 +318,10 @@ def main():
 
     world, rank = parallel.init()
     dev = backend_hip.device()
+    if world > 1 and not args.side_legs:
+        # the first real multi-GPU run should print its line quickly: no side legs (each builds optimisers of its own with their
+        # own broadcasts / all-reduces) -- `--side-legs` brings them back
+        args.no_variants = args.no_unreduced = args.no_host_leg = args.no_reference_shape = args.no_bf16_leg = args.no_gated_leg = True
     spec, nm = 65, 20
     cfg, voc, mod, crit, opt = build_optimizer(args, args.ctx, spec, nm, args.batch, args.errtype)
     par_streams = bool(cfg.train_wgan_parallel_streams)
@@ -363,6 +371,20 @@ def main():
     use_graph = bool(cfg.train_wgan_hipgraph)
     extra['critic_step_ms'] = timeit((lambda: opt._graphed('critic', X, Y)) if use_graph else (lambda: opt.critic_step(X, Y)), 10)
     extra['generator_step_ms'] = timeit((lambda: opt._graphed('generator', X, Y)) if use_graph else (lambda: opt.generator_step(X, Y)), 5)
+    if world > 1:
+        # the two exchanges of a cycle, timed on their own (HIP events on the launch stream, max over ranks): all-reduce (sum) of
+        # the flat fp32 gradient bucket of each network
+        import torch.distributed as dist
+        def ar_ms(t, n=10):
+            parallel.allreduce_sum_(t); torch.cuda.synchronize(); parallel.barrier()
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record()
+            for _ in range(n): parallel.allreduce_sum_(t)
+            e_.record(); torch.cuda.synchronize()
+            return parallel.max_over_ranks(s_.elapsed_time(e_) / n, dev)
+        gc, gg = torch.zeros_like(opt.critic_opti.flat.grad), torch.zeros_like(opt.gen_opti.flat.grad)
+        extra['allreduce_ms'] = {'critic_grads': ar_ms(gc), 'generator_grads': ar_ms(gg), 'critic_bytes': gc.numel() * 4, 'generator_bytes': gg.numel() * 4,
+                                 'backend': dist.get_backend(), 'what': 'all-reduce(sum) of one flat fp32 gradient bucket per network, max over ranks'}
     if not args.no_roofline:
         extra.update(roofline_leg(opt, X, Y, args))
         opt.cfg.train_wgan_parallel_streams = par_streams
@@ -438,7 +460,7 @@ def main():
             'config': {'workload': 'BASELINE configs[{n}]: synthetic [{b},{t},{c}]->[{b},{t},{o}] (f0 1 + spec 65 + noise 20), DCNN generator + '
                                    '2D-conv critic, {d}, {e}, lambda=10, schedule 5 critic steps : 1 generator step; '
                                    'step = one train_on_batch'.format(n=2 if args.dtype == 'bf16' else 1, b=B, t=T, c=args.ctx, o=voc.featuressize(), e=args.errtype,
-                                                                      d='bf16 maps in the critic conv stack (fp32 elsewhere)' if args.dtype == 'bf16' else 'fp32'),
+                                                                      d='bf16 (see config.bf16)' if args.dtype == 'bf16' else 'fp32'),
                        'per_gpu_batch': B, 'global_batch': B * world, 'frames_per_step_per_gpu': B * T,
                        'parallelism': 'dp{}'.format(world), 'hipgraph': bool(cfg.train_wgan_hipgraph),
                        'hip_streams': 3 if par_streams else 1,
@@ -446,7 +468,9 @@ def main():
                        'stack_real_fake_critic_pass': bool(cfg.train_wgan_stack_real_fake),
                        'reuse_generator_ctx_conv_within_train_on_batch': bool(cfg.train_wgan_reuse_ctx_conv),
                        'ctx_conv1d_forward_and_weight_gradient': 'bf16x6 split (bf16 MFMA, fp32 accumulate)' if cfg.train_wgan_split_bf16 else 'fp32 MFMA',
-                       'dense_forward_and_backward_data': 'bf16x6 split (bf16 MFMA, fp32 accumulate); weight gradients on the fp32 matrix pipe' if (cfg.train_wgan_split_bf16 and ops._DenseSplit.enabled) else 'fp32 MFMA',
+                       'dense_products': ('forward / backward-data / weight gradients (>= {} frames, two stages): bf16x6 split (bf16 MFMA, fp32 accumulate); 1-wide heads: fp32'.format(2048)
+                                          if (cfg.train_wgan_split_bf16 and ops._DenseSplit.enabled) else 'fp32 MFMA'),
+                       'collective_backend': (__import__('torch').distributed.get_backend() if world > 1 else None),
                        'conv2d_stacks': ops.conv2d_path_description() if hasattr(ops, 'conv2d_path_description') else 'fp32 packed-FMA stencil',
                        'batchnorm_statistics': 'per rank (B={} each; SyncBN off)'.format(B) if not getattr(cfg, 'train_sync_batchnorm', False) else 'synchronised over ranks (SyncBN)',
                        'input_batches_rotating': nbuf,

@@ -61,6 +61,12 @@ const char* ptts_last_error(void);      /* thread-local message of the last fail
  * thin weight-gradient kernel and the loss scalars take their single-pass forms).  Returns the previous setting. */
 int ptts_set_deterministic(int on);
 int ptts_get_deterministic(void);
+/* bf16 products (BASELINE configs[2]; the reference is fp32, README.md:166): the split GEMM kernels -- ptts_conv1d_bf16x6,
+ * ptts_conv1d_wgrad_bf16x6, ptts_dense_bf16x6, ptts_dense_wgrad_bf16x6* -- form ONE product of the operands' bf16 roundings
+ * (plane 1 of the split) instead of the six products of the fp32 split; fp32 accumulation, fp32 master weights and
+ * gradients.  Returns the previous setting. */
+int ptts_set_bf16_products(int on);
+int ptts_get_bf16_products(void);
 
 /* ---------------------------------------------------------------------------------------
  * 2D convolution over (time x frequency), NHWC, stride 1.

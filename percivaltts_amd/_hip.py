@@ -41,6 +41,8 @@ SIGNATURES = {
     'ptts_last_error': (ctypes.c_char_p, []),
     'ptts_set_deterministic': (c_i, [c_i]),
     'ptts_get_deterministic': (c_i, []),
+    'ptts_set_bf16_products': (c_i, [c_i]),
+    'ptts_get_bf16_products': (c_i, []),
     'ptts_conv2d_fwd': (c_i, [c_p] * 7 + [c_i] * 10 + [c_f, c_p]),
     'ptts_conv2d_bwd_workspace_bytes': (c_sz, [c_i] * 8),
     'ptts_conv2d_bwd': (c_i, [c_p] * 11 + [c_p, c_sz] + [c_i] * 10 + [c_f, c_p]),

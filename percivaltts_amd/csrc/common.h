@@ -10,6 +10,9 @@ namespace ptts {
 void set_error(const char* fmt, ...);
 // ptts_set_deterministic(): fixed-order reductions only (no fp32 atomics between workgroups), at a price in speed
 bool deterministic();
+// ptts_set_bf16_products(): the split GEMM kernels (context Conv1D, Dense, their weight gradients) form ONE product of the
+// operands' bf16 roundings instead of the six products of the fp32 split (BASELINE configs[2]: bf16 products, fp32 accumulation)
+bool bf16_products();
 // Zero fills by kernel, not hipMemsetAsync: memset nodes of a captured hipGraph were found not to be replayed reliably on
 // this stack (tests/test_model_gpu.py::test_split_hipgraph_...: bias-gradient and loss scalars came back unzeroed).
 int zero_f32(float* p, size_t n, hipStream_t st);

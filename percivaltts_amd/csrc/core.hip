@@ -35,9 +35,13 @@ int zero_f32_2d(float* p, size_t ld, size_t cols, size_t rows, hipStream_t st) {
 }
 static int g_deterministic = 0;
 bool deterministic() { return g_deterministic != 0; }
+static int g_bf16_products = 0;
+bool bf16_products() { return g_bf16_products != 0; }
 }  // namespace ptts
 
-extern "C" const char* ptts_version(void) { return "percival_hip 0.2.0 (round 2)"; }
+extern "C" const char* ptts_version(void) { return "percival_hip 0.3.0 (round 3)"; }
+extern "C" int ptts_set_bf16_products(int on) { const int old = ptts::g_bf16_products; ptts::g_bf16_products = on ? 1 : 0; return old; }
+extern "C" int ptts_get_bf16_products(void) { return ptts::g_bf16_products; }
 extern "C" int ptts_set_deterministic(int on) { const int old = ptts::g_deterministic; ptts::g_deterministic = on ? 1 : 0; return old; }
 extern "C" int ptts_get_deterministic(void) { return ptts::g_deterministic; }
 extern "C" const char* ptts_device_arch(void) { return "gfx950"; }

@@ -39,6 +39,9 @@ constexpr int NBLK = 256;          // columns per workgroup
 constexpr int BK = 32;
 
 #define DNS_PRODUCTS(X) X(2, 0) X(1, 1) X(0, 2) X(1, 0) X(0, 1) X(0, 0)
+// NPL = 3: the six products of the fp32 split; NPL = 1 (ptts_set_bf16_products: BASELINE configs[2]): ONE product of the
+// operands' bf16 roundings, fp32 accumulation
+#define DNS_PRODUCTS_NPL(NPL, X) do { if (NPL == 3) { X(2, 0) X(1, 1) X(0, 2) X(1, 0) X(0, 1) } X(0, 0) } while (0)
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
@@ -93,14 +96,14 @@ struct DenseArgs {
     int accumulate, has_affine, vec_out;
 };
 
-template <int MODE, bool AFFINE, int MT>
+template <int MODE, bool AFFINE, int MT, int NPL>
 __global__ __launch_bounds__(THREADS) void dense_bf16x6_kernel(DenseArgs g) {
     constexpr int TBM = 16 * MT;
     constexpr int NA = (TBM * 8 + THREADS - 1) / THREADS;     // 16-byte quads (4 k) per lane and k-step
     constexpr int ROWS = NA * THREADS / 8;                    // staged rows incl. the pad rows the idle lanes of the last slot write
     constexpr int PL = ROWS * BK;                             // elements of one plane of a stage
     constexpr bool MASK = MODE == PTTS_IN_MASKMUL;
-    __shared__ __attribute__((aligned(16))) u16 As[2][3 * PL];
+    __shared__ __attribute__((aligned(16))) u16 As[2][NPL * PL];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
@@ -153,13 +156,17 @@ __global__ __launch_bounds__(THREADS) void dense_bf16x6_kernel(DenseArgs g) {
             } else {
                 if (!(oka[j] && sg.kok)) a = z4;
             }
-            unsigned a1, a2, a3, b1, b2, b3;
-            split3_pair(a[0], a[1], a1, a2, a3);
-            split3_pair(a[2], a[3], b1, b2, b3);
             u16* d = as + dst[j];
-            *reinterpret_cast<u32x2*>(d) = (u32x2){a1, b1};
-            *reinterpret_cast<u32x2*>(d + PL) = (u32x2){a2, b2};
-            *reinterpret_cast<u32x2*>(d + 2 * PL) = (u32x2){a3, b3};
+            if (NPL == 3) {
+                unsigned a1, a2, a3, b1, b2, b3;
+                split3_pair(a[0], a[1], a1, a2, a3);
+                split3_pair(a[2], a[3], b1, b2, b3);
+                *reinterpret_cast<u32x2*>(d) = (u32x2){a1, b1};
+                *reinterpret_cast<u32x2*>(d + PL) = (u32x2){a2, b2};
+                *reinterpret_cast<u32x2*>(d + 2 * PL) = (u32x2){a3, b3};
+            } else {
+                *reinterpret_cast<u32x2*>(d) = (u32x2){pk_bf16(a[0], a[1]), pk_bf16(a[2], a[3])};      // the one rounding of bf16 products
+            }
         }
     };
 
@@ -168,11 +175,11 @@ __global__ __launch_bounds__(THREADS) void dense_bf16x6_kernel(DenseArgs g) {
     const u16* wp[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) wp[j] = g.planes + (((size_t)((n0 >> 4) + 2 * (wave_live ? wave : 0) + j) * KS) * 64 + lane) * 8;
-    auto load_w = [&](int s, bf16x8 (&wf)[2][3]) {
+    auto load_w = [&](int s, bf16x8 (&wf)[2][NPL]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) wf[j][p] = *reinterpret_cast<const bf16x8*>(wp[j] + p * ps + (size_t)s * 512);
+            for (int p = 0; p < NPL; ++p) wf[j][p] = *reinterpret_cast<const bf16x8*>(wp[j] + p * ps + (size_t)s * 512);
     };
 
     f32x4 acc[MT][2];
@@ -180,16 +187,16 @@ __global__ __launch_bounds__(THREADS) void dense_bf16x6_kernel(DenseArgs g) {
     for (int i = 0; i < MT; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     // activation fragment of row tile i: row 16 i + li, quad lg (swizzle = bit 2 of li), plane p: + p PL
     const int boff = li * BK + ((lg ^ ((li >> 1) & 2)) << 3);
-    auto mfma_rows = [&](const u16* as, const bf16x8 (&wf)[2][3], int i0, int i1) {
+    auto mfma_rows = [&](const u16* as, const bf16x8 (&wf)[2][NPL], int i0, int i1) {
 #pragma unroll
         for (int i = i0; i < i1; ++i) {
-            bf16x8 bf[3];
+            bf16x8 bf[NPL];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const bf16x8*>(as + p * PL + boff + i * 16 * BK);
+            for (int p = 0; p < NPL; ++p) bf[p] = *reinterpret_cast<const bf16x8*>(as + p * PL + boff + i * 16 * BK);
 #define DNS_MM(PA, PW)                                                                                    \
-            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][PW], bf[PA], acc[i][0], 0, 0, 0);    \
-            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][PW], bf[PA], acc[i][1], 0, 0, 0);
-            DNS_PRODUCTS(DNS_MM)
+            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][PW < NPL ? PW : 0], bf[PA < NPL ? PA : 0], acc[i][0], 0, 0, 0);    \
+            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][PW < NPL ? PW : 0], bf[PA < NPL ? PA : 0], acc[i][1], 0, 0, 0);
+            DNS_PRODUCTS_NPL(NPL, DNS_MM);
 #undef DNS_MM
         }
     };
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(THREADS) void dense_bf16x6_kernel(DenseArgs g) {
     // of step s+2 sit between the MFMAs of step s.  (A wave whose columns lie beyond N runs the same code on the first
     // tile's planes: the MFMAs are cheap next to a divergent barrier structure, and nothing of it is stored.)
     Stage sg;
-    bf16x8 wc[2][3], wn[2][3];
+    bf16x8 wc[2][NPL], wn[2][NPL];
     load_a(0, sg);
     load_w(0, wc);
     commit(sg, As[0]);
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(THREADS) void dense_bf16x6_kernel(DenseArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) wc[j][p] = wn[j][p];
+            for (int p = 0; p < NPL; ++p) wc[j][p] = wn[j][p];
         __syncthreads();
     };
     if (wave < 4) { for (int s = 0; s < KS; ++s) step(s, 2); }
@@ -340,7 +347,7 @@ constexpr int WROW = WT;                      // elements per staged row of a pl
 constexpr int WPL = 32 * WROW;                // elements of one plane of one operand
 constexpr int WPART = WT * WT + WT;           // floats of a workgroup's partial row: the tile and the bias sums
 
-template <int MODE, bool AFFINE>
+template <int MODE, bool AFFINE, int NPL>
 __global__ __launch_bounds__(THREADS) void dense_wgrad_bf16x6_kernel(WgradArgs g) {
     constexpr bool MASK = MODE == PTTS_IN_MASKMUL;
     extern __shared__ __attribute__((aligned(16))) u16 lds_w[];          // [buffer][A planes 0..2 | dY planes 0..2]: 96 KB
@@ -400,19 +407,24 @@ __global__ __launch_bounds__(THREADS) void dense_wgrad_bf16x6_kernel(WgradArgs g
             }
             if (!(sg.ok[j] && d_ok)) d = z4;
             bsum += d;
-            unsigned a1, a2, a3, b1, b2, b3;
-            split3_pair(a[0], a[1], a1, a2, a3);
-            split3_pair(a[2], a[3], b1, b2, b3);
             u16* q = ls + dst[j];
-            *reinterpret_cast<u32x2*>(q) = (u32x2){a1, b1};
-            *reinterpret_cast<u32x2*>(q + WPL) = (u32x2){a2, b2};
-            *reinterpret_cast<u32x2*>(q + 2 * WPL) = (u32x2){a3, b3};
-            split3_pair(d[0], d[1], a1, a2, a3);
-            split3_pair(d[2], d[3], b1, b2, b3);
-            q += 3 * WPL;
-            *reinterpret_cast<u32x2*>(q) = (u32x2){a1, b1};
-            *reinterpret_cast<u32x2*>(q + WPL) = (u32x2){a2, b2};
-            *reinterpret_cast<u32x2*>(q + 2 * WPL) = (u32x2){a3, b3};
+            if (NPL == 3) {
+                unsigned a1, a2, a3, b1, b2, b3;
+                split3_pair(a[0], a[1], a1, a2, a3);
+                split3_pair(a[2], a[3], b1, b2, b3);
+                *reinterpret_cast<u32x2*>(q) = (u32x2){a1, b1};
+                *reinterpret_cast<u32x2*>(q + WPL) = (u32x2){a2, b2};
+                *reinterpret_cast<u32x2*>(q + 2 * WPL) = (u32x2){a3, b3};
+                split3_pair(d[0], d[1], a1, a2, a3);
+                split3_pair(d[2], d[3], b1, b2, b3);
+                q += 3 * WPL;
+                *reinterpret_cast<u32x2*>(q) = (u32x2){a1, b1};
+                *reinterpret_cast<u32x2*>(q + WPL) = (u32x2){a2, b2};
+                *reinterpret_cast<u32x2*>(q + 2 * WPL) = (u32x2){a3, b3};
+            } else {
+                *reinterpret_cast<u32x2*>(q) = (u32x2){pk_bf16(a[0], a[1]), pk_bf16(a[2], a[3])};
+                *reinterpret_cast<u32x2*>(q + 3 * WPL) = (u32x2){pk_bf16(d[0], d[1]), pk_bf16(d[2], d[3])};
+            }
         }
     };
 
@@ -438,21 +450,21 @@ __global__ __launch_bounds__(THREADS) void dense_wgrad_bf16x6_kernel(WgradArgs g
     // one k-step of MFMAs on buffer BUF (a compile-time index: every LDS address is a lane base + an immediate); the dY
     // fragments are read once and serve both A-column tiles; `stage` (the next step's transform / split / LDS stores and the
     // loads of the step after) runs between the two tile rows in waves 0-3 and in front of them in waves 4-7
-    auto mfma_tile_row = [&](const u16* ls, int i, const bf16x8 (&bf)[4][3]) {
-        bf16x8 af[3];
+    auto mfma_tile_row = [&](const u16* ls, int i, const bf16x8 (&bf)[4][NPL]) {
+        bf16x8 af[NPL];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) af[p] = cat8(tr_read(ls + p * WPL + ao[i][0]), tr_read(ls + p * WPL + ao[i][1]));
+        for (int p = 0; p < NPL; ++p) af[p] = cat8(tr_read(ls + p * WPL + ao[i][0]), tr_read(ls + p * WPL + ao[i][1]));
 #define DNS_MM(PA, PW)                                                                                       \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA], bf[j][PW], acc[i][j], 0, 0, 0);
-        DNS_PRODUCTS(DNS_MM)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA < NPL ? PA : 0], bf[j][PW < NPL ? PW : 0], acc[i][j], 0, 0, 0);
+        DNS_PRODUCTS_NPL(NPL, DNS_MM);
 #undef DNS_MM
     };
-    auto read_bf = [&](const u16* ls, bf16x8 (&bf)[4][3]) {
+    auto read_bf = [&](const u16* ls, bf16x8 (&bf)[4][NPL]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bf[j][p] = cat8(tr_read(ls + p * WPL + bo[j][0]), tr_read(ls + p * WPL + bo[j][1]));
+            for (int p = 0; p < NPL; ++p) bf[j][p] = cat8(tr_read(ls + p * WPL + bo[j][0]), tr_read(ls + p * WPL + bo[j][1]));
     };
 
     Stage sg;
@@ -463,7 +475,7 @@ __global__ __launch_bounds__(THREADS) void dense_wgrad_bf16x6_kernel(WgradArgs g
     u16* const buf0 = lds_w;
     u16* const buf1 = lds_w + 6 * WPL;
     auto step = [&](int s, const u16* cur, u16* nxt, bool stage_first) {
-        bf16x8 bf[4][3];
+        bf16x8 bf[4][NPL];
         if (stage_first) { commit(sg, nxt); load(s + 2, sg); }       // (rows of a step beyond the share are staged as zeros)
         read_bf(cur, bf);
         mfma_tile_row(cur, 0, bf);
@@ -604,7 +616,9 @@ extern "C" int ptts_dense_bf16x6(const float* A, const void* planes, const float
     const int mt = pick_mt(M, cb);
     const dim3 grid((unsigned)((M + 16 * mt - 1) / (16 * mt)), (unsigned)cb);
     hipStream_t st = (hipStream_t)stream;
-#define DNS_L(MODE, AFF, MT) hipLaunchKernelGGL((dense_bf16x6_kernel<MODE, AFF, MT>), grid, dim3(THREADS), 0, st, g)
+    const bool one = ptts::bf16_products();
+#define DNS_L(MODE, AFF, MT) do { if (one) hipLaunchKernelGGL((dense_bf16x6_kernel<MODE, AFF, MT, 1>), grid, dim3(THREADS), 0, st, g); \
+                                  else hipLaunchKernelGGL((dense_bf16x6_kernel<MODE, AFF, MT, 3>), grid, dim3(THREADS), 0, st, g); } while (0)
 #define DNS_M(MT)                                                                \
     do {                                                                         \
         if (in_mode == PTTS_IN_LRELU) { if (in_scale) DNS_L(PTTS_IN_LRELU, true, MT); else DNS_L(PTTS_IN_LRELU, false, MT); } \
@@ -678,11 +692,14 @@ extern "C" int ptts_dense_wgrad_bf16x6_partials(const float* A, const float* dY,
     const dim3 grid((unsigned)g.split, (unsigned)tiles);
     hipStream_t st = (hipStream_t)stream;
     constexpr size_t lds = (size_t)2 * 6 * WPL * sizeof(u16);
+    const bool one = ptts::bf16_products();
 #define DNS_W(MODE, AFF)                                                                                                  \
     do {                                                                                                                  \
         static bool attr = false;                                                                                         \
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_wgrad_bf16x6_kernel<MODE, AFF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; } \
-        hipLaunchKernelGGL((dense_wgrad_bf16x6_kernel<MODE, AFF>), grid, dim3(THREADS), lds, st, g);                      \
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_wgrad_bf16x6_kernel<MODE, AFF, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_wgrad_bf16x6_kernel<MODE, AFF, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; } \
+        if (one) hipLaunchKernelGGL((dense_wgrad_bf16x6_kernel<MODE, AFF, 1>), grid, dim3(THREADS), lds, st, g);          \
+        else hipLaunchKernelGGL((dense_wgrad_bf16x6_kernel<MODE, AFF, 3>), grid, dim3(THREADS), lds, st, g);              \
     } while (0)
     if (in_mode == PTTS_IN_LRELU) { if (in_scale) DNS_W(PTTS_IN_LRELU, true); else DNS_W(PTTS_IN_LRELU, false); }
     else if (in_mode == PTTS_IN_MASKMUL) DNS_W(PTTS_IN_MASKMUL, false);

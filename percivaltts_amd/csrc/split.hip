@@ -313,6 +313,170 @@ __global__ __launch_bounds__(S_THREADS) void gemm_bf16x6_kernel(SplitGemmArgs g)
     }
 }
 
+// ONE product per position (ptts_set_bf16_products, BASELINE configs[2]): plane 1 of each operand alone, fp32 accumulation.
+// The structure of split_segment is kept, with three consecutive TAPS where the three planes were: a k-step is (channel block,
+// taps 3 t3 .. 3 t3 + 2), its B stage holds the three taps' kernel slices (the taps of a channel block lie next to each other in
+// the transposed kernel plane), its A fragments are three row shifts of the one frame image, and the three products
+// (tap 0, 1, 2) take the place of the six split products: a sixth of the MFMAs, a third of the barriers.  KW % 3 == 0, KW >= 6.
+__device__ __forceinline__ void split_segment_1p(const SplitGemmArgs& g, u16* lds, int tile, int cb0, int cb1) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 64;
+    const int li = lane & 15, lg = lane >> 4;
+    const int m0 = (tile / g.tiles_n) * SBM, n0 = (tile % g.tiles_n) * SBN;
+    const int KW = g.taps, KW3 = KW / 3;
+    u16* aimg = lds;                                // 2 x A image (plane 0 used)
+    u16* bst = lds + 2 * S_AIMG;                    // S_STAGES x B stage (three taps x 128 rows)
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int prow0 = s_prow(g, m0);
+    constexpr int A_INSTR = S_AROWS / 16;           // 11 wave-instructions of 16 rows
+    constexpr int A_PER_WAVE = (A_INSTR + S_WAVES - 1) / S_WAVES;   // 2 (waves 0..2; the others issue 1)
+    const int n_a = (A_INSTR - wave + S_WAVES - 1) / S_WAVES;
+    auto issue_a = [&](int cb, int buf) {
+        u16* img = aimg + buf * S_AIMG;
+#pragma unroll
+        for (int x = 0; x < A_PER_WAVE; ++x) {
+            const int u = wave + S_WAVES * x;
+            if (u < A_INSTR) {
+                const int rb = u * 16;
+                const int r = rb + (lane >> 2);
+                const int cg = (lane & 3) ^ ((r >> 1) & 2);
+                long long row = prow0 + r;
+                if (row >= g.a_rows) row = g.a_rows - 1;
+                dma16h(g.A[0] + ((long long)cb * g.a_rows + row) * SBK + 8 * cg, img + rb * SBK);
+            }
+        }
+    };
+    long long boff;
+    {
+        const int r = 16 * wave + (lane >> 2);
+        const int cg = (lane & 3) ^ ((r >> 1) & 2);
+        boff = (long long)(n0 + r) * (KW * SBK) + 8 * cg;
+    }
+    auto issue_b = [&](int cb, int t3, int stage) {        // 3 DMA wave-instructions: taps 3 t3, + 1, + 2
+        u16* st = bst + stage * S_BSTAGE;
+        const long long k0 = ((long long)cb * g.N * KW + 3 * t3) * SBK;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            dma16h(g.Bt[0] + boff + k0 + p * SBK, st + p * S_IMG + 16 * wave * SBK);
+    };
+    int arow[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int m = min(m0 + wm + 16 * f + li, g.M - 1);
+        arow[f] = s_prow(g, m) - prow0;
+    }
+    const int bfrag = (wn + li) * SBK + 8 * (lg ^ ((li >> 1) & 2));
+
+    const int nsteps = (cb1 - cb0) * KW3;
+    auto step_pos = [&](int s, int& c, int& t) { c = cb0 + s / KW3; t = s - (s / KW3) * KW3; };
+    auto read_frags = [&](int s, int c, int t3, bf16x8 (&a)[3][2], bf16x8 (&b)[3][4]) {
+        const u16* img = aimg + ((c - cb0) & 1) * S_AIMG;
+        const u16* st = bst + (s % S_STAGES) * S_BSTAGE;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const int row = arow[f] + 3 * t3 + p;
+                a[p][f] = *reinterpret_cast<const bf16x8*>(img + row * SBK + 8 * (lg ^ ((row >> 1) & 2)));
+            }
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) b[p][f] = *reinterpret_cast<const bf16x8*>(st + p * S_IMG + bfrag + 16 * f * SBK);
+    };
+    issue_a(cb0, 0);
+    {
+        int c, t;
+        step_pos(0, c, t); issue_b(c, t, 0);
+        if (nsteps > 1) { step_pos(1, c, t); issue_b(c, t, 1); }
+        if (nsteps > 2) { step_pos(2, c, t); issue_b(c, t, 2); }
+    }
+    if (nsteps > 2) __builtin_amdgcn_s_waitcnt(0xF76);            // vmcnt(6): A(cb0) and B(0) have landed
+    else if (nsteps > 1) __builtin_amdgcn_s_waitcnt(0xF73);
+    else __builtin_amdgcn_s_waitcnt(0xF70);
+    __syncthreads();
+    bf16x8 fa0[3][2], fb0[3][4], fa1[3][2], fb1[3][4];
+    read_frags(0, cb0, 0, fa0, fb0);
+    int s = 0, cb = cb0, tap = 0;
+    auto step = [&](bf16x8 (&a)[3][2], bf16x8 (&b)[3][4], bf16x8 (&na)[3][2], bf16x8 (&nb)[3][4]) {
+        if (s + 1 < nsteps) {
+            const bool b_next = s + 2 < nsteps;
+            const bool a_after = (tap == 1) && (cb + 1 < cb1) && s >= 1;
+            if (b_next && a_after) { if (n_a == 2) __builtin_amdgcn_s_waitcnt(0xF75); else __builtin_amdgcn_s_waitcnt(0xF74); }   // vmcnt(3 + n_a)
+            else if (b_next) __builtin_amdgcn_s_waitcnt(0xF73);
+            else __builtin_amdgcn_s_waitcnt(0xF70);
+        }
+        __syncthreads();
+        if (tap == 0 && cb + 1 < cb1) issue_a(cb + 1, ((cb + 1 - cb0) & 1));
+        if (s + 3 < nsteps) { int c, t; step_pos(s + 3, c, t); issue_b(c, t, s % S_STAGES); }
+        {
+            const int sn = min(s + 1, nsteps - 1);
+            int c, t; step_pos(sn, c, t); read_frags(sn, c, t, na, nb);
+        }
+#define PTTS_PROD1(P)                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                       \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[P][i], b[P][j], acc[i][j], 0, 0, 0);
+        PTTS_PROD1(0) PTTS_PROD1(1) PTTS_PROD1(2)
+#undef PTTS_PROD1
+        // the 18 fragment reads of the next step spread between the 24 MFMAs of this one
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        ++s;
+        if (++tap == KW3) { tap = 0; ++cb; }
+    };
+    while (s < nsteps) {
+        step(fa0, fb0, fa1, fb1);
+        if (s < nsteps) step(fa1, fb1, fa0, fb0);
+    }
+    __syncthreads();
+
+    const bool whole = (cb0 == 0) && (cb1 == g.cblocks);
+    const bool add_bias = g.bias != nullptr && cb0 == 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn + 16 * j + li;
+            const float bv = add_bias ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm + 16 * i + 4 * lg + r;
+                if (m < g.M) {
+                    float* cp = g.C + (long long)m * g.N + n;
+                    const float v = acc[i][j][r] + bv;
+                    if (whole) *cp = v; else atomicAdd(cp, v);
+                }
+            }
+        }
+}
+
+__global__ __launch_bounds__(S_THREADS) void gemm_bf16x1_kernel(SplitGemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) u16 s_lds[];
+    long long it = g.iters_total * blockIdx.x / g.workers;
+    const long long it_end = g.iters_total * (blockIdx.x + 1) / g.workers;
+    while (it < it_end) {
+        const int tile = (int)(it / g.cblocks);
+        const int cb0 = (int)(it - (long long)tile * g.cblocks);
+        const int cb1 = (int)min((long long)g.cblocks, cb0 + (it_end - it));
+        it += cb1 - cb0;
+        split_segment_1p(g, s_lds, tile, cb0, cb1);
+    }
+}
+
 static int split_grid(long long total, int threads) {
     long long b = (total + threads - 1) / threads;
     return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
@@ -363,9 +527,13 @@ extern "C" int ptts_conv1d_bf16x6(const void* a1, const void* a2, const void* a3
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x6_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x1_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
         if (e != hipSuccess) { set_error("conv1d_bf16x6: cannot reserve %d B of LDS: %s", S_LDS_BYTES, hipGetErrorString(e)); return PTTS_ELAUNCH; }
         attr_set = true;
     }
+    // bf16 products (ptts_set_bf16_products): one product per position; the three-taps-per-step kernel wants KW % 3 == 0, KW >= 6
+    const bool one = ptts::bf16_products() && KW % 3 == 0 && KW >= 6 && 3 * (KW / 3 - 1) + 2 + SBM - 1 + (KW - 1) < S_AROWS + KW;
     SplitGemmArgs g;
     g.A[0] = (const u16*)a1; g.A[1] = (const u16*)a2; g.A[2] = (const u16*)a3;
     g.Bt[0] = (const u16*)bt1; g.Bt[1] = (const u16*)bt2; g.Bt[2] = (const u16*)bt3;
@@ -383,7 +551,8 @@ extern "C" int ptts_conv1d_bf16x6(const void* a1, const void* a2, const void* a3
     if (g.iters_total % workers != 0 || (g.iters_total / workers) % g.cblocks != 0) {
         if (zero_f32(y, (size_t)g.M * N, st) != PTTS_OK) return PTTS_ELAUNCH;
     }
-    hipLaunchKernelGGL(gemm_bf16x6_kernel, dim3(g.workers), dim3(S_THREADS), S_LDS_BYTES, st, g);
+    if (one) hipLaunchKernelGGL(gemm_bf16x1_kernel, dim3(g.workers), dim3(S_THREADS), S_LDS_BYTES, st, g);
+    else hipLaunchKernelGGL(gemm_bf16x6_kernel, dim3(g.workers), dim3(S_THREADS), S_LDS_BYTES, st, g);
     return check_launch("conv1d_bf16x6");
 }
 
@@ -456,7 +625,9 @@ __global__ __launch_bounds__(256) void split3_frames_t_kernel(const float* __res
     }
 }
 
-template <int KW>
+// NPL = 3: the six products of the fp32 split.  NPL = 1 (ptts_set_bf16_products, BASELINE configs[2]): plane 1 of each operand
+// alone (its bf16 rounding), ONE product per tap, fp32 accumulation.
+template <int KW, int NPL>
 __global__ __launch_bounds__(W_THREADS) void wgrad_bf16x6_kernel(WgradSplitArgs g) {
     extern __shared__ __attribute__((aligned(16))) u16 s_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -485,7 +656,7 @@ __global__ __launch_bounds__(W_THREADS) void wgrad_bf16x6_kernel(WgradSplitArgs 
     }
     long long bsrc = 0;
     const int bplane = wave >> 1;
-    if (wave < 6) {
+    if (wave < 2 * NPL) {
         const int r = 16 * (wave & 1) + (lane >> 2);
         const int qd = (lane & 3) ^ ((r >> 1) & 2);
         bsrc = (long long)(n0 + r) * g.Pp + 8 * qd;
@@ -494,8 +665,8 @@ __global__ __launch_bounds__(W_THREADS) void wgrad_bf16x6_kernel(WgradSplitArgs 
         u16* st = s_lds + stage * W_STAGE;
         const long long q0 = (long long)s * W_QS;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) dma16h(g.Xt[p] + asrc + q0, st + p * W_ATILE + 8 * wave * W_AROW);
-        if (wave < 6) {
+        for (int p = 0; p < NPL; ++p) dma16h(g.Xt[p] + asrc + q0, st + p * W_ATILE + 8 * wave * W_AROW);
+        if (wave < 2 * NPL) {
             const u16* yp = bplane == 0 ? g.Yt[0] : (bplane == 1 ? g.Yt[1] : g.Yt[2]);
             dma16h(yp + bsrc + q0, st + 3 * W_ATILE + bplane * W_BTILE + 16 * (wave & 1) * W_QS);
         }
@@ -511,16 +682,18 @@ __global__ __launch_bounds__(W_THREADS) void wgrad_bf16x6_kernel(WgradSplitArgs 
     if (nsteps > 1) issue(s_begin + 1, 1);
     for (int s = 0; s < nsteps; ++s) {
         // DMAs of this wave issued after those of step s: the ones of step s+1 (4 for waves 0..5, 3 for waves 6, 7)
-        if (s + 1 < nsteps) { if (wave < 6) __builtin_amdgcn_s_waitcnt(0xF74); else __builtin_amdgcn_s_waitcnt(0xF73); }
-        else __builtin_amdgcn_s_waitcnt(0xF70);
+        if (s + 1 < nsteps) {
+            if (NPL == 3) { if (wave < 6) __builtin_amdgcn_s_waitcnt(0xF74); else __builtin_amdgcn_s_waitcnt(0xF73); }
+            else { if (wave < 2) __builtin_amdgcn_s_waitcnt(0xF72); else __builtin_amdgcn_s_waitcnt(0xF71); }
+        } else __builtin_amdgcn_s_waitcnt(0xF70);
         __syncthreads();
         if (s + 2 < nsteps) issue(s_begin + s + 2, (s + 2) % W_STAGES);
         const u16* st = s_lds + (s % W_STAGES) * W_STAGE;
         // 32 consecutive frames of this lane's channel row, per plane: 16 dwords
-        unsigned d[3][16];
-        bf16x8 bq[3];
+        unsigned d[NPL][16];
+        bf16x8 bq[NPL];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NPL; ++p) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint4 v = *reinterpret_cast<const uint4*>(st + p * W_ATILE + abase + 8 * ((lg + u) ^ asw));
@@ -530,9 +703,9 @@ __global__ __launch_bounds__(W_THREADS) void wgrad_bf16x6_kernel(WgradSplitArgs 
         }
 #pragma unroll
         for (int j = 0; j < KW; ++j) {
-            bf16x8 a[3];
+            bf16x8 a[NPL];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
+            for (int p = 0; p < NPL; ++p) {
                 unsigned w4[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -541,11 +714,13 @@ __global__ __launch_bounds__(W_THREADS) void wgrad_bf16x6_kernel(WgradSplitArgs 
                 const u32x4 t = {w4[0], w4[1], w4[2], w4[3]};
                 a[p] = __builtin_bit_cast(bf16x8, t);
             }
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], bq[0], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bq[1], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bq[2], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bq[0], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bq[1], acc[j], 0, 0, 0);
+            if (NPL == 3) {
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[NPL - 1], bq[0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[NPL / 2], bq[NPL / 2], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bq[NPL - 1], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[NPL / 2], bq[0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bq[NPL / 2], acc[j], 0, 0, 0);
+            }
             acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bq[0], acc[j], 0, 0, 0);
         }
     }
@@ -599,16 +774,20 @@ extern "C" int ptts_conv1d_wgrad_bf16x6(const void* xt1, const void* xt2, const 
     if (nsplit > qsteps) nsplit = qsteps;
     g.nsplit = nsplit; g.steps_per_split = (qsteps + nsplit - 1) / nsplit;
     if (zero_f32(dw, (size_t)KW * C * N, st) != PTTS_OK) return PTTS_ELAUNCH;
+    const bool one = ptts::bf16_products();
 #define PTTS_WG_LAUNCH(KWV)                                                                                               \
     {                                                                                                                     \
         static bool attr = false;                                                                                         \
         if (!attr) {                                                                                                      \
-            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16x6_kernel<KWV>),                   \
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16x6_kernel<KWV, 3>),                \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES);                 \
+            if (e2 == hipSuccess) e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16x6_kernel<KWV, 1>),     \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES);                 \
             if (e2 != hipSuccess) { set_error("conv1d_wgrad_bf16x6: LDS attribute: %s", hipGetErrorString(e2)); return PTTS_ELAUNCH; } \
             attr = true;                                                                                                  \
         }                                                                                                                 \
-        hipLaunchKernelGGL((wgrad_bf16x6_kernel<KWV>), dim3(tiles * nsplit), dim3(W_THREADS), W_LDS_BYTES, st, g);        \
+        if (one) hipLaunchKernelGGL((wgrad_bf16x6_kernel<KWV, 1>), dim3(tiles * nsplit), dim3(W_THREADS), W_LDS_BYTES, st, g); \
+        else hipLaunchKernelGGL((wgrad_bf16x6_kernel<KWV, 3>), dim3(tiles * nsplit), dim3(W_THREADS), W_LDS_BYTES, st, g); \
     }
     if (KW == 21) PTTS_WG_LAUNCH(21) else if (KW == 5) PTTS_WG_LAUNCH(5) else PTTS_WG_LAUNCH(3)
 #undef PTTS_WG_LAUNCH

@@ -80,6 +80,19 @@ def _prep(v):
 class _Flags(object):
     skip_param_grads = False
     deterministic = os.environ.get('PTTS_DETERMINISTIC', '0') == '1'
+    bf16_products = False
+
+
+def bf16_products(on=None):
+    """bf16 products (BASELINE configs[2]; build extension, the reference is fp32): the split GEMM kernels -- context Conv1D
+    forward and weight gradient, Dense forward / backward-data / weight gradient, LSTM input projections -- form ONE product of
+    the operands' bf16 roundings (plane 1 of the split they already hold) instead of six; fp32 accumulation, fp32 master
+    weights, gradients and activations in HBM.  Products that do not take a split kernel (the 1-wide heads, small shapes,
+    the recurrent LSTM products) stay fp32.  Returns the setting; `on=None` only reads it."""
+    if on is not None:
+        _Flags.bf16_products = bool(on)
+    _hip.lib().ptts_set_bf16_products(1 if _Flags.bf16_products else 0)
+    return _Flags.bf16_products
 
 
 def deterministic(on=None):

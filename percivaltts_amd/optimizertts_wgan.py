@@ -136,6 +136,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         cfg.train_wgan_graph_split = False           # hipGraph of forward + backward only, update launched eagerly (what data parallelism uses; settable for tests)
         cfg.train_wgan_async_update = None           # all-reduce + Adam on a communication stream, overlapped with the next forward that does not need the weights (None: on when world > 1)
         cfg.train_sync_batchnorm = False             # data parallelism: BatchNorm statistics over all ranks (SyncBN) instead of per rank
+        cfg.train_wgan_bf16_products = False         # BASELINE configs[2]: ONE bf16 product per position in the split GEMM kernels (context Conv1D, Dense, LSTM projections) instead of the six of the fp32 split; fp32 accumulation and master weights (ops.bf16_products)
         cfg.train_wgan_split_bf16 = None             # context Conv1D (forward + weight gradient) and Dense products as bf16x6 split products (fp32 arithmetic on the bf16 matrix cores: ops._C1Split, ops._DenseSplit); None: the defaults (on; PTTS_CONV1D_SPLIT=0 / PTTS_DENSE_SPLIT=0 turn them off), False: fp32 MFMA kernels
         return cfg
 
@@ -185,6 +186,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             parallel.broadcast_(self.critic_opti.flat.flat)
             parallel.broadcast_(self.gen_opti.flat.flat)
         ops.sync_batchnorm(self.world if bool(getattr(cfg, 'train_sync_batchnorm', False)) else 1)
+        ops.bf16_products(bool(getattr(cfg, 'train_wgan_bf16_products', False)))
 
         # kept for API compatibility: Keras needed target arrays, the kernels take the signs directly
         self.wgan_valid = -np.ones((cfg.train_batch_size, 1, 1))
@@ -427,6 +429,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         # the generator step that follows on the same batch reuses the generator's context-Conv1D product of the critic
         # step's fake sample (same input, same not-yet-updated kernel): ops._C1Cache, valid inside this call only
         ops.conv1d_cache(gen_too and not use_graph and bool(getattr(self.cfg, 'train_wgan_reuse_ctx_conv', True)))
+        ops.bf16_products(bool(getattr(self.cfg, 'train_wgan_bf16_products', False)))
         split = getattr(self.cfg, 'train_wgan_split_bf16', None)
         if split is not None:
             if bool(split) != ops._C1Split.enabled:

@@ -164,3 +164,7 @@ def test_bench_two_ranks_prints_one_line():
     res = json.loads(lines[0])
     assert res['n_gpus'] == 2 and res['config']['global_batch'] == 8 and res['scaling'] == 'weak'
     assert res['value'] > 0 and 'roofline' in res
+    # a multi-GPU run prints the headline loop, the two step times and the two all-reduce times -- no side legs unless --side-legs
+    assert res['allreduce_ms']['backend'] == 'gloo' and res['allreduce_ms']['critic_grads'] > 0 and res['allreduce_ms']['generator_grads'] > 0
+    assert 'critic_step_ms' in res and 'generator_step_ms' in res and 'variant_fp32_mfma_gemms' not in res and 'pcie_inclusive' not in res
+    assert 'per rank' in res['config']['batchnorm_statistics'] and res['config']['collective_backend'] == 'gloo'

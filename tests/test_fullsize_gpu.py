@@ -136,6 +136,55 @@ def test_dense_split_products_full_size():
     close(db, dY.double().cpu().sum(0), 2e-4, 2e-3, 'dense db, full size')
 
 
+def test_context_conv1d_split_products_full_size():
+    """The DEFAULT context Conv1D at BASELINE size (csrc/split.hip: M = 25 600 frames, K = 21 x 601, N = 256; ops.conv1d on a
+    weight of a flat parameter buffer selects the bf16x6 split kernels) with direct oracle contact: the forward on frames at
+    utterance borders, at the 128-frame tile borders and at the stream-K segment borders (every output column), and the
+    frame-major weight gradient wgrad_bf16x6_kernel<21> -- rows of dW over all 25 600 frames -- plus the bias gradient,
+    against fp64 products of the fp32 operands.  Reference: networktts.py:116-120 (kl.Conv1D)."""
+    from percivaltts_amd import ops, layers, _hip
+    g = torch.Generator().manual_seed(31)
+    KW, N = 21, 256
+    x = torch.randn(B, T, CTX, generator=g).cuda()
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.randn(KW, CTX, N, generator=g) * 0.01)
+            self.b = torch.nn.Parameter(torch.randn(N, generator=g) * 0.1)
+    h = Holder(); layers.FlatParams(h, 'cuda'); w, b = h.w, h.b
+    with _hip.KernelTimer() as kt:
+        y = ops.conv1d(x, w, b)
+    names = [r[0] for r in kt.records]
+    assert 'ptts_conv1d_bf16x6' in names and 'ptts_gemm' not in names, names
+    w64 = w.detach().double().cpu().reshape(KW * CTX, N); b64 = b.detach().double().cpu()
+    xp = torch.zeros(B, T + KW - 1, CTX, dtype=torch.float64)
+    xp[:, KW // 2:KW // 2 + T] = x.double().cpu()
+    # frames: first / last of an utterance (zero padding), neighbours of the 128-frame tile borders (frame 25 599 = tile 199),
+    # an utterance border inside a tile (399 | 400), the middle
+    frames = [(0, 0), (0, 9), (0, 10), (0, 127), (0, 128), (0, 399), (1, 0), (1, 1), (17, 200), (31, 255), (31, 256), (63, 389), (63, 399)]
+    scale = float(y.abs().mean())
+    for (bi, t) in frames:
+        want = xp[bi, t:t + KW].reshape(-1) @ w64 + b64
+        err = float((y[bi, t].detach().double().cpu() - want).abs().max())
+        assert err < 1e-4 * scale + 2e-5 * float(want.abs().max()), 'conv1d frame ({}, {}): {:.3e} (scale {:.3e})'.format(bi, t, err, scale)
+    # weight gradient and bias gradient of all frames
+    dy = torch.randn(B, T, N, generator=g).cuda()
+    with _hip.KernelTimer() as kt:
+        y.backward(dy)
+    names = [r[0] for r in kt.records]
+    assert 'ptts_conv1d_wgrad_bf16x6' in names, names
+    dy64 = dy.double().cpu().reshape(B * T, N)
+    gw = w.grad.detach().double().cpu()
+    gscale = float(gw.abs().mean())
+    for (kw, ci) in ((0, 0), (0, 600), (3, 31), (10, 300), (10, 32), (20, 0), (20, 600), (7, 575), (7, 576)):      # taps at both ends, channel-block borders
+        col = xp[:, kw:kw + T, ci].reshape(-1)
+        want = col @ dy64
+        err = float((gw[kw, ci] - want).abs().max())
+        assert err < 2e-4 * gscale + 2e-5 * float(want.abs().max()), 'conv1d dW[{}, {}]: {:.3e} (scale {:.3e})'.format(kw, ci, err, gscale)
+    close(b.grad, dy64.sum(0), 2e-4, 2e-3, 'conv1d db, full size')
+
+
 def test_gemm_full_size_rows_and_linearity():
     from percivaltts_amd import ops
     g = torch.Generator().manual_seed(2)
@@ -460,10 +509,11 @@ def test_gated_dilated_causal_generator_at_T2000():
       * a gated layer at every dilation against the fp64 oracle on crops with their causal halo;
       * causality of the spectral branch in inference mode: frames before t0 - 10 (the context Conv1D looks 10 frames
         ahead) do not depend on the labels from t0 on;
-      * one critic step and one generator step run and give finite losses and gradients."""
+      * one critic step and one generator step run and give finite losses and gradients.
+    Batch 64 per GPU, as BASELINE configs[4] and the bench leg run it (round 2 tested B = 8)."""
     import bench
     from percivaltts_amd import vocoders, modeltts_common, networks_critic, optimizertts_wgan, backend_hip, ops, layers as kl
-    Bq, Tq = 8, 2000
+    Bq, Tq = 64, 2000
 
     class A: batch = Bq; frames = Tq; ctx = CTX
     cfg = bench.make_cfg(A)

@@ -280,6 +280,35 @@ def test_hipgraph_replay_matches_eager():
     close(outs[1][1], outs[0][1], 1e-3, 1e-5, 'critic weights after 3 steps, graph vs eager')
 
 
+def test_hipgraph_critic_costs_are_per_batch_and_async_whole_graph():
+    """costs_tra_critic_batches under cfg.train_wgan_hipgraph: every replay returns the SAME static loss tensor
+    of the captured graph, so the device-side cost list must copy it -- pending views would all read the last batch's loss.
+    Two different batches: the two fetched costs differ and equal the values read right after each step.  The same loop with
+    cfg.train_wgan_async_update in whole-graph mode (the update left pending by the warm-up must not leak a wait into the
+    capture): finite, and the weights move."""
+    from percivaltts_amd import optimizertts_wgan
+    for async_update in (False, True):
+        cfg, voc, mod, crit, a, gw, cw, X, Y, al = build('default')
+        cfg.train_wgan_hipgraph = True
+        cfg.train_wgan_async_update = async_update
+        opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype='WLSWGAN', critic=crit)
+        opt.prepare()
+        opt.generator_updates = 26
+        w0 = opt.critic_opti.flat.flat.detach().clone()
+        Xd, Yd = f32(X), f32(Y)
+        X2, Y2 = f32(X.flip(0) * 0.5), f32(Y.flip(1) + 0.25)
+        seen = []
+        for b, (xb, yb) in enumerate(((Xd, Yd), (X2, Y2), (Xd, Yd))):
+            lc, _ = opt.device_step(b + 1, xb, yb)            # batchid 1..3: critic steps only
+            opt.costs_tra_critic_batches.append_device(lc)
+            seen.append(float(lc.item()))
+        fetched = list(opt.costs_tra_critic_batches)
+        assert fetched == seen, (fetched, seen)
+        assert abs(seen[0] - seen[1]) > 1e-6 * max(1.0, abs(seen[0])), seen
+        opt.wait_updates(); torch.cuda.synchronize()
+        assert all(np.isfinite(v) for v in seen) and not torch.equal(w0, opt.critic_opti.flat.flat)
+
+
 def test_parallel_streams_match_single_stream():
     """cfg.train_wgan_parallel_streams runs the three critic evaluations on three HIP streams: same loss and gradients."""
     from percivaltts_amd import optimizertts_wgan

@@ -610,6 +610,86 @@ def test_conv1d_bf16x6_split_product(ops, case):
     close(db_split, br.grad, rtol=2e-4, atol=3e-4, what='db')
 
 
+@pytest.mark.parametrize('case', [(3, 129, 70, 256, 21), (2, 300, 601, 256, 21), (2, 130, 37, 128, 3)])
+def test_conv1d_bf16_products(ops, case):
+    """ops.bf16_products(True) (BASELINE configs[2]; build extension): the context Conv1D forward (gemm_bf16x1_kernel: three taps
+    per k-step) and its weight gradient (wgrad_bf16x6_kernel<KW, 1>) as ONE product of the operands' bf16 roundings with fp32
+    accumulation.  Oracle: the fp64 products of the ROUNDED operands (what is left is fp32 summation order: 2e-5 of the mean
+    magnitude, the bound of the fp32 kernels); and, as a sanity bound, within 2^-7 of the unrounded product's scale.  KW = 3 has
+    no three-taps-per-step kernel (KW >= 6): its forward stays on the six-product kernel, its weight gradient is one product."""
+    B, T, Cin, N, KW = case
+    g = gen(33)
+    x = torch.randn(B, T, Cin, generator=g).float()
+    w = (torch.randn(KW, Cin, N, generator=g) * (1.0 / (KW * Cin) ** 0.5)).float()
+    b = torch.randn(N, generator=g).float()
+    dy = torch.randn(B, T, N, generator=g).float()
+    bf = lambda t: t.to(torch.bfloat16).double()
+    one_fwd = KW >= 6
+    yr = O.conv1d_ntc(bf(x) if one_fwd else x.double(), bf(w) if one_fwd else w.double(), b.double())
+    wr = bf(w).requires_grad_(True)
+    O.conv1d_ntc(bf(x), wr, None).backward(bf(dy))          # dW = corr(bf16(x), bf16(dy))
+    ops.bf16_products(True)
+    try:
+        wd, bd = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+        with ops._hip.KernelTimer() as kt:
+            y = ops.conv1d(x.cuda(), wd, bd)
+            y.backward(dy.cuda())
+        torch.cuda.synchronize()
+    finally:
+        ops.bf16_products(False)
+    names = [r[0] for r in kt.records]
+    assert 'ptts_conv1d_bf16x6' in names and 'ptts_conv1d_wgrad_bf16x6' in names, names
+    scale = float(yr.abs().mean())
+    e = float((y.detach().double().cpu() - yr).abs().max()) / scale
+    assert e < 3e-5, 'forward vs the product of the rounded operands: {:.3e}'.format(e)
+    exact = O.conv1d_ntc(x.double(), w.double(), b.double())
+    assert float((y.detach().double().cpu() - exact).abs().max()) < 2.0 ** -5 * float(exact.abs().mean()) * 4
+    gs = float(wr.grad.abs().mean())
+    ge = float((wd.grad.double().cpu() - wr.grad).abs().max()) / gs
+    assert ge < 3e-5, 'weight gradient vs the product of the rounded operands: {:.3e}'.format(ge)
+    close(bd.grad, dy.double().sum((0, 1)), rtol=2e-4, atol=3e-4, what='db')
+
+
+def test_dense_bf16_products(ops):
+    """ops.bf16_products(True): Dense forward (pending LeakyReLU applied, then ONE rounding to bf16), backward-data with the
+    output mask, and the two-stage weight gradient as single products of bf16 roundings (csrc/dense.hip with one plane) against
+    the fp64 products of the rounded operands; the weight lies in a flat parameter buffer, as in the model."""
+    from percivaltts_amd import layers
+    g = gen(34)
+    M, K, N = 4096, 256, 256
+    A = torch.randn(M, K, generator=g).float(); dY = torch.randn(M, N, generator=g).float()
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.randn(K, N, generator=g) / 16)
+    h = Holder(); layers.FlatParams(h, 'cuda'); W = h.w
+    bias = torch.randn(N, generator=g).float()
+    bf = lambda t: t.to(torch.bfloat16).double()
+    W64 = bf(W.detach().cpu())
+    a_act = bf(torch.maximum(A, A * 0.3))          # the kernel's fp32 LeakyReLU, max(x, 0.3f x), then the one rounding to bf16
+    ops.bf16_products(True)
+    try:
+        Ad, dYd = A.cuda(), dY.cuda()
+        C1 = torch.empty(M, N, device='cuda'); dX = torch.empty(M, K, device='cuda'); dW = torch.empty(K, N, device='cuda'); db = torch.empty(N, device='cuda')
+        with ops._hip.KernelTimer() as kt:
+            ops.gemm_raw(Ad, W, C1, M, N, K, bias=bias.cuda(), mode=ops.IN_LRELU)
+            ops.gemm_raw(dYd, W, dX, M, K, N, transB=1, ldb=N, alpha=0.3, out_mask=Ad)
+            ops.gemm_raw(Ad, dYd, dW, K, N, M, transA=1, lda=K, rows_per_seg=M, mode=ops.IN_LRELU, alpha=0.3, colsum_b=db)
+        torch.cuda.synchronize()
+    finally:
+        ops.bf16_products(False)
+    names = [r[0] for r in kt.records]
+    assert names.count('ptts_dense_bf16x6') == 2 and 'ptts_dense_wgrad_bf16x6' in names, names
+    want = a_act @ W64 + bias.double()
+    assert float((C1.double().cpu() - want).abs().max()) < 3e-5 * float(want.abs().mean()) * 4, 'dense forward'
+    want = (bf(dY) @ W64.t()) * torch.where(A.double() > 0, 1.0, 0.3)
+    assert float((dX.double().cpu() - want).abs().max()) < 3e-5 * float(want.abs().mean()) * 4, 'dense backward data'
+    want = a_act.t() @ bf(dY)
+    assert float((dW.double().cpu() - want).abs().max()) < 3e-5 * float(want.abs().mean()) * 4, 'dense weight gradient'
+    close(db, dY.double().sum(0), rtol=2e-4, atol=2e-3, what='dense db')
+
+
 @pytest.mark.parametrize('shape', [(2, 12, 9, 4), (3, 50, 65, 4), (1, 7, 5, 3)])
 def test_gated_product(ops, shape):
     """y = a * sigmoid(b) and its backward (ptts_gated_mul_fwd/bwd: the Multiply + sigmoid of the reference's gated
