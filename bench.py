@@ -181,12 +181,16 @@ def roofline_leg(opt, X, Y, args):
                            'frac': fl / t / 1e12 / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
                            'launch_ms': t * 1e3, 'launches_per_critic_step': len(conv1d_fwd)}
     if conv1d_split:
-        # six bf16 products per fp32 product: the fp32-equivalent peak of this formulation is the dense bf16 peak / 6
+        # six bf16 products per fp32 product: the fp32-equivalent peak of this formulation is the dense bf16 peak / 6;
+        # with cfg.train_wgan_bf16_products (configs[2]) ONE bf16 product per position: the dense bf16 peak itself
         t = sum(conv1d_split) / len(conv1d_split) * 1e-3
         fl = 2.0 * M * N * K
-        out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_bf16x6_kernel (context Conv1D, M={} N={} K={}; algorithmic fp32 flop, 6 bf16 MFMA products each)'.format(M, N, K),
-                           'achieved': fl / t / 1e12, 'peak': PEAK_BF16_MFMA_TFLOPS / 6.0, 'unit': 'TFLOP/s',
-                           'frac': fl / t / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 6.0), 'traffic': None,
+        one = bool(getattr(opt.cfg, 'train_wgan_bf16_products', False))
+        peak = PEAK_BF16_MFMA_TFLOPS if one else PEAK_BF16_MFMA_TFLOPS / 6.0
+        out['roofline'] = {'bound': 'mfma', 'kernel': ('gemm_bf16x1_kernel (context Conv1D, M={} N={} K={}; bf16 products of the operands\' bf16 roundings, fp32 accumulation)' if one else
+                                                       'gemm_bf16x6_kernel (context Conv1D, M={} N={} K={}; algorithmic fp32 flop, 6 bf16 MFMA products each)').format(M, N, K),
+                           'achieved': fl / t / 1e12, 'peak': peak, 'unit': 'TFLOP/s',
+                           'frac': fl / t / 1e12 / peak, 'traffic': None,
                            'launch_ms': t * 1e3, 'launches_per_critic_step': len(conv1d_split)}
     if conv1d_bww:
         t = sum(conv1d_bww) / len(conv1d_bww) * 1e-3
@@ -226,7 +230,8 @@ def roofline_leg(opt, X, Y, args):
             tr = json.load(open(os.path.join(ROOT, 'profiles', cands[-1])))
             key = next((k for k in ('gemm_dma_kernel<0, 1>', 'gemm_dma_kernel<0>', 'gemm_f32_mfma_kernel<0, 0, 1, 0>') if k in tr), None)
             if conv1d_split:
-                key = 'gemm_bf16x6_kernel' if 'gemm_bf16x6_kernel' in tr else None
+                kname = 'gemm_bf16x1_kernel' if bool(getattr(opt.cfg, 'train_wgan_bf16_products', False)) else 'gemm_bf16x6_kernel'
+                key = kname if kname in tr else None
             if 'roofline' in out and key:
                 out['roofline']['traffic'] = tr[key]['hbm_bytes_per_launch']
                 out['roofline']['traffic_source'] = 'profiles/' + cands[-1]

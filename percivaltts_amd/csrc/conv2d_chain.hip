@@ -83,6 +83,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ void stamp(unsigned long long* dbg, int slot) {
     if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 32 + slot] = __builtin_amdgcn_s_memrealtime();
 }
+// ... and of the parts of one step (the second) as waves 0 (weight-gradient wave) and 7 see them: slots 16 + 8 (wave == 7) + i
+__device__ __forceinline__ void stamp_w(unsigned long long* dbg, int s, int wave, int lane, int i) {
+    if (dbg && s == 1 && lane == 0 && (wave == 0 || wave == 7)) dbg[(size_t)blockIdx.x * 32 + 16 + (wave == 7 ? 8 : 0) + i] = __builtin_amdgcn_s_memrealtime();
+}
 static unsigned long long* g_dbg = nullptr;
 
 // ------------------------------------------------------------------------------------------------------------
@@ -375,12 +379,24 @@ __device__ __forceinline__ void acc_add(f32x4 (&acc)[LMAX][2], int s, f32x4 c0, 
 }
 static_assert(LMAX == 8, "acc_add: eight cases");
 
+// dst[0..3] += the sums of v over the wave, by lane 0.  Data-parallel-primitive rotations inside the rows of 16 lanes and four
+// v_readlane: no LDS round trips (the butterfly of __shfl_xor -- six dependent ds_bpermute per component -- cost 1 us per step).
+__device__ __forceinline__ float row_sum16(float v) {
+    // after rotations by 8, 4, 2, 1 every lane of a row holds the row's sum
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
 __device__ __forceinline__ void wave_add4(float* dst, f32x4 v, int lane) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        float s = v[e];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float r = row_sum16(v[e]);
+        const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 0)) +
+                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 16)) +
+                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 32)) +
+                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 48));
         if (lane == 0) dst[e] += s;
     }
 }
@@ -590,14 +606,18 @@ __global__ __launch_bounds__(NT) void chain_bwd_kernel(BwdArgs a) {
                 const u16* Ac = (s & 1) ? A1 : A0;
                 u16* An = (s & 1) ? A0 : A1;
                 // the map of the next step: a_{l-2} (l - 2 >= 1: a padded map; l == 2: the stack's input, for the first layer's dW)
+                stamp_w(a.dbg, s, wave, lane, 0);
                 if (l >= 3) mp.load(a.maps + (long long)(l - 3) * g.map_stride, g, b, aorg, RA);
                 else if (l == 2 && WG) xp.load(a.x0, a.ldx, g, b, t0 - 2, TR + 4);        // rows t0 - 2 .. t0 + TR + 2 of the input
+                stamp_w(a.dbg, s, wave, lane, 1);
                 if (!WG && a.gmaps) rs.run(Dc + (t0 - dorg) * RS, a.gmaps + (long long)(l - 1) * g.map_stride + (long long)(b * g.T + t0) * g.FP * C, min(TR, g.T - t0));
                 if (WG && wave < KT) {
                     f32x4 c0 = zero4(), c1 = zero4();
                     dw_step(c0, c1, Ac + (t0 + wave - 2 - aorg) * RS, Dc + (t0 - dorg) * RS, g.ng, zero, lane);
+                    stamp_w(a.dbg, s, wave, lane, 2);
                     acc_add(acc, s, c0, c1);
                 }
+                stamp_w(a.dbg, s, wave, lane, 3);
                 if (l >= 2 || !WG) {
                     bf16x8 af[KT];
                     load_afrag(lds + (l - 1) * TLAY, lane, af);
@@ -605,7 +625,7 @@ __global__ __launch_bounds__(NT) void chain_bwd_kernel(BwdArgs a) {
                     const int ta = t0 - ext, tb = t0 + TR + ext;
                     if (l >= 2) {
                         f32x4 bs = zero4();
-                        conv_chunks<NW, WG, WG>(Dc, dorg, af, ta, tb, g, wave, s, lo, zero4(),
+                        conv_chunks<NW, WG, false>(Dc, dorg, af, ta, tb, g, wave, s, lo, zero4(),
                                    [&](int tc, int, int, int px) { return *reinterpret_cast<const bf16x4*>(Ac + (tc - aorg) * RS + px); },
                                    [&](int tc, int t, int, int px, f32x4 v, bf16x4 mk, bool ok, bool fresh) {
                                        const f32x4 m = to_f32(mk);
@@ -615,7 +635,9 @@ __global__ __launch_bounds__(NT) void chain_bwd_kernel(BwdArgs a) {
                                        if (WG && fresh && t >= t0 && t < t0 + TR) bs += v;
                                        *reinterpret_cast<bf16x4*>(Dn + (tc - dorg) * RS + px) = to_bf16(v);
                                    });
+                        stamp_w(a.dbg, s, wave, lane, 4);
                         if (WG) wave_add4(bsl + ((l - 2) * NW + wave) * 4, bs, lane);
+                        stamp_w(a.dbg, s, wave, lane, 5);
                     } else if (a.g0) {
                         // d/dx0: channel 0 of the transposed first layer, own rows, straight to HBM
                         conv_chunks<NW, false, false>(Dc, dorg, af, t0, t0 + TR, g, wave, s, lo, zero4(),
@@ -627,7 +649,9 @@ __global__ __launch_bounds__(NT) void chain_bwd_kernel(BwdArgs a) {
                 }
                 if (l >= 3) mp.commit(An, RA);
                 else if (l == 2 && WG) xp.commit(An + (EXTA - 2) * RS, TR + 4);
+                stamp_w(a.dbg, s, wave, lane, 6);
                 lds_barrier();
+                stamp_w(a.dbg, s, wave, lane, 7);
                 stamp(a.dbg, 3 + s);
             }
         }
@@ -747,7 +771,7 @@ __global__ __launch_bounds__(NT) void chain_second_kernel(SecArgs a) {
                 const bool last = l == L;
                 const u16* am = last ? a.a_last : a.maps + (long long)(l - 1) * g.map_stride;
                 const int apitch = last ? g.F : g.FP;
-                conv_chunks<NW, true, true>(Uc, uorg, af, ta, tb, g, wave, s, lo, zero4(),
+                conv_chunks<NW, true, false>(Uc, uorg, af, ta, tb, g, wave, s, lo, zero4(),
                            [&](int, int t, int f, int) {
                                bf16x4 m = to_bf16(zero4());
                                if ((unsigned)t < (unsigned)g.T && f < g.F) m = *reinterpret_cast<const bf16x4*>(am + ((long long)(b * g.T + t) * apitch + f) * C);
@@ -812,10 +836,11 @@ using namespace ptts::c2c;
 
 namespace {
 constexpr int NT = 512;
-// threads of the kernels without weight-gradient accumulators (forward, backward data): 512 or 1024 (PTTS_CHAIN_NT)
+// threads of the kernels without weight-gradient accumulators (forward, backward data): 1024 (16 waves: 7-9 % faster, a wave
+// issues one instruction per four cycles and has half the units of a step) or 512 (PTTS_CHAIN_NT=512)
 int wide_nt() {
     static int nt = -1;
-    if (nt < 0) { const char* e = getenv("PTTS_CHAIN_NT"); nt = (e && atoi(e) == 1024) ? 1024 : 512; }
+    if (nt < 0) { const char* e = getenv("PTTS_CHAIN_NT"); nt = (e && atoi(e) == 512) ? 512 : 1024; }
     return nt;
 }
 

@@ -82,6 +82,10 @@ def main():
         med = rel.median(dim=0).values
         last = 12 if name == 'fwd' else 10
         print(name, 'stamps (us from kernel start, median over workgroups):', [round(float(v), 1) for v in med[:last + 1]], flush=True)
+        if name in ('bwd', 'data'):
+            for w, o in ((0, 16), (7, 24)):
+                seg = (sb[:, o:o + 8] - sb[:, o:o + 1]) / 100.0
+                print('   step 2, wave', w, '[start, loads issued, dW done, acc added, conv done, bias sums, committed, barrier]:', [round(float(v), 2) for v in seg.median(dim=0).values], flush=True)
     # a critic step's stack: forward 2B + B, backward 2B, backward-data (+gamma) B, second order B
     tot = out['B128']['fwd'] + out['B64']['fwd'] + out['B128']['bwd'] + out['B64']['bwd_data+gamma'] + out['B64']['second']
     print('critic-step stack, us:', round(tot, 1), ' -> fraction of 8 TB/s on 1.993 GB:', round(1.993e9 / (tot * 1e-6) / 8e12, 3))
