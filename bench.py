@@ -244,7 +244,7 @@ def roofline_leg(opt, X, Y, args):
     return out
 
 
-def build_optimizer(args, ctx, spec, nm, batch, errtype, gated=False, bf16=None):
+def build_optimizer(args, ctx, spec, nm, batch, errtype, gated=False, bf16=None, graph=None):
     """Generator + critic + optimiser at one geometry (random-init weights of the named architecture)."""
     import io, contextlib
     from percivaltts_amd import vocoders, modeltts_common, networks_critic, optimizertts_wgan
@@ -254,9 +254,9 @@ def build_optimizer(args, ctx, spec, nm, batch, errtype, gated=False, bf16=None)
     cfg.train_wgan_bf16_products = bool(cfg.arch_critic_bf16)      # configs[2]: bf16 products in the GEMM-shaped layers as well
     if gated:       # BASELINE configs[4]: pGCNN2D spectral branch, time dilations 1,2,4,8,1,2,4,8, causal padding
         cfg.arch_gen_gated = True; cfg.arch_gen_dilations = [1, 2, 4, 8]; cfg.arch_gen_causal = True
-    cfg.train_wgan_hipgraph = bool(args.graph) and int(os.environ.get('WORLD_SIZE', '1')) <= 1
+    cfg.train_wgan_hipgraph = (bool(args.graph) if graph is None else graph) if int(os.environ.get('WORLD_SIZE', '1')) <= 1 else False
     cfg.train_wgan_prune_dead_branches = not args.no_prune
-    cfg.train_wgan_parallel_streams = (not args.no_streams) and not cfg.train_wgan_hipgraph
+    cfg.train_wgan_parallel_streams = (not args.no_streams) and cfg.train_wgan_hipgraph is not True
     cfg.train_wgan_stack_real_fake = not args.no_stack
     cfg.train_wgan_reuse_ctx_conv = not args.no_ctx_reuse
     cfg.train_wgan_early_critic = not args.no_early_critic
@@ -415,13 +415,14 @@ def main():
         # the reference's own training geometry (run.py:76,89,125-126): B=10 sentences of 400 frames, 425 context labels ->
         # 163 features (f0 1 + spec 129 + noise 33), same architecture; per rank
         rB, rT, rctx, rspec, rnm = 10, 400, 425, 129, 33
-        _, rvoc, _, _, ropt = build_optimizer(args, rctx, rspec, rnm, rB, args.errtype)
+        # launch-bound at 4 000 frames per step: replayed as a hipGraph (cfg.train_wgan_hipgraph = 'auto': batches of <= 8192 frames)
+        _, rvoc, _, _, ropt = build_optimizer(args, rctx, rspec, rnm, rB, args.errtype, graph='auto')
         rb = [synthetic(rB, rT, rctx, rvoc.featuressize(), rspec, 900 + 17 * rank + i, dev) for i in range(nbuf)]
         nr = max(10, min(args.steps, 100))
         dtr, rcyc = timed_loop(ropt, rb, nr, 10, dev)
         extra['reference_shape'] = {'workload': 'run.py geometry: [10,400,425] -> [10,400,163] (f0 1 + spec 129 + noise 33), per GPU',
                                     'value': nr * rB * rT * world / dtr, 'unit': 'frames/s', 'ms_per_step': dtr / nr * 1e3,
-                                    'steps': nr, 'cycle_ms': rcyc}
+                                    'steps': nr, 'cycle_ms': rcyc, 'hipgraph': bool(ropt._use_graph(rb[0][0]))}
         del ropt, rb
     if args.dtype == 'f32' and not args.no_bf16_leg:
         # BASELINE configs[2]: same shapes, the critic's conv stack with bf16 maps (gradient penalty on, lambda = 10)

@@ -128,7 +128,8 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         cfg.train_wgan_critic_LSWGANtransidx = None   # None: freq2fwspecidx(cutoff) of this build
         cfg.train_wgan_weight_clip = None             # c > 0: clamp critic weights to [-c, c] after each critic update
         cfg.train_wgan_prune_dead_branches = True
-        cfg.train_wgan_hipgraph = False
+        cfg.train_wgan_hipgraph = False              # True: every step replayed as a hipGraph; 'auto': only for batches of at most train_wgan_hipgraph_maxframes frames (launch-bound steps such as the reference's B = 10, run.py:125-126)
+        cfg.train_wgan_hipgraph_maxframes = 8192
         cfg.train_wgan_parallel_streams = False      # the critic evaluations on separate HIP streams
         cfg.train_wgan_stack_real_fake = True        # critic(real) and critic(fake) as one stacked 2B pass (exact: no BatchNorm)
         cfg.train_wgan_reuse_ctx_conv = True         # generator step reuses the critic step's G-context-Conv1D product (same batch)
@@ -387,6 +388,10 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             else:
                 fn = (lambda: self._critic_grads(sX, sY, sA)) if kind == 'critic' else (lambda: self._generator_grads(sX, sY))
             from . import layers
+            # the graph is captured on one stream: the evaluations' side streams would become cross-stream edges of the capture
+            saved_streams = (self.cfg.train_wgan_parallel_streams, getattr(self._model.kerasmodel, 'parallel_branches', False))
+            self.cfg.train_wgan_parallel_streams = False
+            self._model.kerasmodel.parallel_branches = False
             side = layers.side_streams(1, 'capture')[0]
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -403,6 +408,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             with torch.cuda.graph(g):
                 out = fn()
             ops.clear_caches()         # ... and the graph's private copies are not for eager code
+            self.cfg.train_wgan_parallel_streams, self._model.kerasmodel.parallel_branches = saved_streams
             ent = (g, sX, sY, sA, out)
             self._graphs[key] = ent
         g, sX, sY, sA, out = ent
@@ -420,10 +426,18 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             self._update(kind)
         return out
 
+    def _use_graph(self, X):
+        """cfg.train_wgan_hipgraph: True / False, or 'auto' = replay the step as a hipGraph when it is launch-bound (few frames:
+        about 1 000 launches of a few microseconds each against 8 ms of host enqueue time at the reference's B = 10)."""
+        g = self.cfg.train_wgan_hipgraph
+        if g == 'auto':
+            return X.shape[0] * X.shape[1] <= int(getattr(self.cfg, 'train_wgan_hipgraph_maxframes', 8192))
+        return bool(g)
+
     def device_step(self, batchid, X, Y, alpha=None):
         """One `train_on_batch` worth of device work on resident tensors; returns (critic_loss, generator_loss|None)
         as device scalars."""
-        use_graph = bool(self.cfg.train_wgan_hipgraph)
+        use_graph = self._use_graph(X)
         critic_runs = 10 if (self.generator_updates < 25) or (self.generator_updates % 500 == 0) else 5   # (:225-228)
         gen_too = batchid % critic_runs == 0
         # the generator step that follows on the same batch reuses the generator's context-Conv1D product of the critic

@@ -289,7 +289,7 @@ def test_hipgraph_critic_costs_are_per_batch_and_async_whole_graph():
     from percivaltts_amd import optimizertts_wgan
     for async_update in (False, True):
         cfg, voc, mod, crit, a, gw, cw, X, Y, al = build('default')
-        cfg.train_wgan_hipgraph = True
+        cfg.train_wgan_hipgraph = 'auto' if async_update else True      # 'auto': graphs for batches of <= 8192 frames (this one)
         cfg.train_wgan_async_update = async_update
         opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype='WLSWGAN', critic=crit)
         opt.prepare()
@@ -302,6 +302,7 @@ def test_hipgraph_critic_costs_are_per_batch_and_async_whole_graph():
             lc, _ = opt.device_step(b + 1, xb, yb)            # batchid 1..3: critic steps only
             opt.costs_tra_critic_batches.append_device(lc)
             seen.append(float(lc.item()))
+        assert opt._use_graph(Xd) and len(opt._graphs) == 1
         fetched = list(opt.costs_tra_critic_batches)
         assert fetched == seen, (fetched, seen)
         assert abs(seen[0] - seen[1]) > 1e-6 * max(1.0, abs(seen[0])), seen
