@@ -130,9 +130,12 @@ def croplen_weight(xs, w, thresh=0.5, cropmode='begend', cropsize=int(0.750 / 0.
     return xs, w
 
 
-def batching(xs, length=None, lengthmax=None, padtype='randshift', outmask=False):
+def batching(xs, length=None, lengthmax=None, padtype='randshift', outmask=False, rand=None):
     """Stack 2-D matrices into [B, length, feat] batches.  'randshift' takes a random window of `length` frames from
-    every sample (np.random.randint, so the numpy seed makes it repeatable); 'padright' zero-pads on the right."""
+    every sample (np.random.randint, so the numpy seed makes it repeatable); 'padright' zero-pads on the right.
+    `rand` (optional, one uniform number in [0, 1) per sample): the shift of sample b is floor(rand[b] * (number of possible
+    shifts)) instead of a fresh np.random.randint draw -- what data parallelism uses, so that a rank that loads only its
+    shard of the files takes the same windows as the process that loads the whole batch (load_inoutset)."""
     if len(set(len(x) for x in xs)) > 1:
         raise ValueError('the size of the data sets are not identical ({})'.format([len(x) for x in xs]))
     nb = len(xs[0])
@@ -151,7 +154,10 @@ def batching(xs, length=None, lengthmax=None, padtype='randshift', outmask=False
         samplelen = xs[0][b].shape[0]
         minlen = min(samplelen, length)
         if padtype == 'randshift':
-            shift = np.random.randint(0, (samplelen - length) + 1)
+            if rand is not None:
+                shift = min(int(rand[b] * ((samplelen - length) + 1)), samplelen - length)
+            else:
+                shift = np.random.randint(0, (samplelen - length) + 1)
         for xi, x in enumerate(xs):
             seg = x[b][shift:shift + minlen]
             xbs[xi][b, :minlen, :] = seg.reshape(minlen, -1)
@@ -169,15 +175,17 @@ def addstop(X, value=1.0):
 
 
 def load_inoutset(indir, outdir, outwdir, fid_lst, inouttimesync=True, length=None, lengthmax=None,
-                  maskpadtype='padright', cropmode='begend', verbose=0):
-    """Load one batch of inputs, outputs and time weights, cropped and windowed: X [B,T,ctx], Y [B,T,out], W [B,T,1]."""
+                  maskpadtype='padright', cropmode='begend', verbose=0, rand=None):
+    """Load one batch of inputs, outputs and time weights, cropped and windowed: X [B,T,ctx], Y [B,T,out], W [B,T,1]
+    (reference data.py:297-322).  `rand`: see batching -- the per-sample uniforms of the random window shifts, drawn by the
+    caller for the WHOLE global batch so that every rank can load its shard of `fid_lst` alone."""
     X = load(indir, fid_lst, verbose=verbose, label='Context labels: ')
     Y = load(outdir, fid_lst, verbose=verbose, label='Output features: ')
     W = load(outwdir, fid_lst, verbose=verbose, label='Time weights: ')
     if inouttimesync:
         X, Y, W = croplen([X, Y, W])
         [X, Y], W = croplen_weight([X, Y], W, cropmode=cropmode)
-        [X, Y, W], _ = batching([X, Y, W], length=length, lengthmax=lengthmax, padtype=maskpadtype)
+        [X, Y, W], _ = batching([X, Y, W], length=length, lengthmax=lengthmax, padtype=maskpadtype, rand=rand)
     else:
         X = addstop(X)
         Y, W = croplen([Y, W])

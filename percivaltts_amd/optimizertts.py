@@ -174,13 +174,23 @@ class OptimizerTTS:
             np.random.shuffle(rndidx)
             rndidxb = np.split(rndidx, nbbatches)
             costs_tra_batches, load_times, train_times = [], [], []
-            def make_batch(batchid, rndidxb=rndidxb):
-                fid_lst_trab = [fid_lst_tra[bidx] for bidx in rndidxb[batchid]]
+            world, rank = getattr(self, 'world', 1), getattr(self, 'rank', 0)
+            # data parallelism: a rank reads only the files of ITS shard of the global batch.  The random
+            # window shifts are drawn for the whole batch, up front and in batch order (every rank holds the same numpy RNG
+            # state), as uniforms that load_inoutset turns into shifts: W ranks take the windows one process would take.
+            shift_rand = [np.random.random_sample(int(self.cfg.train_batch_size)) for _ in range(nbbatches)] if world > 1 else None
+            def make_batch(batchid, rndidxb=rndidxb, shift_rand=shift_rand):
+                ids = rndidxb[batchid]
+                rnd = None
+                if world > 1:
+                    lo, hi = parallel.shard_batch(len(ids), world, rank)
+                    ids, rnd = ids[lo:hi], shift_rand[batchid][lo:hi]
+                fid_lst_trab = [fid_lst_tra[bidx] for bidx in ids]
                 X_trab, Y_trab, W_trab = data.load_inoutset(
                     indir, outdir, wdir, fid_lst_trab, length=self.cfg.train_batch_length,
                     lengthmax=self.cfg.train_batch_lengthmax, maskpadtype=self.cfg.train_batch_padtype,
-                    cropmode=self.cfg.train_batch_cropmode)
-                return self._local_shard(X_trab, Y_trab)      # only this rank's shard crosses PCIe
+                    cropmode=self.cfg.train_batch_cropmode, rand=rnd)
+                return X_trab, Y_trab                        # already this rank's shard: only it was read and crosses PCIe
 
             # batches are loaded, pinned and copied to the device two ahead of the step that consumes them
             prefetch = data.BatchPrefetcher(make_batch, nbbatches, device=self.device, depth=2)

@@ -164,6 +164,71 @@ def test_data_batching(tmp_path):
     assert data.prediction_rms(Stub(), [X]) == 0.0
 
 
+def test_loader_windows_are_the_files_frames_and_rank_shards_agree(tmp_path):
+    """load_inoutset (reference data.py:297-322 -> croplen :143-171, croplen_weight :173-231, batching :234-284): every returned
+    window must be the file's frames -- after the common-length crop and the silence crop of the time weights -- at the drawn
+    shift, for inputs, outputs and weights alike.  Then the data-parallel form: with the per-sample uniforms of the shifts
+    drawn for the whole batch (`rand`), a rank that loads only ITS shard of the file list gets exactly the rows the whole-batch
+    load gives (optimizertts.train_oneparamset shards the file ids before reading)."""
+    rng = np.random.RandomState(3)
+    fids = ['u{}'.format(i) for i in range(6)]
+    lens = [61, 75, 58, 90, 66, 71]
+    files = {}
+    for sub, dim in (('lab', 7), ('cmp', 5), ('w', 1)):
+        os.makedirs(str(tmp_path / sub))
+        for k, (fid, n) in enumerate(zip(fids, lens)):
+            arr = rng.rand(n + (2 if sub == 'lab' else 0), dim).astype(np.float32)      # labels two frames longer: croplen cuts them
+            if sub == 'w':
+                arr[:] = 1.0
+                arr[:4 + k] = 0.0                       # leading silence of 4 + k frames
+                arr[n - 3 - k:] = 0.0                   # trailing silence
+                arr[20:23] = 0.2                        # a short pause inside: 'begend' keeps it
+            files[(sub, fid)] = arr
+            arr.tofile(str(tmp_path / sub / (fid + '.' + sub)))
+    indir = str(tmp_path / 'lab' / '*.lab') + ':(-1,7)'
+    outdir = str(tmp_path / 'cmp' / '*.cmp') + ':(-1,5)'
+    wdir = str(tmp_path / 'w' / '*.w') + ':(-1,1)'
+    L = 24
+
+    def expected_rows(fid, k, shift):
+        n = lens[k]
+        w = files[('w', fid)][:n, 0]
+        on = np.where(w > 0.5)[0]
+        sel = slice(int(on.min()), int(on.max()))            # croplen_weight 'begend' (the reference's slice drops the last kept frame)
+        return (files[('lab', fid)][:n][sel][shift:shift + L], files[('cmp', fid)][:n][sel][shift:shift + L],
+                files[('w', fid)][:n][sel][shift:shift + L]), (sel.stop - sel.start)
+
+    # ---- np.random.randint shifts (one process): replay the draws
+    np.random.seed(11)
+    Xb, Yb, Wb = data.load_inoutset(indir, outdir, wdir, fids, length=None, lengthmax=L, maskpadtype='randshift', cropmode='begend')
+    assert Xb.shape == (6, L, 7) and Yb.shape == (6, L, 5) and Wb.shape == (6, L, 1)
+    np.random.seed(11)
+    for k, fid in enumerate(fids):
+        _, kept = expected_rows(fid, k, 0)
+        shift = np.random.randint(0, kept - L + 1)
+        (ex, ey, ew), _ = expected_rows(fid, k, shift)
+        assert np.array_equal(Xb[k], ex) and np.array_equal(Yb[k], ey) and np.array_equal(Wb[k], ew), (fid, shift)
+        assert kept == lens[k] - (4 + k) - (3 + k) - 1       # silence cropped at both ends
+    # ---- uniforms drawn for the whole batch: windows at floor(u * number of shifts); a rank's shard == the batch's rows
+    u = np.random.RandomState(5).random_sample(6)
+    Xa, Ya, Wa = data.load_inoutset(indir, outdir, wdir, fids, length=None, lengthmax=L, maskpadtype='randshift', cropmode='begend', rand=u)
+    for k, fid in enumerate(fids):
+        _, kept = expected_rows(fid, k, 0)
+        (ex, ey, ew), _ = expected_rows(fid, k, int(u[k] * (kept - L + 1)))
+        assert np.array_equal(Xa[k], ex) and np.array_equal(Ya[k], ey) and np.array_equal(Wa[k], ew)
+    from percivaltts_amd import parallel
+    for world in (2, 3):
+        for rank in range(world):
+            lo, hi = parallel.shard_batch(6, world, rank)
+            Xr, Yr, Wr = data.load_inoutset(indir, outdir, wdir, fids[lo:hi], length=None, lengthmax=L, maskpadtype='randshift',
+                                            cropmode='begend', rand=u[lo:hi])
+            assert np.array_equal(Xr, Xa[lo:hi]) and np.array_equal(Yr, Ya[lo:hi]) and np.array_equal(Wr, Wa[lo:hi]), (world, rank)
+    # ---- cropmode 'all' drops the pause inside as well
+    Xc, Yc, Wc = data.load_inoutset(indir, outdir, wdir, fids[:1], length=None, lengthmax=L, maskpadtype='randshift', cropmode='all', rand=np.zeros(1))
+    w0 = files[('w', 'u0')][:lens[0], 0]
+    assert np.array_equal(Yc[0], files[('cmp', 'u0')][:lens[0]][np.where(w0 > 0.5)[0]][:L]) and float(Wc.min()) == 1.0
+
+
 def test_batch_prefetcher_host_mode_order_and_errors():
     """data.BatchPrefetcher without a GPU: same iterator (order, contents, length), loader failures reach the consumer."""
     import numpy as np
