@@ -56,7 +56,8 @@ constexpr int HDR_BIAS = LMAX * TLAY * 2, HDR_ZERO = HDR_BIAS + LMAX * 16, HDR_B
 static_assert(HDR_ZERO + 64 <= HDR_BS, "header layout");
 // device table buffer: [LMAX][2 directions][TLAY] bf16, then [LMAX][4] fp32 biases
 constexpr size_t TAB_BIAS_OFF = (size_t)LMAX * 2 * TLAY * sizeof(u16);
-constexpr size_t TAB_BYTES = TAB_BIAS_OFF + LMAX * 4 * sizeof(float);
+constexpr size_t TAB_ZERO_OFF = TAB_BIAS_OFF + LMAX * 4 * sizeof(float);          // 64 zero bytes: the source of halo units in the map DMAs
+constexpr size_t TAB_BYTES = TAB_ZERO_OFF + 64;
 
 __host__ __device__ constexpr int unit_pos(int u) { return (u & ~3) | ((u & 1) << 1) | ((u >> 1) & 1); }
 __host__ __device__ constexpr int bin_off(int c) { return unit_pos(c >> 1) * 8 + (c & 1) * 4; }      // elements, staged bin c = f + 2
@@ -115,6 +116,7 @@ __global__ void chain_tables_kernel(TabArgs a, u16* __restrict__ tab, float* __r
         *reinterpret_cast<bf16x4*>(tab + (size_t)(l * 2 + transposed) * TLAY + (kt * C + oc) * TROW + slot * C) = to_bf16(v);
     }
     if (!transposed && idx < C) bias[l * C + idx] = a.b[l] ? a.b[l][idx] : 0.f;
+    if (blockIdx.x == 0 && idx < 16) reinterpret_cast<unsigned*>(bias + LMAX * C)[idx] = 0u;       // the zero block
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -131,27 +133,41 @@ struct Geo {
 // ------------------------------------------------------------------------------------------------------------
 // tile loaders (global -> registers -> LDS; the loads of the next step's tile are in flight while this step multiplies)
 // ------------------------------------------------------------------------------------------------------------
-// (a) a padded bf16 map: whole 16-byte units.  Slot k of a thread: unit image index tid + NT k -> (row r, position p)
+// (a) a padded bf16 map: whole 16-byte units, global -> LDS by DMA (global_load_lds_dwordx4: every lane names its own 16
+// source bytes, a wave-instruction fills 64 consecutive units of the tile's unit image; no staging registers, no ds_write --
+// the register-staged form held 20 VGPRs across a step, which the accumulator kernel spilled to scratch: the "prefetch" was
+// waited for right after its issue).  Slot k of a thread: unit image index tid + NT k -> (row r, position p); units without
+// data (the row halo, rows outside the utterance) read a zero block.  The caller waits (dma_wait) before the barrier that
+// publishes the tile.
+typedef void __attribute__((address_space(3)))* lds_void_ptr;
+__device__ __forceinline__ void dma16(const void* src, const u16* lds_wave_base) {
+    const unsigned lds_off = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long)(lds_void_ptr)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_off) : "memory", "m0");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <int NS, int NT>
-struct MapPref {
-    bf16x8 v[NS];
-    __device__ __forceinline__ void load(const u16* __restrict__ map, const Geo& g, int b, int t_org, int nrows) {
+struct MapDma {
+    int pk[NS];        // tile-independent: row << 16 | element offset of the unit inside a map row, or -1 (no data)
+    __device__ __forceinline__ void init(const Geo& g) {
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             const int idx = threadIdx.x + k * NT;
             const int r = (int)__umulhi((unsigned)idx, 116080198u /* ceil(2^32 / 37) */), p = idx - r * RSU;
-            const int u = unit_pos(p), t = t_org + r;
-            v[k] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
-            if (r < nrows && u >= 1 && 2 * u <= g.FP && (unsigned)t < (unsigned)g.T)
-                v[k] = *reinterpret_cast<const bf16x8*>(map + ((long long)(b * g.T + t) * g.FP + (2 * u - 2)) * C);
+            const int u = unit_pos(p);
+            pk[k] = (r << 16) | ((u >= 1 && 2 * u <= g.FP) ? (2 * u - 2) * C : 0xffff);
         }
     }
-    __device__ __forceinline__ void commit(u16* tile, int nrows) const {
+    // rows [t_org, t_org + nrows) of utterance b -> tile (row 0 <-> t_org)
+    __device__ __forceinline__ void issue(const u16* __restrict__ map, const Geo& g, int b, int t_org, int nrows, const u16* tile, const u16* zeros) const {
+        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const u16* base = map + (long long)(b * g.T + t_org) * g.FP * C;
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            const int idx = threadIdx.x + k * NT;
-            const int r = (int)__umulhi((unsigned)idx, 116080198u);
-            if (r < nrows) *reinterpret_cast<bf16x8*>(tile + (size_t)idx * 8) = v[k];       // unit image: row r, position p = idx - 37 r
+            if ((k * NT + wave * 64) >= nrows * RSU) break;                  // wave-uniform: nothing of this instruction is needed
+            const int r = pk[k] >> 16, uo = pk[k] & 0xffff, t = t_org + r;
+            const u16* src = (uo != 0xffff && (unsigned)t < (unsigned)g.T) ? base + (long long)r * g.FP * C + uo : zeros;
+            if (r < nrows) dma16(src, tile + (size_t)(k * NT + wave * 64) * 8);
         }
     }
 };
@@ -274,7 +290,7 @@ __device__ __forceinline__ int pair_of(int j, int c, int wave, int ng2, int rot)
 // (A hand-pipelined stream of single units -- reads of unit i + 1 before the MFMAs of unit i -- was built and measured 1.7 x
 // SLOWER: a wave issues one instruction per four cycles, and the scalar bookkeeping of the stream cost more than the LDS latency
 // it hid.  What counts here is the number of instructions per wave and step.)
-template <int NW, bool WG, bool SEQ, class Pre, class Epi>
+template <int NW, bool WG, bool SEQ, bool DUAL = false, class Pre, class Epi>
 __device__ __forceinline__ void conv_chunks(const u16* in, int in_torg, const bf16x8 (&a)[KT], int ta, int tb, const Geo& g,
                                             int wave_, int rot, const LaneOff& lo, f32x4 acc0, Pre&& pre, Epi&& epi) {
     constexpr int NWP = NW > 8 ? 8 : NW, CST = NW / NWP;
@@ -284,6 +300,47 @@ __device__ __forceinline__ void conv_chunks(const u16* in, int in_torg, const bf
         const int tc = min(ta + 16 * c, tb - 16);
         const int t = tc + lo.rl;
         const bool tin = (unsigned)t < (unsigned)g.T, fresh = t >= ta + 16 * c;
+        if (DUAL) {
+            // a wave that owns TWO full pairs at this chunk (the waves without weight-gradient work): all twenty fragment reads
+            // and the four mask fetches first, then four interleaved MFMA chains -- one exposed LDS latency per chunk instead of
+            // two, and the epilogue of one group under the MFMAs of the next
+            const int g0 = pair_of<NWP, WG>(0, c, wave, ng2, rot), g1 = pair_of<NWP, WG>(1, c, wave, ng2, rot);
+            if (g0 >= 0 && g1 >= 0 && 2 * g0 + 1 < g.ng && 2 * g1 + 1 < g.ng) {
+                const u16* bp0 = in + (tc - 2 - in_torg) * RS + 32 * g0;
+                const u16* bp1 = in + (tc - 2 - in_torg) * RS + 32 * g1;
+                const int f0 = 8 * g0 + lo.lg, f1 = 8 * g1 + lo.lg;
+                const int px0 = lo.pxA + 32 * g0, px1 = lo.pxB + 32 * g0, px2 = lo.pxA + 32 * g1, px3 = lo.pxB + 32 * g1;
+                auto p0 = pre(tc, t, f0, px0); auto p1 = pre(tc, t, f0 + 4, px1);
+                auto p2 = pre(tc, t, f1, px2); auto p3 = pre(tc, t, f1 + 4, px3);
+                bf16x8 b0[KT], b1[KT], b2[KT], b3[KT];
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    b0[kt] = *reinterpret_cast<const bf16x8*>(bp0 + lo.rdA + kt * RS);
+                    b1[kt] = *reinterpret_cast<const bf16x8*>(bp0 + lo.rdB + kt * RS);
+                }
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    b2[kt] = *reinterpret_cast<const bf16x8*>(bp1 + lo.rdA + kt * RS);
+                    b3[kt] = *reinterpret_cast<const bf16x8*>(bp1 + lo.rdB + kt * RS);
+                }
+                f32x4 x0 = acc0, x1 = acc0, x2 = acc0, x3 = acc0;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    x0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kt], b0[kt], x0, 0, 0, 0);
+                    x1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kt], b1[kt], x1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    x2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kt], b2[kt], x2, 0, 0, 0);
+                    x3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kt], b3[kt], x3, 0, 0, 0);
+                }
+                epi(tc, t, f0, px0, x0, p0, tin && f0 < g.F, fresh);
+                epi(tc, t, f0 + 4, px1, x1, p1, tin && f0 + 4 < g.F, fresh);
+                epi(tc, t, f1, px2, x2, p2, tin && f1 < g.F, fresh);
+                epi(tc, t, f1 + 4, px3, x3, p3, tin && f1 + 4 < g.F, fresh);
+                continue;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int gp = pair_of<NWP, WG>(j, c, wave, ng2, rot);
@@ -572,7 +629,9 @@ __global__ __launch_bounds__(NT) void chain_bwd_kernel(BwdArgs a) {
     u16* A1 = A0 + RA * RS;
     constexpr int NSA = ((TR + 4 * (LMAX - 1)) * RSU + NT - 1) / NT;
     constexpr int NSX = ((TR + 4) * 72 + NT - 1) / NT;
-    MapPref<NSA, NT> mp;
+    MapDma<NSA, NT> mp;
+    mp.init(g);
+    const u16* zpage = reinterpret_cast<const u16*>(reinterpret_cast<const char*>(a.tab) + TAB_ZERO_OFF);
     X0Pref<NSX, NT> xp;
     f32x4 acc[LMAX][2];
 #pragma unroll
@@ -585,11 +644,11 @@ __global__ __launch_bounds__(NT) void chain_bwd_kernel(BwdArgs a) {
         {
             f32x4 bs = zero4();
             const int e = WG ? 2 * (L - 1) : 2 * L;
+            if (L >= 2) mp.issue(a.maps + (long long)(L - 2) * g.map_stride, g, b, aorg, RA, A0, zpage);       // in flight under the first stage
             stage_d_last<NT, WG>(a, g, D0, dorg, b, t0 - e, t0 + TR + e, t0, bs);
             if (WG) wave_add4(bsl + ((L - 1) * NW + wave) * 4, bs, lane);
             if (L >= 2) {
-                mp.load(a.maps + (long long)(L - 2) * g.map_stride, g, b, aorg, RA);
-                mp.commit(A0, RA);
+                dma_wait();
             } else if (WG) {
                 xp.load(a.x0, a.ldx, g, b, aorg, RA);
                 xp.commit(A0, RA);
@@ -607,7 +666,7 @@ __global__ __launch_bounds__(NT) void chain_bwd_kernel(BwdArgs a) {
                 u16* An = (s & 1) ? A0 : A1;
                 // the map of the next step: a_{l-2} (l - 2 >= 1: a padded map; l == 2: the stack's input, for the first layer's dW)
                 stamp_w(a.dbg, s, wave, lane, 0);
-                if (l >= 3) mp.load(a.maps + (long long)(l - 3) * g.map_stride, g, b, aorg, RA);
+                if (l >= 3) mp.issue(a.maps + (long long)(l - 3) * g.map_stride, g, b, aorg, RA, An, zpage);
                 else if (l == 2 && WG) xp.load(a.x0, a.ldx, g, b, t0 - 2, TR + 4);        // rows t0 - 2 .. t0 + TR + 2 of the input
                 stamp_w(a.dbg, s, wave, lane, 1);
                 if (!WG && a.gmaps) rs.run(Dc + (t0 - dorg) * RS, a.gmaps + (long long)(l - 1) * g.map_stride + (long long)(b * g.T + t0) * g.FP * C, min(TR, g.T - t0));
@@ -625,7 +684,7 @@ __global__ __launch_bounds__(NT) void chain_bwd_kernel(BwdArgs a) {
                     const int ta = t0 - ext, tb = t0 + TR + ext;
                     if (l >= 2) {
                         f32x4 bs = zero4();
-                        conv_chunks<NW, WG, false>(Dc, dorg, af, ta, tb, g, wave, s, lo, zero4(),
+                        conv_chunks<NW, WG, false, false>(Dc, dorg, af, ta, tb, g, wave, s, lo, zero4(),      // (both pairs' reads in one burst measured 9 % slower here)
                                    [&](int tc, int, int, int px) { return *reinterpret_cast<const bf16x4*>(Ac + (tc - aorg) * RS + px); },
                                    [&](int tc, int t, int, int px, f32x4 v, bf16x4 mk, bool ok, bool fresh) {
                                        const f32x4 m = to_f32(mk);
@@ -647,7 +706,7 @@ __global__ __launch_bounds__(NT) void chain_bwd_kernel(BwdArgs a) {
                                    });
                     }
                 }
-                if (l >= 3) mp.commit(An, RA);
+                if (l >= 3) dma_wait();
                 else if (l == 2 && WG) xp.commit(An + (EXTA - 2) * RS, TR + 4);
                 stamp_w(a.dbg, s, wave, lane, 6);
                 lds_barrier();
@@ -733,7 +792,9 @@ __global__ __launch_bounds__(NT) void chain_second_kernel(SecArgs a) {
     u16* G1 = G0 + TR * RS;
     constexpr int NSG = (TR * RSU + NT - 1) / NT;
     constexpr int NSX = ((TR + 4 * LMAX) * 72 + NT - 1) / NT;
-    MapPref<NSG, NT> mp;
+    MapDma<NSG, NT> mp;
+    mp.init(g);
+    const u16* zpage = reinterpret_cast<const u16*>(reinterpret_cast<const char*>(a.tab) + TAB_ZERO_OFF);
     f32x4 acc[LMAX][2];
 #pragma unroll
     for (int s = 0; s < LMAX; ++s) { acc[s][0] = zero4(); acc[s][1] = zero4(); }
@@ -744,9 +805,9 @@ __global__ __launch_bounds__(NT) void chain_second_kernel(SecArgs a) {
         {
             X0Pref<NSX, NT> xp;
             xp.load(a.u0, g.F, g, b, uorg, RU);
-            mp.load(a.gmaps, g, b, t0, TR);
+            mp.issue(a.gmaps, g, b, t0, TR, G0, zpage);
             xp.commit(U0, RU);
-            mp.commit(G0, TR);
+            dma_wait();
         }
         lds_barrier();
         stamp(a.dbg, 2);
@@ -758,7 +819,7 @@ __global__ __launch_bounds__(NT) void chain_second_kernel(SecArgs a) {
                 u16* Un = (s & 1) ? U0 : U1;
                 const u16* Gc = (s & 1) ? G1 : G0;
                 u16* Gn = (s & 1) ? G0 : G1;
-                if (l < L) mp.load(a.gmaps + (long long)l * g.map_stride, g, b, t0, TR);
+                if (l < L) mp.issue(a.gmaps + (long long)l * g.map_stride, g, b, t0, TR, Gn, zpage);
                 if (wave < KT) {
                     f32x4 c0 = zero4(), c1 = zero4();
                     dw_step(c0, c1, Uc + (t0 + wave - 2 - uorg) * RS, Gc, g.ng, zero, lane);
@@ -771,7 +832,7 @@ __global__ __launch_bounds__(NT) void chain_second_kernel(SecArgs a) {
                 const bool last = l == L;
                 const u16* am = last ? a.a_last : a.maps + (long long)(l - 1) * g.map_stride;
                 const int apitch = last ? g.F : g.FP;
-                conv_chunks<NW, true, false>(Uc, uorg, af, ta, tb, g, wave, s, lo, zero4(),
+                conv_chunks<NW, true, false, true>(Uc, uorg, af, ta, tb, g, wave, s, lo, zero4(),
                            [&](int, int t, int f, int) {
                                bf16x4 m = to_bf16(zero4());
                                if ((unsigned)t < (unsigned)g.T && f < g.F) m = *reinterpret_cast<const bf16x4*>(am + ((long long)(b * g.T + t) * apitch + f) * C);
@@ -789,7 +850,7 @@ __global__ __launch_bounds__(NT) void chain_second_kernel(SecArgs a) {
                                    else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + off) = v;
                                }
                            });
-                if (l < L) mp.commit(Gn, TR);
+                if (l < L) dma_wait();
                 lds_barrier();
                 stamp(a.dbg, 3 + s);
             }
