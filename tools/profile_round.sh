@@ -2,12 +2,17 @@
 # Run ON THE GPU BOX (through gpurun): rocprofv3 kernel trace of the default bench command plus separate PMC passes
 # (HBM traffic of the dominant kernels) -> gpurun_out/prof_<tag>/ ; summarise with tools/summarize_profiles.py.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --steps 100 --warmup 20 > $OUT/bench.json 2> $OUT/bench.err
+# the HEADLINE loop only (one geometry per kernel: the averages of the trace are the per-launch times of the bench line), then
+# the same for BASELINE configs[2] (--dtype bf16)
+LEGS="--no-variants --no-unreduced --no-host-leg --no-reference-shape --no-bf16-leg --no-gated-leg --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $LEGS --steps 100 --warmup 20 > $OUT/bench.json 2> $OUT/bench.err
 echo "trace done" > $OUT/progress.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_bf16 -- python3 bench.py --dtype bf16 $LEGS --steps 100 --warmup 20 > $OUT/bench_bf16.json 2> $OUT/bench_bf16.err
+echo "bf16 trace done" >> $OUT/progress.txt
 # HBM traffic: FETCH_SIZE and WRITE_SIZE in passes of their own (TCC slots), kernel trace only beside them
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_split -- python3 tools/split_probe.py 3 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_split -- python3 tools/split_probe.py 3 > /dev/null 2>&1
@@ -22,6 +27,10 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM SQ_INSTS_SALU --output-format csv -d $OUT/pmc_lds_conv -- python3 tools/conv2d_mfma_probe.py > /dev/null 2>&1
 unset C2M_ONLY
 echo "conv pmc done" >> $OUT/progress.txt
+# the fused conv-stack kernels (csrc/conv2d_chain.hip): SQ / LDS counters and HBM traffic, summarised by the script itself
+bash tools/chain_pmc.sh > $OUT/chain_pmc.log 2>&1
+cp gpurun_out/chain_pmc/summary.json $OUT/chain_summary.json
+echo "chain pmc done" >> $OUT/progress.txt
 # summarise on the box (the raw traces are too large to travel back) into gpurun_out/prof_<tag>/summary/
 python3 tools/summarize_profiles.py $TAG $OUT/summary > $OUT/summary.log 2>&1
 rm -f $OUT/*/runc/*_kernel_trace.csv $OUT/*/runc/*_counter_collection.csv $OUT/*/runc/*_domain_stats.csv

@@ -8,7 +8,7 @@ import json
 import os
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 src = os.path.join('gpurun_out', 'prof_' + tag)
 outdir = sys.argv[2] if len(sys.argv) > 2 else 'profiles'
 os.makedirs(outdir, exist_ok=True)
@@ -21,7 +21,7 @@ def short(name):
 
 rows = list(csv.DictReader(open(max(glob.glob(src + '/trace/runc/*_kernel_stats.csv'), key=os.path.getmtime))))
 total = sum(float(r['TotalDurationNs']) for r in rows)
-lines = ['# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline   (round %s)' % tag,
+lines = ['# rocprofv3 --kernel-trace --stats -- python bench.py (headline loop only: --no-variants --no-unreduced --no-host-leg --no-reference-shape --no-bf16-leg --no-gated-leg --no-cpu-baseline)   (round %s)' % tag,
          '# total kernel time %.1f ms' % (total / 1e6),
          '%8s %12s %11s %11s %11s %6s  %s' % ('calls', 'total_us', 'avg_us', 'min_us', 'max_us', '%', 'kernel')]
 for r in rows[:40]:
@@ -30,6 +30,26 @@ for r in rows[:40]:
 open(outdir + '/%s_kernel_stats.txt' % tag, 'w').write('\n'.join(lines) + '\n')
 bench = open(src + '/bench.json').read().strip()
 open(outdir + '/%s_bench_under_rocprof.json' % tag, 'w').write(bench + '\n')
+# the same for the configs[2] run (--dtype bf16)
+bf = glob.glob(src + '/trace_bf16/runc/*_kernel_stats.csv')
+if bf:
+    rows16 = list(csv.DictReader(open(max(bf, key=os.path.getmtime))))
+    total16 = sum(float(r['TotalDurationNs']) for r in rows16)
+    l16 = ['# rocprofv3 --kernel-trace --stats -- python bench.py --dtype bf16 (headline loop only)   (round %s)' % tag,
+           '# total kernel time %.1f ms' % (total16 / 1e6),
+           '%8s %12s %11s %11s %11s %6s  %s' % ('calls', 'total_us', 'avg_us', 'min_us', 'max_us', '%', 'kernel')]
+    for r in rows16[:40]:
+        l16.append('%8s %12.1f %11.1f %11.1f %11.1f %6.2f  %s' % (r['Calls'], float(r['TotalDurationNs']) / 1e3, float(r['AverageNs']) / 1e3,
+                   float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3, float(r['Percentage']), short(r['Name'])))
+    open(outdir + '/%s_kernel_stats_bf16.txt' % tag, 'w').write('\n'.join(l16) + '\n')
+    if os.path.exists(src + '/bench_bf16.json'):
+        open(outdir + '/%s_bench_bf16_under_rocprof.json' % tag, 'w').write(open(src + '/bench_bf16.json').read().strip() + '\n')
+if os.path.exists(src + '/chain_summary.json'):
+    cs = json.load(open(src + '/chain_summary.json'))
+    for k, d in cs.items():       # gfx950: FETCH_SIZE counts half the bytes of a wide coalesced read; counters are in KiB
+        if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
+            d['hbm_bytes_per_launch'] = (2 * d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024
+    json.dump(cs, open(outdir + '/%s_conv2d_chain_counters.json' % tag, 'w'), indent=1, sort_keys=True)
 
 
 def pmc(dirname, counter):
