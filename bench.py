@@ -39,6 +39,7 @@ def parse():
     ap.add_argument('--ctx', type=int, default=601)
     ap.add_argument('--errtype', default='WLSWGAN')
     ap.add_argument('--graph', action='store_true', help='capture each step once and replay it as a hipGraph (single stream)')
+    ap.add_argument('--no-graph', action='store_true', help="never replay a step as a hipGraph (the default, cfg.train_wgan_hipgraph = 'tune', times eager launches against a replay per step kind on the first batch and keeps the faster)")
     ap.add_argument('--eager', action='store_true', help='(default) eager launches; kept for compatibility')
     ap.add_argument('--no-prune', action='store_true', help="also run G's f0/noise branches in the critic step")
     ap.add_argument('--no-stack', action='store_true', help='evaluate critic(real) and critic(fake) separately instead of as one 2B pass')
@@ -254,9 +255,10 @@ def build_optimizer(args, ctx, spec, nm, batch, errtype, gated=False, bf16=None,
     cfg.train_wgan_bf16_products = bool(cfg.arch_critic_bf16)      # configs[2]: bf16 products in the GEMM-shaped layers as well
     if gated:       # BASELINE configs[4]: pGCNN2D spectral branch, time dilations 1,2,4,8,1,2,4,8, causal padding
         cfg.arch_gen_gated = True; cfg.arch_gen_dilations = [1, 2, 4, 8]; cfg.arch_gen_causal = True
-    cfg.train_wgan_hipgraph = (bool(args.graph) if graph is None else graph) if int(os.environ.get('WORLD_SIZE', '1')) <= 1 else False
+    cfg.train_wgan_hipgraph = ((True if args.graph else False if args.no_graph else 'tune') if graph is None else graph) if int(os.environ.get('WORLD_SIZE', '1')) <= 1 else False
     cfg.train_wgan_prune_dead_branches = not args.no_prune
-    cfg.train_wgan_parallel_streams = (not args.no_streams) and cfg.train_wgan_hipgraph is not True
+    cfg.train_wgan_graph_streams = os.environ.get('PTTS_GRAPH_STREAMS', '0') == '1'      # (experiment) fork / join inside the capture
+    cfg.train_wgan_parallel_streams = (not args.no_streams) and (cfg.train_wgan_hipgraph is not True or cfg.train_wgan_graph_streams)
     cfg.train_wgan_stack_real_fake = not args.no_stack
     cfg.train_wgan_reuse_ctx_conv = not args.no_ctx_reuse
     cfg.train_wgan_early_critic = not args.no_early_critic
@@ -336,6 +338,12 @@ def main():
     batches = [synthetic(B, T, args.ctx, voc.featuressize(), spec, 123 + 17 * rank + i, dev) for i in range(nbuf)]
 
     # ---- the headline loop ------------------------------------------------------------------------------------------
+    # cfg.train_wgan_hipgraph = 'tune': the choice eager launches / hipGraph replay per step kind is made here, on the first batch
+    # and before the warm-up (the training state is put back after the timing runs)
+    hipgraph_choice = {'critic': bool(opt._use_graph(batches[0][0], 'critic', batches[0][1])),
+                       'generator': bool(opt._use_graph(batches[0][0], 'generator', batches[0][1])),
+                       'mode': cfg.train_wgan_hipgraph,
+                       'tuning_ms': {k[0]: {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in opt._graph_tuning.items()}}
     dt, cyc = timed_loop(opt, batches, args.steps, args.warmup, dev)
     extra = {}
     if cyc:
@@ -373,9 +381,15 @@ def main():
         for _ in range(n): fn()
         torch.cuda.synchronize()
         return (time.time() - t) / n * 1e3
-    use_graph = bool(cfg.train_wgan_hipgraph)
-    extra['critic_step_ms'] = timeit((lambda: opt._graphed('critic', X, Y)) if use_graph else (lambda: opt.critic_step(X, Y)), 10)
-    extra['generator_step_ms'] = timeit((lambda: opt._graphed('generator', X, Y)) if use_graph else (lambda: opt.generator_step(X, Y)), 5)
+    graph_c, graph_g = bool(opt._use_graph(X, 'critic', Y)), bool(opt._use_graph(X, 'generator', Y))
+    extra['critic_step_ms'] = timeit((lambda: opt._graphed('critic', X, Y)) if graph_c else (lambda: opt.critic_step(X, Y)), 10)
+    extra['generator_step_ms'] = timeit((lambda: opt._graphed('generator', X, Y)) if graph_g else (lambda: opt.generator_step(X, Y)), 5)
+    import ctypes
+    from percivaltts_amd import _hip
+    st3 = [ctypes.c_ulonglong(0) for _ in range(3)]
+    _hip.lib().ptts_lstm_graph_stats(*[ctypes.byref(v) for v in st3])
+    extra['lstm_graph'] = {'replays': st3[0].value, 'captures': st3[1].value, 'plain_launch_fallbacks': st3[2].value,
+                           'what': "the BLSTM's 400-step recurrences (forward, backward) replayed as one hipGraph launch each"}
     if world > 1:
         # the two exchanges of a cycle, timed on their own (HIP events on the launch stream, max over ranks): all-reduce (sum) of
         # the flat fp32 gradient bucket of each network
@@ -468,7 +482,7 @@ def main():
                                    'step = one train_on_batch'.format(n=2 if args.dtype == 'bf16' else 1, b=B, t=T, c=args.ctx, o=voc.featuressize(), e=args.errtype,
                                                                       d='bf16 (see config.bf16)' if args.dtype == 'bf16' else 'fp32'),
                        'per_gpu_batch': B, 'global_batch': B * world, 'frames_per_step_per_gpu': B * T,
-                       'parallelism': 'dp{}'.format(world), 'hipgraph': bool(cfg.train_wgan_hipgraph),
+                       'parallelism': 'dp{}'.format(world), 'hipgraph': hipgraph_choice,
                        'hip_streams': 3 if par_streams else 1,
                        'prune_dead_generator_branches_in_critic_step': bool(cfg.train_wgan_prune_dead_branches),
                        'stack_real_fake_critic_pass': bool(cfg.train_wgan_stack_real_fake),

@@ -399,6 +399,14 @@ size_t ptts_lstm_bwd_workspace_bytes(int B, int T, int H, int ndir);
 int ptts_lstm_bwd(const float* dh_out /*[B,T,ndir*H]*/, const float* U, const float* gates, const float* c_out,
                   float* dgates, void* workspace, size_t workspace_bytes,
                   int B, int T, int H, int ndir, int reverse, void* stream);
+/* Optionally the T step launches of a recurrence go out as ONE hipGraph launch: the chain of a (pointers, shape) tuple is captured once and
+ * replayed while the same addresses come back (a training loop's allocation pattern repeats); misses capture anew (16 entries,
+ * least recently used dropped), repeated misses fall back to plain launches, a call inside a stream capture joins that capture.
+ * Off by default; PTTS_LSTM_GRAPH=1 or ptts_set_lstm_graph(1) switch it on.  Counters since load: replays, captures,
+ * plain-launch fallbacks. */
+int ptts_set_lstm_graph(int on);
+int ptts_lstm_graph_stats(unsigned long long* hits, unsigned long long* captures, unsigned long long* direct);
+int ptts_lstm_graph_clear(void);
 
 #ifdef __cplusplus
 }

@@ -105,6 +105,9 @@ SIGNATURES = {
     'ptts_lstm_fwd': (c_i, [c_p] * 5 + [c_p, c_sz] + [c_i] * 5 + [c_p]),
     'ptts_lstm_bwd_workspace_bytes': (c_sz, [c_i] * 4),
     'ptts_lstm_bwd': (c_i, [c_p] * 5 + [c_p, c_sz] + [c_i] * 5 + [c_p]),
+    'ptts_set_lstm_graph': (c_i, [c_i]),
+    'ptts_lstm_graph_stats': (c_i, [c_p] * 3),
+    'ptts_lstm_graph_clear': (c_i, []),
 }
 
 _lib = None

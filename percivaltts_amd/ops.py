@@ -1445,6 +1445,16 @@ def gated_mul(a, b):
 # ----------------------------------------------------------------------------------------------
 # LSTM / Bidirectional LSTM (networktts.py:72-96)
 # ----------------------------------------------------------------------------------------------
+lstm_trace = None        # a list: (tag, HIP event on the recurrence's stream) around the step chains (tools/gen_timeline.py events)
+
+
+def _lstm_mark(tag):
+    if lstm_trace is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        lstm_trace.append((tag, ev))
+
+
 class LSTMFn(torch.autograd.Function):
     """x [B,T,In]; W [In, ndir*4H]; U [ndir,H,4H]; b [ndir*4H] -> h [B,T,ndir*H] (Keras gate order i,f,c,o)."""
     @staticmethod
@@ -1460,7 +1470,9 @@ class LSTMFn(torch.autograd.Function):
         c = torch.empty((B, T, ndir * H), dtype=torch.float32, device=dev)
         gates = torch.empty((B, T, ndir * G4), dtype=torch.float32, device=dev)
         wsf = _workspace(_hip.lib().ptts_lstm_fwd_workspace_bytes(B, T, H, ndir), dev)
+        _lstm_mark('fwd0')
         call('ptts_lstm_fwd', ptr(xproj), ptr(U), ptr(h), ptr(gates), ptr(c), ptr(wsf), wsf.numel(), B, T, H, ndir, int(reverse), stream())
+        _lstm_mark('fwd1')
         ctx.save_for_backward(x, W, U, h, c, gates)
         ctx.reverse = int(reverse)
         return h
@@ -1476,8 +1488,10 @@ class LSTMFn(torch.autograd.Function):
         dgates = torch.empty_like(gates)
         nws = _hip.lib().ptts_lstm_bwd_workspace_bytes(B, T, H, ndir)
         ws = _workspace(nws, dev)
+        _lstm_mark('bwd0')
         call('ptts_lstm_bwd', ptr(dh), ptr(U), ptr(gates), ptr(c), ptr(dgates), ptr(ws), ws.numel(),
              B, T, H, ndir, ctx.reverse, stream())
+        _lstm_mark('bwd1')
         M = B * T
         dx = dW = dU = db = None
         if ctx.needs_input_grad[0]:

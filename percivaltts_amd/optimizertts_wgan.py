@@ -21,6 +21,8 @@ shard of the minibatch and the flat gradient buffer of the network being updated
 from __future__ import print_function
 
 import numpy as np
+import time
+
 import torch
 
 from . import backend_hip
@@ -216,6 +218,8 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         self.critic_model = self.critic_net
         self.generator_model = generator
         self._graphs = {}
+        self._graph_choice = {}      # cfg.train_wgan_hipgraph = 'tune': (kind, shapes) -> replay the step as a hipGraph?
+        self._graph_tuning = {}      # ... and the two timings behind the choice
         self._pending = {}           # 'critic' / 'generator' -> event of an optimiser update still running on the communication stream
         self._comm = None
 
@@ -372,6 +376,57 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         self._update('generator')
         return total
 
+    # ---- training state kept across the extra step executions of a capture / tuning run ------------------------------------
+    def _state_snapshot(self):
+        """Everything a training step changes: both networks' weights, Adam moments and step counters, the layers' buffers
+        (BatchNorm moving averages) and the device's random stream."""
+        self.wait_updates()
+        snap = {'opt': [], 'buf': [], 'rng': torch.cuda.get_rng_state(), 'gen_updates': self.generator_updates}
+        for o in (self.critic_opti, self.gen_opti):
+            snap['opt'].append((o, o.flat.flat.clone(), o.m.clone(), o.v.clone(), o.step_count.clone()))
+        for net in (self.critic_net, self._model.kerasmodel):
+            for b in net.buffers():
+                snap['buf'].append((b, b.clone()))
+        return snap
+
+    def _state_restore(self, snap):
+        self.wait_updates()
+        for o, w, m, v, t in snap['opt']:
+            o.flat.flat.copy_(w); o.m.copy_(m); o.v.copy_(v); o.step_count.copy_(t)
+            o.flat.epoch += 1                     # weights changed behind every weight-keyed cache
+        for b, val in snap['buf']:
+            b.copy_(val)
+        torch.cuda.set_rng_state(snap['rng'])
+        self.generator_updates = snap['gen_updates']
+        ops.clear_caches()
+
+    def _tune_graph(self, kind, X, Y):
+        """cfg.train_wgan_hipgraph = 'tune': time the step of this kind and shape eagerly (side streams on) and as a hipGraph
+        replay (single stream, no host work), keep the faster.  The timing runs are real steps on the first batch, so the training
+        state is put back afterwards: the run that follows is the one an untuned run would have made."""
+        key = (kind, tuple(X.shape), tuple(Y.shape))
+        if key in self._graph_choice:
+            return self._graph_choice[key]
+        snap = self._state_snapshot()
+        def timed(fn, n=3):
+            torch.cuda.synchronize()
+            t = time.time()
+            for _ in range(n): fn()
+            torch.cuda.synchronize()
+            return (time.time() - t) / n
+        eager = (lambda: self.critic_step(X, Y)) if kind == 'critic' else (lambda: self.generator_step(X, Y))
+        graph = lambda: self._graphed(kind, X, Y)
+        for _ in range(2): eager()          # both forms warm (allocator, weight-keyed caches, the capture itself) before either is timed
+        graph()
+        t_eager, t_graph = [], []
+        for _ in range(2):                  # alternating: clocks and caches drift over the first seconds of a process
+            t_eager.append(timed(eager)); t_graph.append(timed(graph))
+        t_eager, t_graph = min(t_eager), min(t_graph)
+        self._state_restore(snap)
+        self._graph_choice[key] = bool(t_graph < t_eager)
+        self._graph_tuning[key] = {'eager_ms': t_eager * 1e3, 'graph_ms': t_graph * 1e3, 'graph': bool(t_graph < t_eager)}
+        return self._graph_choice[key]
+
     # hipGraph replay of a whole step: static input buffers, one capture per (kind, shape)
     def _graphed(self, kind, X, Y, alpha=None):
         """hipGraph replay of a step.  One process: the whole step (forward, backward, Adam) is one graph.  Data parallel: the
@@ -380,7 +435,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         key = (kind, tuple(X.shape), tuple(Y.shape), whole)
         ent = self._graphs.get(key)
         if ent is None:
-            self.wait_updates()
+            snap = self._state_snapshot()       # the warm-up below runs real steps: the state is put back before the first replay
             sX, sY = X.clone(), Y.clone()
             sA = torch.rand(X.shape[0], device=X.device, dtype=torch.float32)
             if whole:
@@ -390,8 +445,9 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             from . import layers
             # the graph is captured on one stream: the evaluations' side streams would become cross-stream edges of the capture
             saved_streams = (self.cfg.train_wgan_parallel_streams, getattr(self._model.kerasmodel, 'parallel_branches', False))
-            self.cfg.train_wgan_parallel_streams = False
-            self._model.kerasmodel.parallel_branches = False
+            if not bool(getattr(self.cfg, 'train_wgan_graph_streams', False)):
+                self.cfg.train_wgan_parallel_streams = False
+                self._model.kerasmodel.parallel_branches = False
             side = layers.side_streams(1, 'capture')[0]
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -411,6 +467,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             self.cfg.train_wgan_parallel_streams, self._model.kerasmodel.parallel_branches = saved_streams
             ent = (g, sX, sY, sA, out)
             self._graphs[key] = ent
+            self._state_restore(snap)
         g, sX, sY, sA, out = ent
         sX.copy_(X); sY.copy_(Y)
         if kind == 'critic':
@@ -426,34 +483,43 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             self._update(kind)
         return out
 
-    def _use_graph(self, X):
-        """cfg.train_wgan_hipgraph: True / False, or 'auto' = replay the step as a hipGraph when it is launch-bound (few frames:
-        about 1 000 launches of a few microseconds each against 8 ms of host enqueue time at the reference's B = 10)."""
+    def _use_graph(self, X, kind=None, Y=None):
+        """cfg.train_wgan_hipgraph: True / False; 'auto' = replay the step as a hipGraph when it is launch-bound (few frames:
+        about 1 000 launches of a few microseconds each against 8 ms of host enqueue time at the reference's B = 10); 'tune' = as
+        'auto' below the frame threshold, above it measured per step kind on the first batch (`_tune_graph`): a step whose kernels
+        are short against the host's enqueue time (the bf16 critic step) replays faster than it launches, one that lives on
+        overlapping streams (the generator step's BLSTM branch) does not."""
         g = self.cfg.train_wgan_hipgraph
-        if g == 'auto':
-            return X.shape[0] * X.shape[1] <= int(getattr(self.cfg, 'train_wgan_hipgraph_maxframes', 8192))
+        if g in ('auto', 'tune'):
+            if X.shape[0] * X.shape[1] <= int(getattr(self.cfg, 'train_wgan_hipgraph_maxframes', 8192)):
+                return True
+            if g == 'tune' and kind is not None and self.world == 1:
+                return self._tune_graph(kind, X, Y)
+            return False
         return bool(g)
 
     def device_step(self, batchid, X, Y, alpha=None):
         """One `train_on_batch` worth of device work on resident tensors; returns (critic_loss, generator_loss|None)
         as device scalars."""
-        use_graph = self._use_graph(X)
         critic_runs = 10 if (self.generator_updates < 25) or (self.generator_updates % 500 == 0) else 5   # (:225-228)
         gen_too = batchid % critic_runs == 0
         # the generator step that follows on the same batch reuses the generator's context-Conv1D product of the critic
         # step's fake sample (same input, same not-yet-updated kernel): ops._C1Cache, valid inside this call only
-        ops.conv1d_cache(gen_too and not use_graph and bool(getattr(self.cfg, 'train_wgan_reuse_ctx_conv', True)))
         ops.bf16_products(bool(getattr(self.cfg, 'train_wgan_bf16_products', False)))
         split = getattr(self.cfg, 'train_wgan_split_bf16', None)
         if split is not None:
             if bool(split) != ops._C1Split.enabled:
                 ops.conv1d_split(split)
             ops.dense_split(split)
+        graph_c = self._use_graph(X, 'critic', Y)
+        graph_g = gen_too and self._use_graph(X, 'generator', Y)
+        use_graph = graph_c or graph_g
+        ops.conv1d_cache(gen_too and not use_graph and bool(getattr(self.cfg, 'train_wgan_reuse_ctx_conv', True)))
         try:
-            lc = self._graphed('critic', X, Y, alpha) if use_graph else self.critic_step(X, Y, alpha)
+            lc = self._graphed('critic', X, Y, alpha) if graph_c else self.critic_step(X, Y, alpha)
             lg = None
             if gen_too:
-                lg = self._graphed('generator', X, Y) if use_graph else self.generator_step(X, Y)
+                lg = self._graphed('generator', X, Y) if graph_g else self.generator_step(X, Y)
                 self.generator_updates += 1
         finally:
             ops.conv1d_cache(False)

@@ -310,6 +310,42 @@ def test_hipgraph_critic_costs_are_per_batch_and_async_whole_graph():
         assert all(np.isfinite(v) for v in seen) and not torch.equal(w0, opt.critic_opti.flat.flat)
 
 
+def test_hipgraph_tune_restores_training_state_and_trains_like_eager():
+    """cfg.train_wgan_hipgraph = 'tune' times eager launches against a hipGraph replay per step kind with REAL steps on the first
+    batch: weights, Adam moments and step counters, BatchNorm moving averages and the device's random stream must be back
+    afterwards, so that the steps that follow are the ones an untuned run makes (same losses, same weights after a critic-only
+    step and after a critic + generator step)."""
+    from percivaltts_amd import optimizertts_wgan
+    res = []
+    for mode in (False, 'tune'):
+        cfg, voc, mod, crit, a, gw, cw, X, Y, al = build('default')
+        cfg.train_wgan_hipgraph = mode
+        cfg.train_wgan_hipgraph_maxframes = 0            # no 'auto' shortcut for this small batch: the timing runs decide
+        opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype='WLSWGAN', critic=crit)
+        opt.prepare()
+        opt.generator_updates = 26
+        Xd, Yd, ald = f32(X), f32(Y), f32(al)
+        if mode == 'tune':
+            state = lambda: [t.detach().clone() for o in (opt.critic_opti, opt.gen_opti) for t in (o.flat.flat, o.m, o.v, o.step_count)] + \
+                            [b.detach().clone() for net in (opt.critic_net, opt._model.kerasmodel) for b in net.buffers()] + [torch.cuda.get_rng_state()]
+            before = state()
+            for kind in ('critic', 'generator'):
+                assert opt._use_graph(Xd, kind, Yd) in (True, False)
+            assert set(k[0] for k in opt._graph_tuning) == {'critic', 'generator'}
+            for x, y in zip(before, state()):
+                assert torch.equal(x, y), 'the tuning runs left a trace in the training state'
+        out = []
+        for b in (1, 5):                                  # batchid 1: critic only; 5: critic + generator (critic_runs = 5)
+            lc, lg = opt.device_step(b, Xd, Yd, ald)
+            out.append((float(lc.item()), None if lg is None else float(lg.item())))
+        opt.wait_updates(); torch.cuda.synchronize()
+        assert out[0][1] is None and out[1][1] is not None
+        res.append((out, opt.critic_opti.flat.flat.detach().cpu().clone(), opt.gen_opti.flat.flat.detach().cpu().clone()))
+    np.testing.assert_allclose([v for o in res[0][0] for v in o if v is not None], [v for o in res[1][0] for v in o if v is not None], rtol=2e-5, atol=1e-6)
+    close(res[1][1], res[0][1], 1e-4, 1e-6, "critic weights, 'tune' vs eager", kinks=True)
+    close(res[1][2], res[0][2], 1e-4, 1e-6, "generator weights, 'tune' vs eager", kinks=True)
+
+
 def test_parallel_streams_match_single_stream():
     """cfg.train_wgan_parallel_streams runs the three critic evaluations on three HIP streams: same loss and gradients."""
     from percivaltts_amd import optimizertts_wgan

@@ -1049,3 +1049,51 @@ def test_persistent_lstm_forward_equals_the_per_step_launches(ops, monkeypatch):
         torch.cuda.synchronize()
         assert torch.equal(h_pers, h_steps), float((h_pers - h_steps).abs().max())
         close(h_pers, O.blstm(x, W, U, b), rtol=2e-4, atol=2e-5, what='h')
+
+
+def test_lstm_recurrence_graph_replay_equals_the_plain_launches(ops):
+    """csrc/lstm.hip, lstm_graph_run (ptts_set_lstm_graph(1)): the T step launches of the forward and of the backward recurrence
+    captured once per (pointers, shape) tuple and replayed as one hipGraph launch.  Same kernels in the same order: h and every
+    gradient BIT-identical to the plain launches; a second call on the same buffers is a replay (counters), a call on other
+    buffers captures anew; ptts_lstm_graph_clear drops the cache."""
+    import ctypes
+    lib = ops._hip.lib()
+    g = gen(31)
+    B, T, In, H = 20, 24, 8, 256
+    x = torch.randn(B, T, In, generator=g, dtype=torch.float64)
+    W = torch.randn(In, 8 * H, generator=g, dtype=torch.float64) / math.sqrt(In)
+    U = torch.randn(2, H, 4 * H, generator=g, dtype=torch.float64) / math.sqrt(H)
+    b = torch.randn(8 * H, generator=g, dtype=torch.float64) * 0.2
+    dy = dev(torch.randn(B, T, 2 * H, generator=g, dtype=torch.float64))
+
+    def run():
+        xs = [dev(t).requires_grad_(True) for t in (x, W, U, b)]
+        h = ops.lstm(*xs)
+        h.backward(dy)
+        torch.cuda.synchronize()
+        return [h.detach().clone()] + [t.grad.detach().clone() for t in xs]
+
+    def stats():
+        v = [ctypes.c_ulonglong(0) for _ in range(3)]
+        lib.ptts_lstm_graph_stats(*[ctypes.byref(q) for q in v])
+        return [q.value for q in v]
+
+    lib.ptts_set_lstm_graph(0)
+    ops.deterministic(True)          # the products around the recurrence (dx, dW, dU) without order-dependent atomics
+    plain = run()
+    try:
+        lib.ptts_lstm_graph_clear()
+        lib.ptts_set_lstm_graph(1)
+        s0 = stats()
+        first = run()
+        s1 = stats()
+        again = run()           # the allocator hands the same blocks back: replays, or new captures -- identical results either way
+        s2 = stats()
+    finally:
+        lib.ptts_set_lstm_graph(0)
+        lib.ptts_lstm_graph_clear()
+        ops.deterministic(False)
+    assert s1[1] - s0[1] == 2 and s1[2] == s0[2], (s0, s1)              # forward + backward chains captured
+    assert (s2[0] - s1[0]) + (s2[1] - s1[1]) == 2, (s1, s2)
+    for name, a, c, p in zip(('h', 'dx', 'dW', 'dU', 'db'), first, again, plain):
+        assert torch.equal(a, p) and torch.equal(c, p), name
