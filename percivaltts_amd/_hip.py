@@ -175,8 +175,15 @@ def call(name, *args, **kw):
         raise HipLibraryError('{} failed (rc={}): {}'.format(name, rc, last_error()))
 
 
+def stream_id():
+    """Raw handle (an integer) of the current HIP stream of the current device.  torch.cuda.current_stream() builds a Stream object
+    through several layers of Python (7 us a call, 150 calls per training step: a millisecond of a host-bound step); the raw getter
+    is the same lookup without them."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
 def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(stream_id())
 
 
 def ptr(t):

@@ -331,9 +331,18 @@ class LSTM(Layer):
     def out_shape(self, in_shapes):
         return (self.units * self.ndir,)
 
-    def compute(self, vals, training, memo):
-        return ops.lstm(vals[0] if not isinstance(vals[0], LazyConcat) else vals[0].tensor(),
-                        self.kernel, self.recurrent_kernel, self.bias)
+    def _input(self, vals):
+        return to_tensor(vals[0] if not isinstance(vals[0], LazyConcat) else vals[0].tensor()).contiguous()
+
+    def precompute(self, vals, training, memo):
+        """The forward launches now, the autograd node later (`compute(..., pre=...)`): Model._run creates the node of a side-stream
+        recurrence last, so that its backward chain -- the critical path of the generator step -- is the first thing the backward
+        pass enqueues."""
+        with torch.no_grad():
+            return ops.lstm_launch(self._input(vals).detach(), self.kernel.detach(), self.recurrent_kernel.detach(), self.bias.detach())
+
+    def compute(self, vals, training, memo, pre=None):
+        return ops.lstm(self._input(vals), self.kernel, self.recurrent_kernel, self.bias, pre=pre)
 
 
 class GRU(Layer):
@@ -538,6 +547,8 @@ class Model(nn.Module):
         on_side = set()
         if '__side__' in values:
             on_side, pending, side, cur = values.pop('__side__')
+        pre = values.pop('__pre__', {})       # node id -> launched-ahead results of a side-stream layer (Layer.precompute)
+        late = bool(getattr(self, 'side_backward_first', False))
         held = set()
         order = self.order
         if use_side and os.environ.get('PTTS_SIDE_DEFER', '0') != '0':
@@ -566,6 +577,13 @@ class Model(nn.Module):
                 if side is None:
                     side = self._variant_streams(2)[0]
                     cur = torch.cuda.current_stream()
+                if id(n) in pre:
+                    # launched in the earlier call; this one only creates the autograd node (no kernel reads the parents now)
+                    with torch.cuda.stream(side):
+                        values[id(n)] = n.layer.compute(vals, training, memo, pre=pre.pop(id(n)))
+                    on_side.add(id(n))
+                    pending = True
+                    continue
                 if not any(id(p) in on_side for p in n.parents):
                     # inputs come from the main stream: if they all existed before this call, wait only for the point
                     # where the call started, not for the main-stream work enqueued since
@@ -573,6 +591,14 @@ class Model(nn.Module):
                         side.wait_event(start_ev)
                     else:
                         side.wait_stream(cur)
+                if late and hold and torch.is_grad_enabled() and hasattr(n.layer, 'precompute'):
+                    # a later call finishes the graph (`hold`): launch now, create the node then -- after everything the caller
+                    # evaluates in between (the critic), i.e. with the highest priority of the backward pass
+                    with torch.cuda.stream(side):
+                        pre[id(n)] = n.layer.precompute(vals, training, memo)
+                    held.add(id(n))
+                    pending = True
+                    continue
                 with torch.cuda.stream(side):
                     values[id(n)] = n.layer.compute(vals, training, memo)
                 on_side.add(id(n))
@@ -590,6 +616,7 @@ class Model(nn.Module):
             values[id(n)] = n.layer.compute(vals, training, memo)
         if held:
             values['__side__'] = (on_side, pending, side, cur)      # the join happens in the call that finishes the graph
+            values['__pre__'] = pre
         elif pending:
             cur.wait_stream(side)
         return values

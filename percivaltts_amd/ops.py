@@ -260,7 +260,7 @@ _ws_cache = {}
 
 def _workspace(nbytes, device):
     """One growing scratch buffer per device and stream (kernels on one stream are ordered)."""
-    key = (device.index, torch.cuda.current_stream().cuda_stream, torch.cuda.is_current_stream_capturing())
+    key = (device.index, _hip.stream_id(), torch.cuda.is_current_stream_capturing())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -289,7 +289,7 @@ class _C2M(object):
     def table(cls, w, transposed, planes=3):
         flat = getattr(w, '_ptts_flat', None)
         epoch = None if flat is None else flat.epoch
-        sid = torch.cuda.current_stream().cuda_stream
+        sid = _hip.stream_id()
         key = (id(w), sid, planes)         # one copy per stream: the build is ordered with its consumers by the stream itself
         ent = cls.tables.get(key)
         if ent is None or ent[0] is not w or ent[1] != w._version or ent[2] != epoch or flat is None:
@@ -488,7 +488,7 @@ class _DenseSplit(object):
         flat = getattr(owner, '_ptts_flat', None)
         if flat is None:
             return None
-        key = (id(owner), Bm.data_ptr(), K, N, ldb, transB, torch.cuda.current_stream().cuda_stream)
+        key = (id(owner), Bm.data_ptr(), K, N, ldb, transB, _hip.stream_id())
         ent = cls.planes.get(key)
         if ent is None or ent[0] is not owner or ent[1] != owner._version or ent[2] != flat.epoch:
             reuse = ent is not None and ent[0] is owner
@@ -720,7 +720,7 @@ class _C2C(object):
     def table(cls, ws, bs):
         flat = getattr(ws[0], '_ptts_flat', None)
         epoch = None if flat is None else flat.epoch
-        sid = torch.cuda.current_stream().cuda_stream
+        sid = _hip.stream_id()
         key = (tuple(id(w) for w in ws), sid)
         vers = tuple(w._version for w in ws) + tuple(-1 if b is None else b._version for b in bs)
         ent = cls.tables.get(key)
@@ -1070,7 +1070,7 @@ class _C1Split(object):
     def frames(cls, a, pl, pr):
         B, T, Cin = a.shape
         Cp = (Cin + 31) // 32 * 32
-        key = (a._version, tuple(a.shape), pl, pr, torch.cuda.current_stream().cuda_stream)
+        key = (a._version, tuple(a.shape), pl, pr, _hip.stream_id())
         if cls.x_src is a and cls.x_key == key:
             return cls.x_planes, Cp
         planes = torch.empty((3, Cp // 32, B, T + pl + pr, 32), dtype=torch.bfloat16, device=a.device)
@@ -1086,7 +1086,7 @@ class _C1Split(object):
         flat = getattr(w, '_ptts_flat', None)
         epoch = None if flat is None else flat.epoch
         ent = cls.w_planes.get(id(w))
-        sid = torch.cuda.current_stream().cuda_stream
+        sid = _hip.stream_id()
         if ent is not None and ent[0] is w and ent[1] == w._version and ent[2] == epoch and ent[4] == sid and flat is not None:
             return ent[3]
         planes = ent[3] if ent is not None and ent[0] is w and ent[4] == sid else torch.empty((3, Cp // 32, N, KW, 32), dtype=torch.bfloat16, device=w.device)
@@ -1125,7 +1125,7 @@ class _C1Split(object):
         weight gradients of generator and critic read the same context input."""
         Tp = T + KW - 1
         Pp = cls.plane_len(B, T, KW)
-        key = None if src is None else (src._version, tuple(src.shape), KW, torch.cuda.current_stream().cuda_stream)
+        key = None if src is None else (src._version, tuple(src.shape), KW, _hip.stream_id())
         if src is not None and cls.xt_src is src and cls.xt_key == key:
             return cls.xt_planes
         if padded:
@@ -1159,7 +1159,7 @@ class _C1WgradT(object):
         B, Tp, C = ap.shape
         Pp = _C1Split.plane_len(B, Tp - (KW - 1), KW)
         Crows = (C + 63) // 64 * 64
-        key = None if src is None else (src._version, tuple(src.shape), KW, torch.cuda.current_stream().cuda_stream)
+        key = None if src is None else (src._version, tuple(src.shape), KW, _hip.stream_id())
         if src is not None and cls.src is src and cls.key == key:
             return cls.planes
         xt = torch.empty((Crows, Pp), dtype=torch.float32, device=ap.device)
@@ -1280,7 +1280,7 @@ def conv1d(v, w, b=None):
     flat = getattr(w, '_ptts_flat', None) if c.enabled else None
     if flat is not None:
         key = (a.data_ptr(), a._version, tuple(a.shape), w.data_ptr(), w._version, flat.epoch,
-               None if b is None else (b.data_ptr(), b._version), torch.cuda.current_stream().cuda_stream)
+               None if b is None else (b.data_ptr(), b._version), _hip.stream_id())
         if not torch.is_grad_enabled():
             c.capture = True
             try:
@@ -1455,24 +1455,32 @@ def _lstm_mark(tag):
         lstm_trace.append((tag, ev))
 
 
+def lstm_launch(x, W, U, b, reverse=False):
+    """The forward launches of LSTMFn (input projection + the T-step recurrence) with no autograd node: (h, c, gates)."""
+    f32c(x, 'lstm.x'); f32c(W); f32c(U); f32c(b)
+    B, T, In = x.shape
+    ndir, H, G4 = U.shape
+    assert G4 == 4 * H and W.shape == (In, ndir * G4)
+    dev = x.device
+    xproj = torch.empty((B, T, ndir * G4), dtype=torch.float32, device=dev)
+    gemm_raw(x, W, xproj, B * T, ndir * G4, In, bias=b)
+    h = torch.empty((B, T, ndir * H), dtype=torch.float32, device=dev)
+    c = torch.empty((B, T, ndir * H), dtype=torch.float32, device=dev)
+    gates = torch.empty((B, T, ndir * G4), dtype=torch.float32, device=dev)
+    wsf = _workspace(_hip.lib().ptts_lstm_fwd_workspace_bytes(B, T, H, ndir), dev)
+    _lstm_mark('fwd0')
+    call('ptts_lstm_fwd', ptr(xproj), ptr(U), ptr(h), ptr(gates), ptr(c), ptr(wsf), wsf.numel(), B, T, H, ndir, int(reverse), stream())
+    _lstm_mark('fwd1')
+    return h, c, gates
+
+
 class LSTMFn(torch.autograd.Function):
     """x [B,T,In]; W [In, ndir*4H]; U [ndir,H,4H]; b [ndir*4H] -> h [B,T,ndir*H] (Keras gate order i,f,c,o)."""
     @staticmethod
-    def forward(ctx, x, W, U, b, reverse):
-        f32c(x, 'lstm.x'); f32c(W); f32c(U); f32c(b)
-        B, T, In = x.shape
-        ndir, H, G4 = U.shape
-        assert G4 == 4 * H and W.shape == (In, ndir * G4)
-        dev = x.device
-        xproj = torch.empty((B, T, ndir * G4), dtype=torch.float32, device=dev)
-        gemm_raw(x, W, xproj, B * T, ndir * G4, In, bias=b)
-        h = torch.empty((B, T, ndir * H), dtype=torch.float32, device=dev)
-        c = torch.empty((B, T, ndir * H), dtype=torch.float32, device=dev)
-        gates = torch.empty((B, T, ndir * G4), dtype=torch.float32, device=dev)
-        wsf = _workspace(_hip.lib().ptts_lstm_fwd_workspace_bytes(B, T, H, ndir), dev)
-        _lstm_mark('fwd0')
-        call('ptts_lstm_fwd', ptr(xproj), ptr(U), ptr(h), ptr(gates), ptr(c), ptr(wsf), wsf.numel(), B, T, H, ndir, int(reverse), stream())
-        _lstm_mark('fwd1')
+    def forward(ctx, x, W, U, b, reverse, pre=None):
+        # `pre`: (h, c, gates) of lstm_launch() on the same operands -- the launches went out earlier, this call only ties the result
+        # into the autograd tape (layers.Model._run: a node created late has its backward chain enqueued early)
+        h, c, gates = lstm_launch(x, W, U, b, reverse) if pre is None else pre
         ctx.save_for_backward(x, W, U, h, c, gates)
         ctx.reverse = int(reverse)
         return h
@@ -1517,11 +1525,11 @@ class LSTMFn(torch.autograd.Function):
             for d in range(ndir):
                 gemm_raw(hprev.view(M, ndir * H)[:, d * H:], dgates.view(M, ndir * G4)[:, d * G4:], dU[d],
                          H, G4, M, transA=1, lda=ndir * H, rows_per_seg=M, ldb=ndir * G4)
-        return dx, dW, dU, db, None
+        return dx, dW, dU, db, None, None
 
 
-def lstm(v, W, U, b, reverse=False):
-    return LSTMFn.apply(as_tensor(v).contiguous(), W, U, b, reverse)
+def lstm(v, W, U, b, reverse=False, pre=None):
+    return LSTMFn.apply(as_tensor(v).contiguous(), W, U, b, reverse, pre)
 
 
 # ----------------------------------------------------------------------------------------------

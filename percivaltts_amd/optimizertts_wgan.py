@@ -133,6 +133,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         cfg.train_wgan_hipgraph = False              # True: every step replayed as a hipGraph; 'auto': only for batches of at most train_wgan_hipgraph_maxframes frames (launch-bound steps such as the reference's B = 10, run.py:125-126)
         cfg.train_wgan_hipgraph_maxframes = 8192
         cfg.train_wgan_parallel_streams = False      # the critic evaluations on separate HIP streams
+        cfg.train_wgan_side_backward_first = False   # generator step: the BLSTM's autograd node created last (its launches go out first), so that its backward chain is enqueued first.  Measured: the chain then ends 1 ms earlier, the step does not (the main stream's backward becomes the tail): off
         cfg.train_wgan_stack_real_fake = True        # critic(real) and critic(fake) as one stacked 2B pass (exact: no BatchNorm)
         cfg.train_wgan_reuse_ctx_conv = True         # generator step reuses the critic step's G-context-Conv1D product (same batch)
         cfg.train_wgan_early_critic = True           # generator step: critic starts on the spectral branch, BLSTM joins for the LS term
@@ -215,6 +216,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
 
         # these two names are what the reference exposes after prepare()
         generator.parallel_branches = bool(cfg.train_wgan_parallel_streams)
+        generator.side_backward_first = bool(getattr(cfg, 'train_wgan_side_backward_first', False))
         self.critic_model = self.critic_net
         self.generator_model = generator
         self._graphs = {}
@@ -279,9 +281,9 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             # The critic reads the spectral columns only (the condition under which the critic step prunes the other
             # branches).  It is therefore fed the spectral branch as soon as that exists, while the latency-bound f0
             # branch (BLSTM, side stream) still runs; the final concatenation -- the join with the side stream -- is
-            # needed by the least-squares term alone and comes last.  Same values.  (Also tried: creating the BLSTM's
-            # autograd node last so that its backward chain is enqueued first -- slower, the host then spends 1 ms on
-            # the chain's 400 launches before the wide kernels of the backward pass are queued.)
+            # needed by the least-squares term alone and comes last.  Same values.  (cfg.train_wgan_side_backward_first creates
+            # the BLSTM's autograd node last -- launches first, layers.Model._run -- so that its backward chain is enqueued
+            # first: the chain then ends 1 ms earlier but the step does not, tools/gen_timeline.py events; off.)
             feed = {id(m.inputs[0]): X}
             out_node = m.outputs[0]
             values = m._run(feed, training, None, hold={id(out_node)})

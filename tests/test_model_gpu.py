@@ -346,6 +346,28 @@ def test_hipgraph_tune_restores_training_state_and_trains_like_eager():
     close(res[1][2], res[0][2], 1e-4, 1e-6, "generator weights, 'tune' vs eager", kinks=True)
 
 
+def test_side_backward_first_generator_step_matches_the_default_order():
+    """cfg.train_wgan_side_backward_first: the BLSTM's forward launches go out when its inputs exist, its autograd node is created
+    only when the held join is evaluated (layers.Model._run, LSTM.precompute / compute(pre=...)), so the backward pass enqueues its
+    chain first.  Same kernels on the same operands: loss, generator gradient and updated weights as with the default order."""
+    from percivaltts_amd import optimizertts_wgan
+    res = []
+    for first in (False, True):
+        cfg, voc, mod, crit, a, gw, cw, X, Y, al = build('default')
+        cfg.train_wgan_parallel_streams = True
+        cfg.train_wgan_side_backward_first = first
+        opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype='WLSWGAN', critic=crit)
+        opt.prepare()
+        assert opt._model.kerasmodel.side_backward_first == first
+        Xd, Yd = f32(X), f32(Y)
+        lg = [float(opt.generator_step(Xd, Yd).item()) for _ in range(2)]
+        opt.wait_updates(); torch.cuda.synchronize()
+        res.append((lg, opt.gen_opti.flat.grad.detach().cpu().clone(), opt.gen_opti.flat.flat.detach().cpu().clone()))
+    np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-5, atol=1e-6)
+    close(res[1][1], res[0][1], 1e-4, 1e-6, 'generator gradient, BLSTM node created last vs first', kinks=True)
+    close(res[1][2], res[0][2], 1e-4, 1e-6, 'generator weights after 2 steps', kinks=True)
+
+
 def test_parallel_streams_match_single_stream():
     """cfg.train_wgan_parallel_streams runs the three critic evaluations on three HIP streams: same loss and gradients."""
     from percivaltts_amd import optimizertts_wgan
