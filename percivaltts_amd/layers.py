@@ -338,11 +338,19 @@ class LSTM(Layer):
         """The forward launches now, the autograd node later (`compute(..., pre=...)`): Model._run creates the node of a side-stream
         recurrence last, so that its backward chain -- the critical path of the generator step -- is the first thing the backward
         pass enqueues."""
+        x = self._input(vals)
         with torch.no_grad():
-            return ops.lstm_launch(self._input(vals).detach(), self.kernel.detach(), self.recurrent_kernel.detach(), self.bias.detach())
+            res = ops.lstm_launch(x.detach(), self.kernel.detach(), self.recurrent_kernel.detach(), self.bias.detach())
+        # the input passes through an identity node created NOW, on this (side) stream: the late node's dx lands in that node's input
+        # buffer -- a side-stream consumer -- and reaches the producer of x when the engine gets to this early, low-priority node.
+        # Delivered directly, the engine would make the main stream wait for the whole backward chain at the moment the chain's node
+        # finishes on the host, i.e. before the critic's backward is even enqueued.
+        return {'x': ops.grad_gate(x) if x.requires_grad else x, 'res': res}
 
     def compute(self, vals, training, memo, pre=None):
-        return ops.lstm(self._input(vals), self.kernel, self.recurrent_kernel, self.bias, pre=pre)
+        if pre is not None:
+            return ops.lstm(pre['x'], self.kernel, self.recurrent_kernel, self.bias, pre=pre['res'])
+        return ops.lstm(self._input(vals), self.kernel, self.recurrent_kernel, self.bias)
 
 
 class GRU(Layer):

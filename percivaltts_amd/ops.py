@@ -1455,6 +1455,22 @@ def _lstm_mark(tag):
         lstm_trace.append((tag, ev))
 
 
+class _GradGateFn(torch.autograd.Function):
+    """Identity whose only purpose is its place in the autograd tape (creation order = priority of the backward pass, stream of
+    creation = stream its input buffer accumulates on)."""
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def grad_gate(x):
+    return _GradGateFn.apply(x)
+
+
 def lstm_launch(x, W, U, b, reverse=False):
     """The forward launches of LSTMFn (input projection + the T-step recurrence) with no autograd node: (h, c, gates)."""
     f32c(x, 'lstm.x'); f32c(W); f32c(U); f32c(b)
@@ -1483,6 +1499,11 @@ class LSTMFn(torch.autograd.Function):
         h, c, gates = lstm_launch(x, W, U, b, reverse) if pre is None else pre
         ctx.save_for_backward(x, W, U, h, c, gates)
         ctx.reverse = int(reverse)
+        # inside deferred_weight_grads(): the weight gradients are added straight into the flat gradient buffer on the stream of the
+        # backward chain.  Handed to autograd instead, their AccumulateGrad nodes (made on the main stream) make the MAIN stream wait
+        # for this side stream at the moment the engine reaches them -- with the chain enqueued first (Model.side_backward_first) that
+        # is before the critic's backward pass, which then runs after the recurrence instead of under it.
+        ctx.gt = (grad_target(W), grad_target(U), grad_target(b)) if _Deferred.active else None
         return h
 
     @staticmethod
@@ -1525,6 +1546,16 @@ class LSTMFn(torch.autograd.Function):
             for d in range(ndir):
                 gemm_raw(hprev.view(M, ndir * H)[:, d * H:], dgates.view(M, ndir * G4)[:, d * G4:], dU[d],
                          H, G4, M, transA=1, lda=ndir * H, rows_per_seg=M, ldb=ndir * G4)
+        gt = ctx.gt
+        if gt is not None and _Deferred.active and not _Flags.deterministic and \
+                all(t is not None or g is None for t, g in zip(gt, (dW, dU, db))):
+            for t, g in zip(gt, (dW, dU, db)):
+                if g is not None:
+                    t.add_(g.view(t.shape))
+            cur = torch.cuda.current_stream()
+            if all(cur.cuda_stream != q.cuda_stream for q in _Deferred.streams):
+                _Deferred.streams.append(cur)             # flush_weight_grads() joins this stream before the optimiser reads the buffer
+            dW = dU = db = None
         return dx, dW, dU, db, None, None
 
 

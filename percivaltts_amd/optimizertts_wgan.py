@@ -287,15 +287,20 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             feed = {id(m.inputs[0]): X}
             out_node = m.outputs[0]
             values = m._run(feed, training, None, hold={id(out_node)})
+            ops._lstm_mark('G_spec_fwd_end')
             spec = kl.to_tensor(values[id(node_spec)])
+            if ops.lstm_trace is not None and spec.requires_grad:
+                spec.register_hook(lambda g: ops._lstm_mark('critic_bwd_end'))
             voc = self._model.vocoder
             feat = torch.zeros(X.shape[0], X.shape[1], voc.featuressize(), dtype=torch.float32, device=X.device)
             feat[:, :, 1:1 + voc.specsize()] = spec
             self._wait_update('critic')          # the critic's update of this batch may still be in flight: G's forward above did not need it
             valid = self.critic_net(feat, X, training=training)
             l_w = wasserstein_loss(-1.0, valid)
+            ops._lstm_mark('critic_fwd_end')
             values = m._run(feed, training, None, values=values)
             pred = kl.to_tensor(values[id(out_node)])
+            ops._lstm_mark('join')
         else:
             pred = m(X, training=training)
             self._wait_update('critic')
@@ -368,7 +373,10 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         try:
             with ops.deferred_weight_grads():
                 total, _ = self.generator_loss(X, Y, training=True)
+                ops._lstm_mark('loss')
                 total.backward()
+                ops._lstm_mark('bwd_enqueued')
+            ops._lstm_mark('wgrads_flushed')
         finally:
             for p in cps: p.requires_grad_(True)
         return total.detach()
