@@ -352,9 +352,13 @@ def main():
 
     short = max(6, min(args.steps, 60))      # the side loops: a bounded number of steps each
     # the same loop with the context Conv1D on the fp32 MFMA pipe (the variant kept selectable: --fp32-mfma)
+    # (the variants change what a step launches: they run eagerly -- a captured graph would replay the headline's kernels)
+    graph_mode = opt.cfg.train_wgan_hipgraph
     if not args.fp32_mfma and not args.no_variants:
         opt.cfg.train_wgan_split_bf16 = False
+        opt.cfg.train_wgan_hipgraph = False
         dtv, _ = timed_loop(opt, batches, short, 6, dev)
+        opt.cfg.train_wgan_hipgraph = graph_mode
         opt.cfg.train_wgan_split_bf16 = True
         ops.conv1d_split(True)
         ops.dense_split(True)
@@ -366,7 +370,9 @@ def main():
         saved = (opt._gen_spec, opt.cfg.train_wgan_stack_real_fake, opt.cfg.train_wgan_reuse_ctx_conv, opt.cfg.train_wgan_early_critic)
         opt._gen_spec = None
         opt.cfg.train_wgan_stack_real_fake = opt.cfg.train_wgan_reuse_ctx_conv = opt.cfg.train_wgan_early_critic = False
+        opt.cfg.train_wgan_hipgraph = False
         dtu, _ = timed_loop(opt, batches, short, 6, dev)
+        opt.cfg.train_wgan_hipgraph = graph_mode
         opt._gen_spec, opt.cfg.train_wgan_stack_real_fake, opt.cfg.train_wgan_reuse_ctx_conv, opt.cfg.train_wgan_early_critic = saved
         extra['all_exact_work_reductions_off'] = {
             'what': "--no-prune --no-stack --no-ctx-reuse --no-early-critic: G's f0/noise branches run in the critic step, critic(real) and "

@@ -46,9 +46,17 @@ if bf:
         open(outdir + '/%s_bench_bf16_under_rocprof.json' % tag, 'w').write(open(src + '/bench_bf16.json').read().strip() + '\n')
 if os.path.exists(src + '/chain_summary.json'):
     cs = json.load(open(src + '/chain_summary.json'))
-    for k, d in cs.items():       # gfx950: FETCH_SIZE counts half the bytes of a wide coalesced read; counters are in KiB
+    for k, d in cs.items():
+        # counters are in KiB.  No x2 on FETCH_SIZE here: the forward kernel pins it -- its only reads are the fp32 spectrum (13.3 MB at
+        # B = 128: 12 918 KiB counted) and its writes the 8 maps (215.8 MB: 210 800 KiB counted); the maps of the other kernels arrive by
+        # global_load_lds_dwordx4, 16 bytes per lane like the dwordx4 loads the guide's correction is about, and are counted in full too
         if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
-            d['hbm_bytes_per_launch'] = (2 * d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024
+            d['hbm_bytes_per_launch'] = (d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024
+            d['hbm_read_bytes'], d['hbm_write_bytes'] = d['FETCH_SIZE'] * 1024, d['WRITE_SIZE'] * 1024
+    cs['_note'] = ('tools/chain_probe.py at [B,400,65], L = 8, averaged over its launches (B = 64 / 128 / 192, mean 128).  Algorithmic bytes at B = 128: '
+                   'forward 13.3 MB read + 215.8 MB written; backward-data 242.4 MB read + 13.3 MB (g0) + 216.2 MB (gamma maps) written; '
+                   'backward 242.4 MB read, partial rows written (its 88 MB of writes are the scratch slots of the dynamically indexed half of the dW accumulators); '
+                   'second order 13.3 + 2 x 215.8 MB read + 26.6 MB written.')
     json.dump(cs, open(outdir + '/%s_conv2d_chain_counters.json' % tag, 'w'), indent=1, sort_keys=True)
 
 
