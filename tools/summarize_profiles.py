@@ -53,6 +53,7 @@ if os.path.exists(src + '/chain_summary.json'):
         if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
             d['hbm_bytes_per_launch'] = (d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024
             d['hbm_read_bytes'], d['hbm_write_bytes'] = d['FETCH_SIZE'] * 1024, d['WRITE_SIZE'] * 1024
+            d['hbm_bytes_per_launch_with_guide_x2_on_fetch'] = (2 * d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024
     cs['_note'] = ('tools/chain_probe.py at [B,400,65], L = 8, averaged over its launches (B = 64 / 128 / 192, mean 128).  Algorithmic bytes at B = 128: '
                    'forward 13.3 MB read + 215.8 MB written; backward-data 242.4 MB read + 13.3 MB (g0) + 216.2 MB (gamma maps) written; '
                    'backward 242.4 MB read, partial rows written (its 88 MB of writes are the scratch slots of the dynamically indexed half of the dW accumulators); '
