@@ -135,6 +135,9 @@ int ptts_conv2d_mfma_supported(int F, int Cin, int Cout, int KT, int KF, int dil
 size_t ptts_conv2d_mfma_table_bytes(int KT);
 int ptts_conv2d_mfma_tables(const float* w, void* table_fwd, void* table_bwd, int KT, int KF, int Cin, int Cout,
                             int planes /*3: fp32 split, 1: bf16 copy of the kernel*/, void* stream);
+/* The same for n kernels (5x5, 4 -> 4) in one launch: w[i] -> table_fwd[i], table_bwd[i] (host arrays of device pointers). */
+int ptts_conv2d_mfma_tables_grouped(const float* const* w, void* const* table_fwd, void* const* table_bwd, int n, int planes,
+                                    void* stream);
 /* planes = 3: fp32 arithmetic (six products), every tensor fp32.  planes = 1: bf16 arithmetic (BASELINE configs[2]; time
  * dilation 1): ONE product per position with the bf16 copy of the kernel, fp32 accumulation; x and mask_src are bf16 in
  * HBM when in_bf16 (else fp32, rounded to bf16 on load), y and out_mask are bf16 when out_bf16 (else fp32). */
@@ -238,6 +241,14 @@ int ptts_gemm_wgrad_grouped(const ptts_wgrad_desc* descs, int n, void* stream);
  * mask_src laid out like A.  N, K, lda, ldc multiples of 4, operands 16-byte aligned (ptts_dense_bf16x6_supported). */
 size_t ptts_dense_planes_bytes(int N, int K);
 int ptts_split3_dense_weight(const float* w, long long ldw, int K, int N, int transposed, void* planes, void* stream);
+/* The same for n weights in ONE launch: after an optimiser update every Dense kernel of a network needs its planes again (forward and
+ * transposed), 18 launches of 4 us per critic step otherwise. */
+typedef struct ptts_dense_split_desc {
+    const float* w; void* planes;
+    long long ldw;
+    int K, N, transposed, reserved;
+} ptts_dense_split_desc;
+int ptts_split3_dense_weight_grouped(const ptts_dense_split_desc* descs, int n, void* stream);
 int ptts_dense_bf16x6_supported(int M, int N, int K, long long lda, long long ldc);
 /* One weight-gradient product of ptts_gemm_wgrad_grouped (TF's MatMul gradient w.r.t. the kernel of a kl.Dense / LSTM
  * projection, plus the bias gradient) as a bf16x6 split product, in two stages without atomics between workgroups:
@@ -322,6 +333,16 @@ int ptts_bn_finalize(const double* sums, long long count, const float* gamma, co
                      float* moving_mean, float* moving_var, float eps, float momentum,
                      int training, int update_moving, int unbiased_moving, int C,
                      float* scale, float* shift, float* mean /*[C] out*/, float* rstd /*[C] out*/, void* stream);
+
+/* Training-mode statistics AND the affine of a few-channel map (C = 4, 8, 16: the conv stacks' BatchNormalization, networktts.py:124)
+ * in one launch: ptts_colstats + ptts_bn_finalize(training = 1) fused (the workgroup that finishes last adds the partial rows in a
+ * fixed order: bit-reproducible).  workspace: ptts_colstats_workspace_bytes(rows, C); counter: one int, zero before the first call,
+ * left zero by every call, not shared between streams. */
+int ptts_bn_batch_stats_supported(long long rows, int C);
+int ptts_bn_batch_stats(const float* x, long long rows, int C, const float* gamma, const float* beta,
+                        float* moving_mean, float* moving_var, float eps, float momentum, int update_moving, int unbiased_moving,
+                        float* scale, float* shift, float* mean /*[C] out*/, float* rstd /*[C] out*/,
+                        void* workspace, size_t workspace_bytes, int* counter, void* stream);
 
 /* BatchNorm backward through the batch statistics.  Given dscale/dshift (gradients w.r.t. the affine that
  * ptts_bn_finalize produced in training mode):  dgamma = (dscale - dshift*mean)*rstd ;  dbeta = dshift ;

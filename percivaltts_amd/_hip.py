@@ -29,6 +29,11 @@ class DenseWgradReduceDesc(ctypes.Structure):
     _fields_ = [('partials', c_p), ('split', c_i), ('Kin', c_i), ('N', c_i), ('ldc', c_ll), ('C', c_p), ('colsum_b', c_p)]
 
 
+class DenseSplitDesc(ctypes.Structure):
+    """struct ptts_dense_split_desc of include/percival_hip.h (one weight of a grouped plane split)."""
+    _fields_ = [('w', c_p), ('planes', c_p), ('ldw', c_ll), ('K', c_i), ('N', c_i), ('transposed', c_i), ('reserved', c_i)]
+
+
 class Conv2dReduceDesc(ctypes.Structure):
     """struct ptts_conv2d_reduce_desc of include/percival_hip.h (one queued conv2d backward pass)."""
     _fields_ = [('partials', c_p), ('nblocks', c_i), ('npart', c_i), ('nw', c_i), ('cout', c_i), ('dw', c_p), ('dbias', c_p)]
@@ -60,6 +65,7 @@ SIGNATURES = {
     'ptts_conv2d_mfma_debug': (c_i, [c_i, c_p]),
     'ptts_conv2d_mfma_table_bytes': (c_sz, [c_i]),
     'ptts_conv2d_mfma_tables': (c_i, [c_p, c_p, c_p] + [c_i] * 5 + [c_p]),
+    'ptts_conv2d_mfma_tables_grouped': (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),
     'ptts_conv2d_mfma_supported': (c_i, [c_i] * 6),
     'ptts_conv2d_mfma_fwd': (c_i, [c_p] * 8 + [c_i] * 7 + [c_f] + [c_i] * 3 + [c_p]),
     'ptts_conv2d_mfma_wgrad_workspace_bytes': (c_sz, [c_i, c_i]),
@@ -76,6 +82,7 @@ SIGNATURES = {
     'ptts_conv2d_chain_second': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_sz, c_p, c_p] + [c_i] * 5 + [c_f, c_p]),
     'ptts_dense_planes_bytes': (c_sz, [c_i, c_i]),
     'ptts_split3_dense_weight': (c_i, [c_p, c_ll, c_i, c_i, c_i, c_p, c_p]),
+    'ptts_split3_dense_weight_grouped': (c_i, [c_p, c_i, c_p]),
     'ptts_dense_bf16x6_supported': (c_i, [c_i, c_i, c_i, c_ll, c_ll]),
     'ptts_dense_bf16x6': (c_i, [c_p] * 4 + [c_i] * 3 + [c_ll, c_ll, c_i, c_p, c_p, c_p, c_f, c_i, c_p, c_p]),
     'ptts_dense_wgrad_bf16x6_supported': (c_i, [c_i, c_i, c_i, c_ll, c_ll]),
@@ -86,6 +93,8 @@ SIGNATURES = {
     'ptts_colstats_workspace_bytes': (c_sz, [c_ll, c_i]),
     'ptts_colstats': (c_i, [c_p, c_ll, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_sz, c_p]),
     'ptts_bn_finalize': (c_i, [c_p, c_ll, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    'ptts_bn_batch_stats_supported': (c_i, [c_ll, c_i]),
+    'ptts_bn_batch_stats': (c_i, [c_p, c_ll, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_sz, c_p, c_p]),
     'ptts_bn_bwd_coefs': (c_i, [c_p] * 5 + [c_ll, c_i] + [c_p] * 4 + [c_p]),
     'ptts_affine_act': (c_i, [c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_f, c_p]),
     'ptts_affine_act_bwd': (c_i, [c_p] * 7 + [c_p, c_sz, c_ll, c_i, c_i, c_f, c_p]),

@@ -731,6 +731,53 @@ extern "C" int ptts_conv2d_mfma_tables(const float* w, void* table_fwd, void* ta
     return check_launch("conv2d_mfma_tables");
 }
 
+// the tables of up to TAB_GROUP kernels in one launch (blockIdx.y = kernel): a stack's 7 layers need theirs after every update
+constexpr int TAB_GROUP = 16;
+struct TabGroupArgs { const float* w[TAB_GROUP]; u16* fwd[TAB_GROUP]; u16* bwd[TAB_GROUP]; int npl; };
+__global__ void toeplitz_table_grouped_kernel(TabGroupArgs a) {
+    const int i = blockIdx.y;
+    const int transposed = blockIdx.x;
+    u16* tab = transposed ? a.bwd[i] : a.fwd[i];
+    if (!tab) return;
+    const float* __restrict__ w = a.w[i];
+    const int npl = a.npl;
+    const int idx = threadIdx.x;
+    if (idx >= KT * C * TSLOTS) return;
+    const int slot = idx % TSLOTS, oc = (idx / TSLOTS) % C, kt = idx / (TSLOTS * C);
+    const int kf = slot - 3;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (kf >= 0 && kf < KF) {
+#pragma unroll
+        for (int ic = 0; ic < C; ++ic)
+            v[ic] = transposed ? w[(((KT - 1 - kt) * KF + (KF - 1 - kf)) * C + oc) * C + ic] : w[((kt * KF + kf) * C + ic) * C + oc];
+    }
+    bf16x4 h1, h2, h3;
+    split3(v, h1, h2, h3);
+    u16* d = tab + (kt * npl * C + oc) * TROW + slot * C;
+    *reinterpret_cast<bf16x4*>(d) = h1;
+    if (npl == 3) {
+        *reinterpret_cast<bf16x4*>(d + TKP) = h2;
+        *reinterpret_cast<bf16x4*>(d + 2 * TKP) = h3;
+    }
+}
+
+extern "C" int ptts_conv2d_mfma_tables_grouped(const float* const* w, void* const* table_fwd, void* const* table_bwd, int n, int planes,
+                                               void* stream) {
+    PTTS_REQUIRE(w && table_fwd && table_bwd && n > 0, "conv2d_mfma_tables_grouped: nothing to build");
+    PTTS_REQUIRE(planes == 1 || planes == 3, "conv2d_mfma_tables_grouped: planes must be 1 (bf16) or 3 (fp32 split), got %d", planes);
+    for (int base = 0; base < n; base += TAB_GROUP) {
+        TabGroupArgs a;
+        const int m = n - base < TAB_GROUP ? n - base : TAB_GROUP;
+        for (int i = 0; i < m; ++i) {
+            PTTS_REQUIRE(w[base + i] && (table_fwd[base + i] || table_bwd[base + i]), "conv2d_mfma_tables_grouped: null pointer (kernel %d)", base + i);
+            a.w[i] = w[base + i]; a.fwd[i] = (u16*)table_fwd[base + i]; a.bwd[i] = (u16*)table_bwd[base + i];
+        }
+        a.npl = planes;
+        hipLaunchKernelGGL(toeplitz_table_grouped_kernel, dim3(2, (unsigned)m), dim3(256), 0, (hipStream_t)stream, a);
+    }
+    return check_launch("conv2d_mfma_tables_grouped");
+}
+
 namespace {
 constexpr size_t LDS_MAX = 160 * 1024;
 constexpr int NCU = 256;

@@ -87,6 +87,41 @@ __global__ __launch_bounds__(256) void split3_dense_weight_kernel(const float* _
         *reinterpret_cast<uint4*>(planes + p * ps + (size_t)idx * 8) = make_uint4(q[p][0], q[p][1], q[p][2], q[p][3]);
 }
 
+// the same for up to SPLIT_GROUP weights in one launch (blockIdx.y = weight): after an update every Dense kernel of a network needs its
+// planes rebuilt (forward and transposed: 18 launches of 4 us per critic step, each with a launch boundary of its own)
+constexpr int SPLIT_GROUP = 32;
+struct SplitGroupArgs {
+    const float* w[SPLIT_GROUP]; u16* planes[SPLIT_GROUP];
+    long long ldw[SPLIT_GROUP];
+    int K[SPLIT_GROUP], N[SPLIT_GROUP], transposed[SPLIT_GROUP], NT[SPLIT_GROUP], KS[SPLIT_GROUP];
+};
+__global__ __launch_bounds__(256) void split3_dense_weight_grouped_kernel(SplitGroupArgs a) {
+    const int i = blockIdx.y;
+    const int NT = a.NT[i], KS = a.KS[i], K = a.K[i], N = a.N[i], transposed = a.transposed[i];
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;        // (nt, ks, lane)
+    if (idx >= (long long)NT * KS * 64) return;
+    const float* __restrict__ w = a.w[i];
+    u16* __restrict__ planes = a.planes[i];
+    const long long ldw = a.ldw[i];
+    const int lane = (int)(idx & 63);
+    const long long t = idx >> 6;
+    const int ks = (int)(t % KS), nt = (int)(t / KS);
+    const int n = nt * 16 + (lane & 15), k0 = ks * 32 + (lane >> 4) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = k0 + e;
+        v[e] = (n < N && k < K) ? (transposed ? w[(long long)n * ldw + k] : w[(long long)k * ldw + n]) : 0.f;
+    }
+    unsigned q[3][4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) split3_pair(v[2 * h], v[2 * h + 1], q[0][h], q[1][h], q[2][h]);
+    const size_t ps = (size_t)NT * KS * 512;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+        *reinterpret_cast<uint4*>(planes + p * ps + (size_t)idx * 8) = make_uint4(q[p][0], q[p][1], q[p][2], q[p][3]);
+}
+
 struct DenseArgs {
     const float* A; const float* mask_src; const float* in_scale; const float* in_shift;
     const u16* planes; const float* bias; const float* out_mask; float* C;
@@ -580,6 +615,26 @@ extern "C" int ptts_split3_dense_weight(const float* w, long long ldw, int K, in
     hipLaunchKernelGGL(split3_dense_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        w, ldw, K, N, transposed, (u16*)planes, NT, KS);
     return check_launch("split3_dense_weight");
+}
+
+extern "C" int ptts_split3_dense_weight_grouped(const ptts_dense_split_desc* descs, int n, void* stream) {
+    PTTS_REQUIRE(descs && n > 0, "split3_dense_weight_grouped: nothing to split");
+    for (int base = 0; base < n; base += SPLIT_GROUP) {
+        SplitGroupArgs a;
+        const int m = n - base < SPLIT_GROUP ? n - base : SPLIT_GROUP;
+        long long most = 0;
+        for (int i = 0; i < m; ++i) {
+            const ptts_dense_split_desc& d = descs[base + i];
+            PTTS_REQUIRE(d.w && d.planes, "split3_dense_weight_grouped: null pointer (weight %d)", base + i);
+            PTTS_REQUIRE(d.K > 0 && d.N > 0 && d.ldw >= (d.transposed ? d.K : d.N), "split3_dense_weight_grouped: bad dims K=%d N=%d ldw=%lld (weight %d)", d.K, d.N, d.ldw, base + i);
+            a.w[i] = d.w; a.planes[i] = (u16*)d.planes; a.ldw[i] = d.ldw; a.K[i] = d.K; a.N[i] = d.N; a.transposed[i] = d.transposed;
+            a.NT[i] = (d.N + NBLK - 1) / NBLK * (NBLK / 16); a.KS[i] = (d.K + BK - 1) / BK;
+            const long long total = (long long)a.NT[i] * a.KS[i] * 64;
+            if (total > most) most = total;
+        }
+        hipLaunchKernelGGL(split3_dense_weight_grouped_kernel, dim3((unsigned)((most + 255) / 256), (unsigned)m), dim3(256), 0, (hipStream_t)stream, a);
+    }
+    return check_launch("split3_dense_weight_grouped");
 }
 
 // 1 when ptts_dense_bf16x6 takes the shape

@@ -336,6 +336,116 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, long long co
     }
 }
 
+// Batch statistics AND the BatchNorm affine of a few-channel map (C = 4: the conv stacks) in ONE launch: the vectorised partial-sum
+// stage of colreduce2_vec4_kernel, then the workgroup that finishes last (agent-scope counter) adds the partial rows in a fixed
+// order -- the result does not depend on which workgroup that is -- and does bn_finalize's arithmetic.  Three launches of
+// 10 + 5 + 5 us per BatchNorm layer otherwise, 8 such layers in the generator's stack.  `counter` is a zeroed int the caller keeps per
+// stream; the finishing workgroup puts it back to zero.
+__global__ __launch_bounds__(EW_THREADS) void bn_stats_fused_kernel(const float* __restrict__ x, long long rows, int C,
+                                                                   double* __restrict__ partials, int* __restrict__ counter,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   float* __restrict__ moving_mean, float* __restrict__ moving_var,
+                                                                   float eps, float momentum, int update_moving, int unbiased_moving,
+                                                                   float* __restrict__ scale, float* __restrict__ shift,
+                                                                   float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    __shared__ double sh[8][EW_THREADS];
+    __shared__ int is_last;
+    const int tid = threadIdx.x;
+    const int C4 = C / 4;
+    const int R = EW_THREADS / C4;              // rows per sweep (C4 is a power of two <= 4 here: R * C4 == EW_THREADS)
+    const int r = tid / C4, c4 = tid - r * C4;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    {
+        float fs[4] = {0, 0, 0, 0}, fq[4] = {0, 0, 0, 0};
+        int n = 0;
+        const long long step = (long long)gridDim.x * R * VU;
+        for (long long base = (long long)blockIdx.x * R * VU + r; base < rows; base += step) {
+            float4 v[VU];
+#pragma unroll
+            for (int u = 0; u < VU; ++u) {
+                const long long row = base + (long long)u * R;
+                v[u] = row < rows ? ld4(x + row * C + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < VU; ++u) {
+                fs[0] += v[u].x; fs[1] += v[u].y; fs[2] += v[u].z; fs[3] += v[u].w;
+                fq[0] += v[u].x * v[u].x; fq[1] += v[u].y * v[u].y; fq[2] += v[u].z * v[u].z; fq[3] += v[u].w * v[u].w;
+            }
+            if (++n == 16 / VU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s[e] += fs[e]; q[e] += fq[e]; fs[e] = 0.f; fq[e] = 0.f; }
+                n = 0;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[e] += fs[e]; q[e] += fq[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        for (int m = 32; m >= C4; m >>= 1) {
+            s[e] += __shfl_xor(s[e], m, 64);
+            q[e] += __shfl_xor(q[e], m, 64);
+        }
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    if (lane < C4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sh[e][wave * C4 + lane] = s[e]; sh[4 + e][wave * C4 + lane] = q[e]; }
+    }
+    __syncthreads();
+    double* out = partials + (size_t)blockIdx.x * 2 * C;
+    if (tid < C4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            double a = 0.0, b = 0.0;
+            for (int wv = 0; wv < EW_THREADS / 64; ++wv) { a += sh[e][wv * C4 + tid]; b += sh[4 + e][wv * C4 + tid]; }
+            out[tid * 4 + e] = a;
+            out[C + tid * 4 + e] = b;
+        }
+        __threadfence();                                       // this workgroup's row is visible before its tick
+    }
+    __syncthreads();
+    if (tid == 0) is_last = atomicAdd(counter, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    // the finishing workgroup: column j = tid % n2c, row group g = tid / n2c; fixed order whatever the arrival order was
+    const int n2c = 2 * C, G = EW_THREADS / n2c;
+    const int j = tid % n2c, g = tid / n2c;
+    double t = 0.0;
+    if (g < G)
+        for (int b = g; b < (int)gridDim.x; b += G) t += __builtin_nontemporal_load(partials + (size_t)b * n2c + j);
+    __syncthreads();                                           // sh is free again
+    if (g < G) sh[0][g * n2c + j] = t;
+    __syncthreads();
+    if (tid < n2c) {
+        double a = 0.0;
+        for (int k = 0; k < G; ++k) a += sh[0][k * n2c + tid];
+        sh[1][tid] = a;
+    }
+    __syncthreads();
+    if (tid < C) {
+        const int c = tid;
+        const double count = (double)rows;
+        const double mean = sh[1][c] / count;
+        double var = sh[1][C + c] / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        if (update_moving) {
+            const double vm = (unbiased_moving && rows > 1) ? var * count / (count - 1.0) : var;
+            moving_mean[c] = (float)(moving_mean[c] * (double)momentum + mean * (1.0 - (double)momentum));
+            moving_var[c] = (float)(moving_var[c] * (double)momentum + vm * (1.0 - (double)momentum));
+        }
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        const double gm = gamma ? (double)gamma[c] : 1.0;
+        const double bt = beta ? (double)beta[c] : 0.0;
+        scale[c] = (float)(gm * rstd);
+        shift[c] = (float)(bt - mean * gm * rstd);
+        if (mean_out) mean_out[c] = (float)mean;
+        if (rstd_out) rstd_out[c] = (float)rstd;
+    }
+    if (tid == 0) *counter = 0;
+}
+
 __global__ void bn_bwd_coefs_kernel(const float* __restrict__ dscale, const float* __restrict__ dshift,
                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                     const float* __restrict__ gamma, long long count, int C,
@@ -592,6 +702,26 @@ extern "C" int ptts_bn_finalize(const double* sums, long long count, const float
                        gamma, beta, moving_mean, moving_var, eps, momentum, training, update_moving,
                        unbiased_moving, C, scale, shift, mean, rstd);
     return check_launch("bn_finalize");
+}
+
+// 1 when ptts_bn_batch_stats takes the shape: few channels (C = 4, 8, 16), 16-byte aligned rows
+extern "C" int ptts_bn_batch_stats_supported(long long rows, int C) {
+    return (rows > 0 && (C == 4 || C == 8 || C == 16)) ? 1 : 0;
+}
+
+extern "C" int ptts_bn_batch_stats(const float* x, long long rows, int C, const float* gamma, const float* beta,
+                                   float* moving_mean, float* moving_var, float eps, float momentum, int update_moving,
+                                   int unbiased_moving, float* scale, float* shift, float* mean, float* rstd,
+                                   void* workspace, size_t workspace_bytes, int* counter, void* stream) {
+    PTTS_REQUIRE(x && scale && shift && counter, "bn_batch_stats: null pointer");
+    PTTS_REQUIRE(ptts_bn_batch_stats_supported(rows, C) && al16(x), "bn_batch_stats: unsupported shape rows=%lld C=%d (or x not 16-byte aligned)", rows, C);
+    PTTS_REQUIRE(!update_moving || (moving_mean && moving_var), "bn_batch_stats: update needs moving stats");
+    const int nb = colreduce_vec4_blocks(rows, C);
+    const size_t need = (size_t)nb * 2 * C * sizeof(double);
+    if (!workspace || workspace_bytes < need) { set_error("bn_batch_stats: workspace %zu < %zu", workspace_bytes, need); return PTTS_EWORKSPACE; }
+    hipLaunchKernelGGL(bn_stats_fused_kernel, dim3(nb), dim3(EW_THREADS), 0, (hipStream_t)stream, x, rows, C, (double*)workspace, counter,
+                       gamma, beta, moving_mean, moving_var, eps, momentum, update_moving, unbiased_moving, scale, shift, mean, rstd);
+    return check_launch("bn_batch_stats");
 }
 
 extern "C" int ptts_bn_bwd_coefs(const float* dscale, const float* dshift, const float* mean, const float* rstd,

@@ -256,6 +256,16 @@ def flush_weight_grads():
 
 
 _ws_cache = {}
+_counter_cache = {}
+
+
+def _stream_counter(device):
+    """A zeroed int32 per device and stream for kernels that elect their finishing workgroup (they leave it zero)."""
+    key = (device.index, _hip.stream_id())
+    c = _counter_cache.get(key)
+    if c is None:
+        c = _counter_cache[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return c
 
 
 def _workspace(nbytes, device):
@@ -297,11 +307,27 @@ class _C2M(object):
             reuse = ent is not None and ent[0] is w
             tf = ent[3] if reuse else torch.empty(nb, dtype=torch.uint8, device=w.device)
             tb = ent[4] if reuse else torch.empty(nb, dtype=torch.uint8, device=w.device)
-            call('ptts_conv2d_mfma_tables', ptr(w), ptr(tf), ptr(tb), 5, 5, 4, 4, planes, stream(), tag=(5, 5, planes))
-            ent = (w, w._version, epoch, tf, tb)
             if len(cls.tables) > 512:
                 cls.tables = {}
-            cls.tables[key] = ent
+            cls.tables[key] = ent = (w, w._version, epoch, tf, tb)
+            # with it the other kernels of the same flat buffer whose tables on this stream are out of date (the 7 layers of a stack
+            # after an update): one launch
+            todo = [ent]
+            if flat is not None:
+                for k2, e2 in cls.tables.items():
+                    if k2 is not key and k2[1] == sid and k2[2] == planes and getattr(e2[0], '_ptts_flat', None) is flat and \
+                            (e2[1] != e2[0]._version or e2[2] != epoch):
+                        cls.tables[k2] = e2 = (e2[0], e2[0]._version, epoch, e2[3], e2[4])
+                        todo.append(e2)
+            if len(todo) == 1:
+                call('ptts_conv2d_mfma_tables', ptr(w), ptr(tf), ptr(tb), 5, 5, 4, 4, planes, stream(), tag=(5, 5, planes))
+            else:
+                n = len(todo)
+                pw = (ctypes.c_void_p * n)(*[e[0].data_ptr() for e in todo])
+                pf = (ctypes.c_void_p * n)(*[e[3].data_ptr() for e in todo])
+                pb = (ctypes.c_void_p * n)(*[e[4].data_ptr() for e in todo])
+                call('ptts_conv2d_mfma_tables_grouped', ctypes.cast(pw, ctypes.c_void_p), ctypes.cast(pf, ctypes.c_void_p),
+                     ctypes.cast(pb, ctypes.c_void_p), n, planes, stream(), tag=(n, planes))
         return ent[4] if transposed else ent[3]
 
     @staticmethod
@@ -310,7 +336,8 @@ class _C2M(object):
 
     @classmethod
     def clear(cls):
-        cls.tables = {}
+        """Mark every table out of date (keys and buffers stay: the next use rebuilds them, grouped)."""
+        cls.tables = {k: (e[0], None, -1, e[3], e[4]) for k, e in cls.tables.items()}
 
 
 def conv2d_mfma(on):
@@ -488,17 +515,36 @@ class _DenseSplit(object):
         flat = getattr(owner, '_ptts_flat', None)
         if flat is None:
             return None
-        key = (id(owner), Bm.data_ptr(), K, N, ldb, transB, _hip.stream_id())
+        sid = _hip.stream_id()
+        key = (id(owner), Bm.data_ptr(), K, N, ldb, transB, sid)
         ent = cls.planes.get(key)
         if ent is None or ent[0] is not owner or ent[1] != owner._version or ent[2] != flat.epoch:
             reuse = ent is not None and ent[0] is owner
             buf = ent[3] if reuse else torch.empty(_hip.lib().ptts_dense_planes_bytes(N, K), dtype=torch.uint8, device=Bm.device)
-            call('ptts_split3_dense_weight', ptr(Bm), ldb, K, N, transB, ptr(buf), stream(), tag=(K, N, transB))
-            ent = (owner, owner._version, flat.epoch, buf)
             if len(cls.planes) > 512:
                 cls.planes = {}
-            cls.planes[key] = ent
+            cls.planes[key] = ent = (owner, owner._version, flat.epoch, buf, Bm)
+            # ... and with it every other weight of the same flat buffer whose planes on this stream are out of date: after an update
+            # all of a network's Dense kernels need theirs again, one grouped launch instead of one launch per kernel and direction
+            todo = [(key, ent)]
+            for k2, e2 in cls.planes.items():
+                if k2 is not key and k2[6] == sid and len(e2) == 5 and getattr(e2[0], '_ptts_flat', None) is flat and \
+                        (e2[1] != e2[0]._version or e2[2] != flat.epoch) and e2[4].data_ptr() == k2[1]:
+                    todo.append((k2, e2))
+            if len(todo) == 1:
+                call('ptts_split3_dense_weight', ptr(Bm), ldb, K, N, transB, ptr(buf), stream(), tag=(K, N, transB))
+            else:
+                descs = (_hip.DenseSplitDesc * len(todo))()
+                for d, (k2, e2) in zip(descs, todo):
+                    d.w, d.planes, d.ldw, d.K, d.N, d.transposed = k2[1], e2[3].data_ptr(), k2[4], k2[2], k2[3], k2[5]
+                    cls.planes[k2] = (e2[0], e2[0]._version, flat.epoch, e2[3], e2[4])
+                call('ptts_split3_dense_weight_grouped', ctypes.cast(descs, ctypes.c_void_p), len(todo), stream(), tag=(len(todo),))
         return ent[3]
+
+    @classmethod
+    def clear(cls):
+        """Mark every plane set out of date (keys and buffers stay: the next use rebuilds them, grouped)."""
+        cls.planes = {k: (e[0], None, None, e[3], e[4]) for k, e in cls.planes.items() if len(e) == 5}
 
     @classmethod
     def eligible(cls, A, C, M, N, K, lda, ldc, in_side):
@@ -1182,7 +1228,7 @@ def clear_caches():
     _C1WgradT.clear()
     _C2M.clear()
     _C2C.clear()
-    _DenseSplit.planes = {}
+    _DenseSplit.clear()
     _C1Cache.key = _C1Cache.ap = _C1Cache.y = None
 
 
@@ -1325,16 +1371,24 @@ class BatchNormTrainFn(torch.autograd.Function):
         f32c(z, 'bn.z')
         C = z.shape[-1]
         rows = z.numel() // C
-        sums = colsums(z.view(rows, C))
-        ctx.sync = _SyncBN.world
-        if ctx.sync > 1:          # the statistics of the global batch: one tiny all-reduce (2C doubles)
-            _allreduce_small(sums)
-            rows = rows * ctx.sync
         dev = z.device
         scale = torch.empty(C, dtype=torch.float32, device=dev)
         shift = torch.empty(C, dtype=torch.float32, device=dev)
         mean = torch.empty(C, dtype=torch.float32, device=dev)
         rstd = torch.empty(C, dtype=torch.float32, device=dev)
+        ctx.sync = _SyncBN.world
+        if ctx.sync <= 1 and z.data_ptr() % 16 == 0 and _hip.lib().ptts_bn_batch_stats_supported(rows, C):
+            # the conv stacks' few-channel maps: statistics and affine in one launch
+            ws = _workspace(_hip.lib().ptts_colstats_workspace_bytes(rows, C), dev)
+            call('ptts_bn_batch_stats', ptr(z), rows, C, ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var), BN_EPS, BN_MOMENTUM,
+                 1 if update_moving else 0, 1 if unbiased_moving else 0, ptr(scale), ptr(shift), ptr(mean), ptr(rstd),
+                 ptr(ws), ws.numel(), ptr(_stream_counter(dev)), stream(), tag=(rows, C))
+            ctx.save_for_backward(z, gamma, mean, rstd)
+            return scale, shift
+        sums = colsums(z.view(rows, C))
+        if ctx.sync > 1:          # the statistics of the global batch: one tiny all-reduce (2C doubles)
+            _allreduce_small(sums)
+            rows = rows * ctx.sync
         call('ptts_bn_finalize', ptr(sums), rows, ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var),
              BN_EPS, BN_MOMENTUM, 1, 1 if update_moving else 0, 1 if unbiased_moving else 0, C,
              ptr(scale), ptr(shift), ptr(mean), ptr(rstd), stream())

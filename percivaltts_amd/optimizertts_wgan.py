@@ -471,7 +471,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
             ops.clear_caches()         # every derived operand (bf16 planes, Toeplitz tables) must be rebuilt inside the graph
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, stream=side):      # the stream of the warm-up: stream-keyed operand caches (weight planes) keep their entries and are refreshed grouped
                 out = fn()
             ops.clear_caches()         # ... and the graph's private copies are not for eager code
             self.cfg.train_wgan_parallel_streams, self._model.kerasmodel.parallel_branches = saved_streams

@@ -1097,3 +1097,45 @@ def test_lstm_recurrence_graph_replay_equals_the_plain_launches(ops):
     assert (s2[0] - s1[0]) + (s2[1] - s1[1]) == 2, (s1, s2)
     for name, a, c, p in zip(('h', 'dx', 'dW', 'dU', 'db'), first, again, plain):
         assert torch.equal(a, p) and torch.equal(c, p), name
+
+
+def test_bn_batch_stats_one_launch_equals_the_three_launch_path(ops):
+    """csrc/elementwise.hip, bn_stats_fused_kernel (the conv stacks' C = 4 maps): partial sums, the finishing workgroup's fixed-order
+    reduction and bn_finalize's arithmetic in ONE launch.  Against ptts_colstats + ptts_bn_finalize on the same map: affine, saved mean /
+    rstd and the moving statistics to fp32 rounding (the two reduction trees differ in the last bits of the fp64 sums); against the
+    fp64 oracle; twice the same bits (the result does not depend on which workgroup finishes last); the counter is left zero."""
+    import ctypes
+    lib = ops._hip.lib()
+    g = gen(5)
+    for (B, T, F, C) in ((64, 400, 65, 4), (3, 37, 13, 4), (2, 50, 9, 16), (1, 1, 5, 8)):
+        z = dev(torch.randn(B, T, F, C, generator=g, dtype=torch.float64) * 1.7 + 0.4)
+        gamma = dev(torch.rand(C, generator=g, dtype=torch.float64) + 0.5)
+        beta = dev(torch.randn(C, generator=g, dtype=torch.float64))
+        rows = B * T * F
+        assert lib.ptts_bn_batch_stats_supported(rows, C) == 1
+        outs = []
+        for fused in (True, False, True):
+            mm, mv = dev(torch.full((C,), 0.25, dtype=torch.float64)), dev(torch.full((C,), 1.5, dtype=torch.float64))
+            scale, shift, mean, rstd = [torch.empty(C, dtype=torch.float32, device='cuda') for _ in range(4)]
+            ws = torch.empty(lib.ptts_colstats_workspace_bytes(rows, C), dtype=torch.uint8, device='cuda')
+            if fused:
+                cnt = torch.zeros(1, dtype=torch.int32, device='cuda')
+                ops.call('ptts_bn_batch_stats', ops.ptr(z), rows, C, ops.ptr(gamma), ops.ptr(beta), ops.ptr(mm), ops.ptr(mv), 1e-3, 0.99, 1, 0,
+                         ops.ptr(scale), ops.ptr(shift), ops.ptr(mean), ops.ptr(rstd), ops.ptr(ws), ws.numel(), ops.ptr(cnt), ops.stream())
+                torch.cuda.synchronize()
+                assert int(cnt.item()) == 0
+            else:
+                sums = torch.empty(2 * C, dtype=torch.float64, device='cuda')
+                ops.call('ptts_colstats', ops.ptr(z), rows, C, 0, None, None, None, 0.3, ops.ptr(sums), ops.ptr(ws), ws.numel(), ops.stream())
+                ops.call('ptts_bn_finalize', ops.ptr(sums), rows, ops.ptr(gamma), ops.ptr(beta), ops.ptr(mm), ops.ptr(mv), 1e-3, 0.99, 1, 1, 0, C,
+                         ops.ptr(scale), ops.ptr(shift), ops.ptr(mean), ops.ptr(rstd), ops.stream())
+            torch.cuda.synchronize()
+            outs.append([t.clone() for t in (scale, shift, mean, rstd, mm, mv)])
+        for a, b in zip(outs[0], outs[2]):
+            assert torch.equal(a, b), 'the fused launch is not reproducible'
+        for name, a, b in zip(('scale', 'shift', 'mean', 'rstd', 'moving_mean', 'moving_var'), outs[0], outs[1]):
+            close(a, b.double().cpu(), rtol=2e-6, atol=1e-6, what=name + ' fused vs three launches')
+        z64 = z.double().cpu().reshape(-1, C)
+        m64, v64 = z64.mean(0), z64.var(0, unbiased=False)
+        close(outs[0][2], m64, rtol=1e-5, atol=1e-6, what='mean')
+        close(outs[0][0], gamma.double().cpu() / torch.sqrt(v64 + 1e-3), rtol=1e-5, atol=1e-6, what='scale')

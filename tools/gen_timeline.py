@@ -24,7 +24,11 @@ def run(bf16):
     dev = backend_hip.device()
     cfg, voc, mod, crit, opt = bench.build_optimizer(args, args.ctx, 65, 20, args.batch, args.errtype)
     X, Y = bench.synthetic(args.batch, args.frames, args.ctx, voc.featuressize(), 65, 123, dev)
-    gen = (lambda: opt._graphed('generator', X, Y)) if graph else (lambda: opt.generator_step(X, Y))
+    kind = os.environ.get('TL_KIND', 'generator')        # which step is cut out of the trace
+    if kind == 'critic':
+        gen = (lambda: opt._graphed('critic', X, Y)) if graph else (lambda: opt.critic_step(X, Y))
+    else:
+        gen = (lambda: opt._graphed('generator', X, Y)) if graph else (lambda: opt.generator_step(X, Y))
     for _ in range(3):
         opt.critic_step(X, Y)
         gen()
@@ -66,6 +70,16 @@ def report(d):
         busy = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in rs)
         print('queue %s: %4d kernels, busy %.3f ms, span %.3f .. %.3f ms' % (q, len(rs), busy / 1e6, (int(rs[0]['Start_Timestamp']) - t0) / 1e6,
               (max(int(r['End_Timestamp']) for r in rs) - t0) / 1e6))
+    fam = {}
+    for r in step:
+        f = family(r['Kernel_Name'])
+        c = fam.setdefault(f, [0, 0])
+        c[0] += 1; c[1] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+    print('\nkernel families of the step (launches, total us, mean us):')
+    for f, (n, t) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+        print('  %4d %9.1f %8.1f  %s' % (n, t / 1e3, t / 1e3 / n, f))
+    if os.environ.get('TL_NOSEG', '0') == '1':
+        return
     # segments: consecutive kernels of the same (queue, family)
     print('\nsegments (start ms, end ms, queue, n, busy ms, family):')
     for q, rs in sorted(qs.items(), key=lambda kv: int(kv[1][0]['Start_Timestamp'])):
