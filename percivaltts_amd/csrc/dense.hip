@@ -358,8 +358,9 @@ static int pick_mt(int M, int col_blocks) {
 // A row is eight 32-byte segments (one 16-column MFMA tile each); segment t of row r lies at position
 // (t + r + 4 (r >> 3)) & 7: the four rows a 16-lane group reads, and the two groups of a half-wave, hit disjoint banks.
 // Output tile 128 x 128 per workgroup (8 waves: 2 x 4 MFMA tiles each), the frames of a tile shared out over
-// 256 / tiles workgroups, partial sums added with fp32 atomics into the caller's gradient buffer (as the fp32 grouped
-// kernel does).  The bias gradient is summed from the staged dY values by the workgroups of the first tile row.
+// 256 / tiles workgroups; every workgroup stores its partial tile (and 128 bias sums, from the staged dY values of the first
+// tile row) as a row of the caller's workspace, and dense_wgrad_reduce_kernel -- one grouped launch for a batch of products -- adds
+// the rows in a fixed order into the gradient buffers (a first version flushed with fp32 atomics from every workgroup).
 // ------------------------------------------------------------------------------------------------------------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef s16x4 __attribute__((address_space(3)))* lds_s16x4_ptr;

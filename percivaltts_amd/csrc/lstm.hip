@@ -490,7 +490,7 @@ struct LstmPersistArgs {
 __global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(LstmPersistArgs a) {
     constexpr int H = 256, KS = 16;
     __shared__ float red[2][4][2][256];
-    __shared__ int give_up;
+    __shared__ volatile int give_up;
     const int g = blockIdx.x % a.groups, jt = blockIdx.x / a.groups;        // 32 members per group
     const int nslices = a.groups / a.ndir;
     const int d = g / nslices, b0 = (g - d * nslices) * 16, j0 = jt * 8;
@@ -596,7 +596,23 @@ using namespace ptts;
 static bool lstm_persistent_ok(int B, int T, int H, int ndir) {
     const char* e = getenv("PTTS_LSTM_PERSISTENT");
     const int groups = ((B + 15) / 16) * ndir;
-    return e && atoi(e) != 0 && H == 256 && T >= 2 && groups * 32 <= 1024;
+    if (!(e && atoi(e) != 0 && H == 256 && T >= 2 && groups * 32 <= 1024)) return false;
+    // every workgroup of the grid must be resident at once (the members of a group wait for each other): refuse the path --
+    // the per-step launches run instead -- unless the occupancy of an EMPTY chip covers the grid.  (Kernels of other streams
+    // can still hold CUs; the kernel's poll then gives up after ~2^21 rounds and the step shows NaNs: opt-in, experimental.)
+    static int per_cu = -1, ncu = 0;
+    if (per_cu < 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&lstm_fwd_persistent_kernel), 256, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            per_cu = 0;
+        } else {
+            ncu = prop.multiProcessorCount;
+        }
+    }
+    return (long long)per_cu * ncu >= (long long)groups * 32;
 }
 
 // ---- the T launches of a recurrence replayed as ONE hipGraph launch ---------------------------------------------------------------

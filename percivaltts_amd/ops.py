@@ -179,10 +179,10 @@ def _defer_wgrad(x2, dy2, gw, gb, K_in, N, M_rows, mode, scale, shift, mask_src,
 
 
 def _wgrad_split_ok(x2, dy2, mask_src, scale, shift, K_in, N, M_rows):
-    """The bf16x6 split weight-gradient kernel (csrc/dense.hip) takes this product: the wide ones (the LSTM input and
-    recurrent projections, N = 1024 / 2048: 188 us against 292 for the fp32 kernel).  At 256 x 256 its 128 x 128 tiles
-    re-read both operands twice and 64 workgroups per tile flush with atomics: 46 us a product, no better than the grouped
-    fp32 launch (60 us a product inside the step), which therefore keeps the Dense layers' gradients."""
+    """The two-stage split weight-gradient kernels (csrc/dense.hip: partial tiles per workgroup, one grouped fixed-order reduce)
+    take this product: every Dense / LSTM weight gradient over >= 2048 frames with N >= wgrad_min_n (16) outside deterministic
+    mode -- 31 us + its share of the reduce at 256 x 256 x 25 600 against 60 us a product for the grouped fp32 launch, 188 us
+    against 292 at N = 2048 (the LSTM projections)."""
     if not (_DenseSplit.enabled and not _Flags.deterministic and M_rows >= 2048 and N >= _DenseSplit.wgrad_min_n and K_in >= 16):
         return False
     if not _hip.lib().ptts_dense_wgrad_bf16x6_supported(K_in, N, M_rows, x2.stride(0), dy2.stride(0)):
@@ -551,6 +551,8 @@ class _DenseSplit(object):
         """in_side: the tensors read beside A in 16-byte pieces (mask_src, scale, shift); C, bias and out_mask may be
         unaligned or N / ldc no multiple of 4 (the 65-bin spectral head): the kernel then stores element-wise."""
         if not (cls.enabled and M >= 1024 and N >= 16 and K >= 16 and K % 4 == 0 and lda % 4 == 0):
+            return False
+        if not _hip.lib().ptts_dense_bf16x6_supported(M, N, K, lda, ldc):       # (K > 65536, too many column blocks: the fp32 kernel)
             return False
         return all(t is None or t.data_ptr() % 16 == 0 for t in (A,) + tuple(in_side))
 

@@ -1139,3 +1139,42 @@ def test_bn_batch_stats_one_launch_equals_the_three_launch_path(ops):
         m64, v64 = z64.mean(0), z64.var(0, unbiased=False)
         close(outs[0][2], m64, rtol=1e-5, atol=1e-6, what='mean')
         close(outs[0][0], gamma.double().cpu() / torch.sqrt(v64 + 1e-3), rtol=1e-5, atol=1e-6, what='scale')
+
+
+@pytest.mark.parametrize('M', [2048, 3000, 4095])
+def test_dense_weight_gradient_deferred_two_stage_between_2048_and_4096_rows(ops, M):
+    """ops.deferred_weight_grads() hands every Dense weight gradient over >= 2048 frames to the two-stage split kernels
+    (ptts_dense_wgrad_bf16x6_partials + ptts_dense_wgrad_reduce_grouped, csrc/dense.hip); the threshold came down from 4096
+    without a case below it.  Weights of a flat parameter buffer (the deferred path accumulates straight into the
+    buffer's gradient views), two products that share one gradient buffer (first- and second-order sweeps of a layer do), a ragged
+    row count: dW and db against the fp64 products, and the kernels named."""
+    import torch.nn as nn
+    from percivaltts_amd import layers
+    g = gen(41 + M)
+    K, N = 256, 256
+
+    class Net(nn.Module):
+        def __init__(self):
+            super(Net, self).__init__()
+            self.w = nn.Parameter(torch.randn(K, N, generator=g) / 16.0)
+            self.b = nn.Parameter(torch.zeros(N))
+    net = Net()
+    flat = layers.FlatParams(net, torch.device('cuda'))
+    x1 = torch.randn(M, K, generator=g, dtype=torch.float64)
+    x2 = torch.randn(M, K, generator=g, dtype=torch.float64)
+    dy1 = torch.randn(M, N, generator=g, dtype=torch.float64)
+    dy2 = torch.randn(M, N, generator=g, dtype=torch.float64)
+    ops.dense_split(True); ops.deterministic(False)
+    flat.zero_grad()
+    with ops._hip.KernelTimer() as kt, ops.deferred_weight_grads():          # (the queue is launched when the inner context exits)
+        for x, dy in ((x1, dy1), (x2, dy2)):
+            y = ops.dense(dev(x).view(1, M, K), net.w, net.b)
+            y.backward(dev(dy).view(1, M, N))
+    torch.cuda.synchronize()
+    names = [n for n, _, _ in kt.durations_ms()]
+    assert names.count('ptts_dense_wgrad_bf16x6_partials') == 2 and 'ptts_dense_wgrad_reduce_grouped' in names, names
+    dW = x1.t() @ dy1 + x2.t() @ dy2
+    db = dy1.sum(0) + dy2.sum(0)
+    e = float((net.w.grad.double().cpu() - dW).norm() / dW.norm())
+    assert e < 3e-6, e
+    close(net.b.grad, db, rtol=2e-5, atol=2e-4, what='db')
