@@ -277,6 +277,22 @@ int ptts_dense_wgrad_bf16x6(const float* A, const float* dY, const float* mask_s
 int ptts_dense_bf16x6(const float* A, const void* planes, const float* bias, float* C, int M, int N, int K,
                       long long lda, long long ldc, int in_mode, const float* in_scale, const float* in_shift,
                       const float* mask_src, float alpha, int accumulate, const float* out_mask, void* stream);
+/* Frequency-domain context Conv1D, helper: Ap [NB][2][B][2*Kh] floats with [Xr | .] in part 0 and [Xi | .] in part 1 (columns < Cin)
+ * -> columns Kh .. Kh+Cin-1 get -Xi (part 0) and Xr (part 1): the rows [Xr | -Xi], [Xi | Xr] of the real form of a complex product. */
+int ptts_dft_mirror(float* Ap, int NB, int B, int Cin, int Kh, void* stream);
+
+/* Frequency-domain context Conv1D, the kernel's side: planes (ptts_dense_bf16x6_batched layout, ptts_dense_planes_bytes(N, 2*Kh) per
+ * frequency) of [Wr_f ; Wi_f] [2*Kh][N], W^_f = sum_k w[k] tw[(f,.)][k], for f < NB, from w [KW][Cin][N] (KW in 3, 5, 7, 9, 11, 21) and
+ * the twiddle rows tw [2*NB][KW] (row 2f: cos, row 2f+1: -sin of 2 pi f (pl - k) / P).  Once per weight update. */
+int ptts_conv1d_freq_kernel_planes(const float* w, const float* tw, void* planes, int NB, int KW, int Cin, int N, int Kh, void* stream);
+
+/* nbatch products of one shape in one launch: C_z[M,N] = A_z[M,K] . B_z (+ bias), A_z = A + z*strideA and C_z = C + z*strideC (floats;
+ * strideA = 0 shares the left operand), B_z = the planes at planes + z*stride_planes_bytes (ptts_split3_dense_weight[_grouped] layout).
+ * planes_count 3 = fp32 arithmetic (six bf16 products), 1 = one bf16 product.  The building block of the frequency-domain context
+ * Conv1D (kl.Conv1D of networktts.py:116-120 as DFT -> per-frequency products -> inverse DFT). */
+int ptts_dense_bf16x6_batched(const float* A, long long strideA, const void* planes, long long stride_planes_bytes,
+                              const float* bias, float* C, long long strideC, int nbatch, int M, int N, int K,
+                              long long lda, long long ldc, int planes_count, void* stream);
 
 /* The context Conv1D forward (reference networktts.py:116-120: kl.Conv1D(width, winlen, padding='same')) as an fp32
  * product on the bf16 matrix cores by a three-way operand split ("bf16x6"; split.hip): x = x1 + x2 + x3 in bf16 (round

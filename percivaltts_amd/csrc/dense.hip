@@ -122,6 +122,50 @@ __global__ __launch_bounds__(256) void split3_dense_weight_grouped_kernel(SplitG
         *reinterpret_cast<uint4*>(planes + p * ps + (size_t)idx * 8) = make_uint4(q[p][0], q[p][1], q[p][2], q[p][3]);
 }
 
+// ---- frequency-domain context Conv1D: the kernel's transform, straight into the per-frequency planes ----------------------------
+// B_f [2 Kh][N] = [Wr_f ; Wi_f],  W^_f[c][n] = sum_k w[k][c][n] e^{-2 pi i f (pl - k) / P}  (rows c < Cin of each half, the rest zero),
+// written as the planes ptts_dense_bf16x6_batched reads for frequency f.  A lane owns one 16-byte fragment piece (8 consecutive rows
+// of one column) for FCH frequencies: its 8 x KW taps stay in registers, a frequency costs 8 KW FMAs and one split.  (A GEMM with
+// the twiddle matrix + a grouped split pass did the same in 0.35 ms per update: 263 MB of fp32 written, read again and split.)
+constexpr int WDFT_FCH = 32;
+template <int KW>
+__global__ __launch_bounds__(256) void conv1d_wdft_planes_kernel(const float* __restrict__ w, const float* __restrict__ tw,
+                                                                u16* __restrict__ planes, long long fstride, int NB, int Cin,
+                                                                int N, int Kh, int NT, int KS) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;        // (nt, ks, lane)
+    if (idx >= (long long)NT * KS * 64) return;
+    const int lane = (int)(idx & 63);
+    const long long t = idx >> 6;
+    const int ks = (int)(t % KS), nt = (int)(t / KS);
+    const int n = nt * 16 + (lane & 15), k0 = ks * 32 + (lane >> 4) * 8;
+    const int part = k0 >= Kh ? 1 : 0, c0 = k0 - part * Kh;                 // Kh % 8 == 0: the 8 rows lie in one half
+    float wr[KW][8];
+#pragma unroll
+    for (int k = 0; k < KW; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            wr[k][e] = (n < N && c0 + e < Cin && k0 < 2 * Kh) ? w[((long long)k * Cin + c0 + e) * N + n] : 0.f;
+    const size_t ps = (size_t)NT * KS * 512;
+    const int f0 = blockIdx.y * WDFT_FCH;
+    for (int f = f0; f < min(NB, f0 + WDFT_FCH); ++f) {
+        const float* __restrict__ tr = tw + ((long long)f * 2 + part) * KW;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            const float c = tr[k];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaf(c, wr[k][e], v[e]);
+        }
+        unsigned q[3][4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) split3_pair(v[2 * h], v[2 * h + 1], q[0][h], q[1][h], q[2][h]);
+        u16* pf = planes + (long long)f * fstride;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            *reinterpret_cast<uint4*>(pf + p * ps + (size_t)idx * 8) = make_uint4(q[p][0], q[p][1], q[p][2], q[p][3]);
+    }
+}
+
 struct DenseArgs {
     const float* A; const float* mask_src; const float* in_scale; const float* in_shift;
     const u16* planes; const float* bias; const float* out_mask; float* C;
@@ -129,10 +173,16 @@ struct DenseArgs {
     long long lda, ldc;
     float alpha, out_alpha;
     int accumulate, has_affine, vec_out;
+    long long bsA, bsP, bsC;          // batched launch (gridDim.z products of one shape): strides of A and C in floats, of the planes in u16
 };
 
 template <int MODE, bool AFFINE, int MT, int NPL>
 __global__ __launch_bounds__(THREADS) void dense_bf16x6_kernel(DenseArgs g) {
+    if (gridDim.z > 1) {
+        g.A += (long long)blockIdx.z * g.bsA;
+        g.planes += (long long)blockIdx.z * g.bsP;
+        g.C += (long long)blockIdx.z * g.bsC;
+    }
     constexpr int TBM = 16 * MT;
     constexpr int NA = (TBM * 8 + THREADS - 1) / THREADS;     // 16-byte quads (4 k) per lane and k-step
     constexpr int ROWS = NA * THREADS / 8;                    // staged rows incl. the pad rows the idle lanes of the last slot write
@@ -668,6 +718,7 @@ extern "C" int ptts_dense_bf16x6(const float* A, const void* planes, const float
     g.out_mask = out_mask; g.C = C; g.M = M; g.N = N; g.K = K;
     g.NT = (N + NBLK - 1) / NBLK * (NBLK / 16); g.KS = (K + BK - 1) / BK;
     g.lda = lda; g.ldc = ldc; g.alpha = alpha; g.out_alpha = alpha; g.accumulate = accumulate; g.has_affine = in_scale != nullptr; g.vec_out = vec_out;
+    g.bsA = g.bsP = g.bsC = 0;
     const int cb = (N + NBLK - 1) / NBLK;
     const int mt = pick_mt(M, cb);
     const dim3 grid((unsigned)((M + 16 * mt - 1) / (16 * mt)), (unsigned)cb);
@@ -691,6 +742,66 @@ extern "C" int ptts_dense_bf16x6(const float* A, const void* planes, const float
 #undef DNS_M
 #undef DNS_L
     return check_launch("dense_bf16x6");
+}
+
+// planes of [Wr_f ; Wi_f] [2 Kh][N] for f = 0 .. NB-1 (each ptts_dense_planes_bytes(N, 2 Kh) long) from the kernel w [KW][Cin][N] and
+// the twiddle rows tw [(f, part)][KW] = cos / -sin(2 pi f (pl - k) / P)
+extern "C" int ptts_conv1d_freq_kernel_planes(const float* w, const float* tw, void* planes, int NB, int KW, int Cin, int N, int Kh,
+                                              void* stream) {
+    PTTS_REQUIRE(w && tw && planes && NB > 0 && Cin > 0 && N > 0, "conv1d_freq_kernel_planes: bad arguments");
+    PTTS_REQUIRE(Kh >= Cin && Kh % 8 == 0, "conv1d_freq_kernel_planes: Kh=%d must be a multiple of 8 and >= Cin=%d", Kh, Cin);
+    const int NT = (N + NBLK - 1) / NBLK * (NBLK / 16), KS = (2 * Kh + BK - 1) / BK;
+    const long long total = (long long)NT * KS * 64;
+    const long long fstride = (long long)(ptts_dense_planes_bytes(N, 2 * Kh) / sizeof(u16));
+    const dim3 grid((unsigned)((total + 255) / 256), (unsigned)((NB + WDFT_FCH - 1) / WDFT_FCH));
+#define WDFT(KWv) hipLaunchKernelGGL(conv1d_wdft_planes_kernel<KWv>, grid, dim3(256), 0, (hipStream_t)stream, w, tw, (u16*)planes, fstride, NB, Cin, N, Kh, NT, KS)
+    switch (KW) {
+        case 3: WDFT(3); break;
+        case 5: WDFT(5); break;
+        case 7: WDFT(7); break;
+        case 9: WDFT(9); break;
+        case 11: WDFT(11); break;
+        case 21: WDFT(21); break;
+        default: set_error("conv1d_freq_kernel_planes: KW=%d not instantiated (3, 5, 7, 9, 11, 21)", KW); return PTTS_EINVAL;
+    }
+#undef WDFT
+    return check_launch("conv1d_freq_kernel_planes");
+}
+
+// nbatch products C_z[M,N] = A_z[M,K] . B_z (+ bias) of ONE shape in one launch (blockIdx.z = z): A_z = A + z strideA, C_z = C + z strideC
+// (floats; strideA = 0: the same left operand for every product), B_z = the planes at planes + z stride_planes_bytes.  No input
+// transform, no masks.  planes_count: 3 = fp32 arithmetic (six products), 1 = one bf16 product -- explicit here, whatever
+// ptts_set_bf16_products says.  What the frequency-domain context Conv1D is made of (ops._C1FFT): DFT, per-frequency products, inverse DFT.
+extern "C" int ptts_dense_bf16x6_batched(const float* A, long long strideA, const void* planes, long long stride_planes_bytes,
+                                         const float* bias, float* C, long long strideC, int nbatch, int M, int N, int K,
+                                         long long lda, long long ldc, int planes_count, void* stream) {
+    PTTS_REQUIRE(A && planes && C && nbatch > 0 && nbatch <= 65535, "dense_bf16x6_batched: bad arguments");
+    PTTS_REQUIRE(ptts_dense_bf16x6_supported(M, N, K, lda, ldc), "dense_bf16x6_batched: unsupported shape M=%d N=%d K=%d lda=%lld ldc=%lld", M, N, K, lda, ldc);
+    PTTS_REQUIRE(lda >= K && ldc >= N && planes_count >= 1 && planes_count <= 3 && planes_count != 2, "dense_bf16x6_batched: bad leading dims / planes");
+    PTTS_REQUIRE(stride_planes_bytes % 16 == 0 && strideA % 4 == 0 && ((uintptr_t)A & 15) == 0, "dense_bf16x6_batched: strides of A / planes must keep 16-byte alignment");
+    const bool vec_out = N % 4 == 0 && ldc % 4 == 0 && strideC % 4 == 0 && ((uintptr_t)C & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0);
+    DenseArgs g;
+    g.A = A; g.mask_src = nullptr; g.in_scale = nullptr; g.in_shift = nullptr; g.planes = (const u16*)planes; g.bias = bias;
+    g.out_mask = nullptr; g.C = C; g.M = M; g.N = N; g.K = K;
+    g.NT = (N + NBLK - 1) / NBLK * (NBLK / 16); g.KS = (K + BK - 1) / BK;
+    g.lda = lda; g.ldc = ldc; g.alpha = 0.f; g.out_alpha = 0.f; g.accumulate = 0; g.has_affine = 0; g.vec_out = vec_out;
+    g.bsA = strideA; g.bsP = stride_planes_bytes / 2; g.bsC = strideC;
+    const int cb = (N + NBLK - 1) / NBLK;
+    const int mt = pick_mt(M, cb * nbatch);
+    const dim3 grid((unsigned)((M + 16 * mt - 1) / (16 * mt)), (unsigned)cb, (unsigned)nbatch);
+    hipStream_t st = (hipStream_t)stream;
+    const bool one = planes_count == 1;
+#define DNS_B(MT) do { if (one) hipLaunchKernelGGL((dense_bf16x6_kernel<PTTS_IN_NONE, false, MT, 1>), grid, dim3(THREADS), 0, st, g); \
+                       else hipLaunchKernelGGL((dense_bf16x6_kernel<PTTS_IN_NONE, false, MT, 3>), grid, dim3(THREADS), 0, st, g); } while (0)
+    switch (mt) {
+        case 4: DNS_B(4); break;
+        case 5: DNS_B(5); break;
+        case 6: DNS_B(6); break;
+        case 7: DNS_B(7); break;
+        default: DNS_B(8); break;
+    }
+#undef DNS_B
+    return check_launch("dense_bf16x6_batched");
 }
 
 // 1 when ptts_dense_wgrad_bf16x6 takes the shape

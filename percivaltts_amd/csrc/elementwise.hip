@@ -787,6 +787,32 @@ __global__ __launch_bounds__(EW_THREADS) void gated_mul_bwd_kernel(const float4*
     if (blockIdx.x == 0 && (int)threadIdx.x < tail) gated_bwd1(dyt[threadIdx.x], at[threadIdx.x], bt[threadIdx.x], dat[threadIdx.x], dbt[threadIdx.x]);
 }
 
+// ---- frequency-domain context Conv1D (ops._C1FFT): the second half of the per-frequency left operand -----------------------------
+// Ap [NB][2][B][2 Kh] holds [Xr | .] in the rows of part 0 and [Xi | .] in the rows of part 1 (columns < Cin, written by the DFT
+// product); the complex product (Xr + i Xi)(Wr + i Wi) as ONE real product against [Wr; Wi] needs the rows [Xr | -Xi] and [Xi | Xr].
+__global__ __launch_bounds__(256) void dft_mirror_kernel(float* __restrict__ Ap, long long total, int B, int Cin, int Kh) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % Cin);
+        const long long fb = i / Cin;
+        const int b = (int)(fb % B);
+        const long long f = fb / B;
+        float* r0 = Ap + ((f * 2 + 0) * B + b) * (2LL * Kh);
+        float* r1 = Ap + ((f * 2 + 1) * B + b) * (2LL * Kh);
+        const float xr = r0[c], xi = r1[c];
+        r0[Kh + c] = -xi;
+        r1[Kh + c] = xr;
+    }
+}
+
+extern "C" int ptts_dft_mirror(float* Ap, int NB, int B, int Cin, int Kh, void* stream) {
+    PTTS_REQUIRE(Ap && NB > 0 && B > 0 && Cin > 0 && Kh >= Cin, "dft_mirror: bad arguments");
+    const long long total = (long long)NB * B * Cin;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(dft_mirror_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, Ap, total, B, Cin, Kh);
+    return check_launch("dft_mirror");
+}
+
 extern "C" int ptts_gated_mul_fwd(const float* a, const float* b, float* y, long long n, void* stream) {
     PTTS_REQUIRE(a && b && y && n > 0, "gated_mul_fwd: bad args");
     PTTS_REQUIRE(al16(a) && al16(b) && al16(y), "gated_mul_fwd: tensors must be 16-byte aligned");

@@ -1227,11 +1227,173 @@ def clear_caches():
     context-Conv1D product).  A hipGraph capture must start from empty caches: an entry made before the capture would be
     taken instead of being recomputed INSIDE the graph, and every replay would then read the stale copy."""
     _C1Split.clear()
+    _C1FFT.clear()
     _C1WgradT.clear()
     _C2M.clear()
     _C2C.clear()
     _DenseSplit.clear()
     _C1Cache.key = _C1Cache.ap = _C1Cache.y = None
+
+
+class _C1FFT(object):
+    """Context Conv1D FORWARD in the frequency domain (round 3): y = IDFT_t( DFT_t(x) . DFT(w) ), every stage a batched bf16x6 split
+    product of csrc/dense.hip (fp32 arithmetic: six bf16 MFMA products, fp32 accumulation), i.e. no FFT kernel at all:
+        1  X^[(f,part), b, c]   = D [2 NB x T] . x_b [T x Cin]                      (once per input: generator and critic convolve the same)
+        2  Y^_f [(part,b), n]   = [Xr | -Xi ; Xi | Xr]_f [2B x 2 Kh] . [Wr ; Wi]_f [2 Kh x N]   for the NB = P/2 + 1 frequencies
+        3  y_b [T x N]          = E [T x 2 NB] . Y^_b [2 NB x N] + bias
+    with P = T + KW - 1 rounded up to even (the linear convolution fits one period: no FFT-size constraint, the transforms are
+    matrix products).  KW = 21 taps over Cin = 601 channels cost 2 T KW Cin N flop per sample in the time domain; here the taps
+    are gone from the big product: 2 (2B)(2 Kh) N NB per batch, 8 x fewer at BASELINE size, plus the two transforms (together
+    about as much again).  The kernel's transform [Wr ; Wi]_f = Tw . w is one small GEMM + one grouped split per update.
+    Reference: kl.Conv1D of networktts.py:116-120 (pCNN1D), 'same' padding, cross-correlation as TF computes it.
+    On by default for fp32 arithmetic (not in the one-product bf16 mode, whose time-domain kernel is as fast); PTTS_CONV1D_FFT=0 /
+    conv1d_fft(False) select the time-domain kernels."""
+    default = os.environ.get('PTTS_CONV1D_FFT', '1') == '1'
+    enabled = default
+    KWS = (3, 5, 7, 9, 11, 21)      # instantiations of conv1d_wdft_planes_kernel<KW>
+    consts = {}         # (T, KW, device, stream) -> dict of the twiddle operands
+    x_src = None; x_key = None; x_hat = None
+    w_hat = {}          # (id(w), stream) -> (w, version, epoch, W^ buffer, planes)
+    bufs = {}           # persistent zero-padded buffers by (name, shape key, stream)
+
+    @staticmethod
+    def eligible(a, w):
+        B, T, Cin = a.shape
+        KW, _, N = w.shape
+        return a.is_cuda and B * T >= 4096 and KW >= 5 and KW % 2 == 1 and T % 4 == 0 and N % 4 == 0 and Cin >= 64
+
+    @classmethod
+    def geometry(cls, T, KW, Cin):
+        P = T + KW - 1
+        P += P & 1
+        NB = P // 2 + 1
+        Kh = (Cin + 7) // 8 * 8            # half of the per-frequency reduction length (2 Kh a multiple of 16)
+        return P, NB, Kh
+
+    @classmethod
+    def _buf(cls, name, key, nfloats, dev):
+        k = (name, key, _hip.stream_id())
+        t = cls.bufs.get(k)
+        if t is None:
+            t = cls.bufs[k] = torch.zeros(nfloats, dtype=torch.float32, device=dev)
+        return t
+
+    @classmethod
+    def const(cls, T, KW, dev):
+        key = (T, KW, dev.index, _hip.stream_id())
+        c = cls.consts.get(key)
+        if c is not None:
+            return c
+        import math
+        P = T + KW - 1
+        P += P & 1
+        NB = P // 2 + 1
+        pl = (KW - 1) // 2
+        f = torch.arange(NB, dtype=torch.float64).view(NB, 1)
+        t = torch.arange(T, dtype=torch.float64).view(1, T)
+        th = 2.0 * math.pi * torch.remainder(f * t, P) / P
+        D = torch.stack([torch.cos(th), -torch.sin(th)], dim=1).reshape(2 * NB, T)               # rows (f, part): Xr, Xi
+        cf = torch.full((NB,), 2.0, dtype=torch.float64); cf[0] = 1.0; cf[P // 2] = 1.0
+        R = 2 * NB
+        Rp = (R + 3) // 4 * 4
+        E = torch.zeros(T, Rp, dtype=torch.float64)                                              # y[t] = sum_r E[t, r] Y^[r]
+        E[:, 0:R:2] = (torch.cos(th) * cf.view(NB, 1) / P).t()
+        E[:, 1:R:2] = (-torch.sin(th) * cf.view(NB, 1) / P).t()
+        k = torch.arange(KW, dtype=torch.float64).view(1, KW)
+        tk = 2.0 * math.pi * torch.remainder(f * (pl - k), P) / P
+        Tw = torch.stack([torch.cos(tk), -torch.sin(tk)], dim=1).reshape(R, KW)                  # rows (f, part): Wr, Wi
+        c = {'P': P, 'NB': NB, 'R': R, 'Rp': Rp,
+             'D': D.to(torch.float32).to(dev).contiguous(), 'E': E.to(torch.float32).to(dev).contiguous(),
+             'Tw': Tw.to(torch.float32).to(dev).contiguous()}
+        cls.consts[key] = c
+        return c
+
+    @classmethod
+    def x_transform(cls, a, KW):
+        """[Xr | -Xi ; Xi | Xr] per frequency: Ap [NB][2][B][2 Kh] fp32, kept for the tensor it was made from."""
+        B, T, Cin = a.shape
+        key = (a._version, tuple(a.shape), KW, _hip.stream_id())
+        if cls.x_src is a and cls.x_key == key:
+            return cls.x_hat
+        c = cls.const(T, KW, a.device)
+        P, NB, Kh = cls.geometry(T, KW, Cin)
+        Ap = cls._buf('Ap', (B, T, Cin, KW), NB * 2 * B * 2 * Kh, a.device)                        # pad columns stay zero
+        lib = _hip.lib()
+        npb = lib.ptts_dense_planes_bytes(Cin, T)
+        xpl = torch.empty(B * npb, dtype=torch.uint8, device=a.device)
+        descs = (_hip.DenseSplitDesc * B)()
+        for b, d in enumerate(descs):
+            d.w, d.planes, d.ldw, d.K, d.N, d.transposed = a.data_ptr() + b * T * Cin * 4, xpl.data_ptr() + b * npb, Cin, T, Cin, 0
+        call('ptts_split3_dense_weight_grouped', ctypes.cast(descs, ctypes.c_void_p), B, stream(), tag=('x', B))
+        call('ptts_dense_bf16x6_batched', ptr(c['D']), 0, ptr(xpl), npb, None, ptr(Ap), 2 * Kh, B, c['R'], Cin, T, T, B * 2 * Kh, 3, stream(),
+             tag=('dft', B, c['R'], Cin, T))
+        call('ptts_dft_mirror', ptr(Ap), NB, B, Cin, Kh, stream())
+        cls.x_src, cls.x_key, cls.x_hat = a, key, Ap
+        return Ap
+
+    @classmethod
+    def kernel(cls, w, T):
+        """Planes of [Wr ; Wi]_f [2 Kh x N] for all frequencies, rebuilt when the kernel changes."""
+        KW, Cin, N = w.shape
+        flat = getattr(w, '_ptts_flat', None)
+        epoch = None if flat is None else flat.epoch
+        sid = _hip.stream_id()
+        ent = cls.w_hat.get((id(w), sid))
+        if ent is not None and ent[0] is w and ent[1] == w._version and ent[2] == epoch and flat is not None and ent[5][0] == T:
+            return ent[4]
+        c = cls.const(T, KW, w.device)
+        P, NB, Kh = cls.geometry(T, KW, Cin)
+        lib = _hip.lib()
+        npb = lib.ptts_dense_planes_bytes(N, 2 * Kh)
+        if ent is not None and ent[0] is w and ent[5] == (T, NB, Kh):
+            planes = ent[4]
+        else:
+            planes = torch.empty(NB * npb, dtype=torch.uint8, device=w.device)
+        if KW in cls.KWS:
+            call('ptts_conv1d_freq_kernel_planes', ptr(w), ptr(c['Tw']), ptr(planes), NB, KW, Cin, N, Kh, stream(), tag=(NB, KW, Cin, N))
+        else:
+            # any other odd kernel size: the twiddle product as a GEMM (pad rows zero), then one grouped split
+            What = torch.zeros(c['R'] * Kh * N, dtype=torch.float32, device=w.device)
+            gemm_raw(c['Tw'], w.view(KW, Cin * N), What, c['R'], Cin * N, KW, lda=KW, ldb=Cin * N, ldc=Kh * N)
+            descs = (_hip.DenseSplitDesc * NB)()
+            for f, d in enumerate(descs):
+                d.w, d.planes, d.ldw, d.K, d.N, d.transposed = What.data_ptr() + f * 2 * Kh * N * 4, planes.data_ptr() + f * npb, N, 2 * Kh, N, 0
+            call('ptts_split3_dense_weight_grouped', ctypes.cast(descs, ctypes.c_void_p), NB, stream(), tag=('w', NB))
+        cls.w_hat[(id(w), sid)] = (w, w._version, epoch, None, planes, (T, NB, Kh))
+        return planes
+
+    @classmethod
+    def forward(cls, a, w, b, y):
+        B, T, Cin = a.shape
+        KW, _, N = w.shape
+        c = cls.const(T, KW, a.device)
+        P, NB, Kh = cls.geometry(T, KW, Cin)
+        lib = _hip.lib()
+        Ap = cls.x_transform(a, KW)
+        wpl = cls.kernel(w, T)
+        npw = lib.ptts_dense_planes_bytes(N, 2 * Kh)
+        Yh = torch.empty(NB * 2 * B * N, dtype=torch.float32, device=a.device)                       # [NB][2][B][N]
+        call('ptts_dense_bf16x6_batched', ptr(Ap), 2 * B * 2 * Kh, ptr(wpl), npw, None, ptr(Yh), 2 * B * N, NB, 2 * B, N, 2 * Kh,
+             2 * Kh, N, 3, stream(), tag=('freq', NB, 2 * B, N, 2 * Kh))
+        npy = lib.ptts_dense_planes_bytes(N, c['R'])
+        ypl = torch.empty(B * npy, dtype=torch.uint8, device=a.device)
+        descs = (_hip.DenseSplitDesc * B)()
+        for bb, d in enumerate(descs):
+            d.w, d.planes, d.ldw, d.K, d.N, d.transposed = Yh.data_ptr() + bb * N * 4, ypl.data_ptr() + bb * npy, B * N, c['R'], N, 0
+        call('ptts_split3_dense_weight_grouped', ctypes.cast(descs, ctypes.c_void_p), B, stream(), tag=('y', B))
+        call('ptts_dense_bf16x6_batched', ptr(c['E']), 0, ptr(ypl), npy, ptr(b), ptr(y), T * N, B, T, N, c['Rp'], c['Rp'], N, 3, stream(),
+             tag=('idft', B, T, N, c['Rp']))
+
+    @classmethod
+    def clear(cls):
+        cls.x_src = cls.x_key = cls.x_hat = None
+        cls.w_hat = {k: (e[0], None, None, e[3], e[4], e[5]) for k, e in cls.w_hat.items()}
+
+
+def conv1d_fft(on):
+    """Context Conv1D forward in the frequency domain (see _C1FFT): True / False, None = the default (PTTS_CONV1D_FFT)."""
+    _C1FFT.enabled = _C1FFT.default if on is None else bool(on)
+    _C1FFT.clear()
 
 
 def conv1d_split(on):
@@ -1256,7 +1418,10 @@ class Conv1dFn(torch.autograd.Function):
             saved, padded, y = pre
         else:
             y = torch.empty((B, T, N), dtype=torch.float32, device=a.device)
-            if _C1Split.enabled and not _Flags.deterministic and _C1Split.eligible(a, w):
+            if _C1FFT.enabled and _C1Split.enabled and not _Flags.bf16_products and _C1FFT.eligible(a, w):
+                _C1FFT.forward(a, w, b, y)
+                saved, padded = a, False
+            elif _C1Split.enabled and not _Flags.deterministic and _C1Split.eligible(a, w):
                 xp, Cp = _C1Split.frames(a, pl, KW - 1 - pl)
                 wp = _C1Split.kernel(w)
                 call('ptts_conv1d_bf16x6', ptr(xp[0]), ptr(xp[1]), ptr(xp[2]), ptr(wp[0]), ptr(wp[1]), ptr(wp[2]), ptr(b), ptr(y),

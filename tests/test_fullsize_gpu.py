@@ -136,12 +136,23 @@ def test_dense_split_products_full_size():
     close(db, dY.double().cpu().sum(0), 2e-4, 2e-3, 'dense db, full size')
 
 
-def test_context_conv1d_split_products_full_size():
-    """The DEFAULT context Conv1D at BASELINE size (csrc/split.hip: M = 25 600 frames, K = 21 x 601, N = 256; ops.conv1d on a
-    weight of a flat parameter buffer selects the bf16x6 split kernels) with direct oracle contact: the forward on frames at
-    utterance borders, at the 128-frame tile borders and at the stream-K segment borders (every output column), and the
-    frame-major weight gradient wgrad_bf16x6_kernel<21> -- rows of dW over all 25 600 frames -- plus the bias gradient,
-    against fp64 products of the fp32 operands.  Reference: networktts.py:116-120 (kl.Conv1D)."""
+@pytest.mark.parametrize('fwd', ['frequency', 'time'])
+def test_context_conv1d_split_products_full_size(fwd):
+    """The context Conv1D at BASELINE size (M = 25 600 frames, K = 21 x 601, N = 256; ops.conv1d on a weight of a flat parameter
+    buffer) with direct oracle contact, for both forward paths: 'frequency' = the default since round 3 (ops._C1FFT: DFT, per-frequency
+    products, inverse DFT as batched bf16x6 split products), 'time' = the bf16x6 split kernel of csrc/split.hip (conv1d_fft(False)).
+    The forward on frames at utterance borders, at the 128-frame tile borders and at the stream-K segment borders (every output
+    column), and the frame-major weight gradient wgrad_bf16x6_kernel<21> -- rows of dW over all 25 600 frames -- plus the bias
+    gradient, against fp64 products of the fp32 operands.  Reference: networktts.py:116-120 (kl.Conv1D)."""
+    from percivaltts_amd import ops, layers, _hip
+    ops.conv1d_fft(fwd == 'frequency')
+    try:
+        _conv1d_full_size(fwd)
+    finally:
+        ops.conv1d_fft(None)
+
+
+def _conv1d_full_size(fwd):
     from percivaltts_amd import ops, layers, _hip
     g = torch.Generator().manual_seed(31)
     KW, N = 21, 256
@@ -156,7 +167,10 @@ def test_context_conv1d_split_products_full_size():
     with _hip.KernelTimer() as kt:
         y = ops.conv1d(x, w, b)
     names = [r[0] for r in kt.records]
-    assert 'ptts_conv1d_bf16x6' in names and 'ptts_gemm' not in names, names
+    if fwd == 'time':
+        assert 'ptts_conv1d_bf16x6' in names and 'ptts_gemm' not in names, names
+    else:
+        assert names.count('ptts_dense_bf16x6_batched') == 3 and 'ptts_conv1d_bf16x6' not in names, names
     w64 = w.detach().double().cpu().reshape(KW * CTX, N); b64 = b.detach().double().cpu()
     xp = torch.zeros(B, T + KW - 1, CTX, dtype=torch.float64)
     xp[:, KW // 2:KW // 2 + T] = x.double().cpu()
@@ -341,8 +355,9 @@ def test_generator_step_reuses_the_context_conv_of_the_critic_step(setup):
         with _hip.KernelTimer() as kt:
             opt.device_step(0, X, Y)               # batchid 0: critic step + generator step
         torch.cuda.synchronize()
-        nconv = sum(1 for (name, tag, _) in kt.durations_ms()      # context-Conv1D forward products (either kernel)
-                    if (name == 'ptts_gemm' and tag[5] == 1 and tag[3] == 0) or name == 'ptts_conv1d_bf16x6')
+        nconv = sum(1 for (name, tag, _) in kt.durations_ms()      # context-Conv1D forward products (any of the three forms)
+                    if (name == 'ptts_gemm' and tag[5] == 1 and tag[3] == 0) or name == 'ptts_conv1d_bf16x6' or
+                    (name == 'ptts_dense_bf16x6_batched' and tag[0] == 'freq'))
         results.append((opt.gen_opti.flat.grad.detach().clone(), opt.critic_opti.flat.grad.detach().clone(), nconv))
     opt.cfg.train_wgan_reuse_ctx_conv = True
     restore(snap)
@@ -355,9 +370,10 @@ def test_generator_step_reuses_the_context_conv_of_the_critic_step(setup):
 
 
 def test_train_step_with_the_bf16x6_context_conv_matches_the_fp32_one(setup):
-    """device_step at BASELINE configs[1] sizes with the context-Conv1D forward as a bf16x6 split product
-    (cfg.train_wgan_split_bf16, csrc/split.hip) against the same step on the fp32 MFMA kernel: same losses, and gradients
-    within the run-to-run spread of the fp32 path itself (fp32 atomics: ~1e-4 relative L2)."""
+    """device_step at BASELINE configs[1] sizes with the context-Conv1D forward as a bf16x6 split product in the time domain
+    (cfg.train_wgan_split_bf16, csrc/split.hip) and in the frequency domain (ops._C1FFT, the default) against the same step on
+    the fp32 MFMA kernel: same losses, and gradients within the run-to-run spread of the fp32 path itself (fp32 atomics: ~1e-4
+    relative L2)."""
     from percivaltts_amd import ops, _hip
     cfg, opt, crit, X, Y = setup
     state = (opt.critic_opti.flat.flat, opt.critic_opti.m, opt.critic_opti.v, opt.critic_opti.step_count,
@@ -367,7 +383,8 @@ def test_train_step_with_the_bf16x6_context_conv_matches_the_fp32_one(setup):
     moving0 = [t.detach().clone() for t in moving]
     results = []
     try:
-        for split in (True, False):
+        for split, fft in ((True, False), (False, False), (True, True)):
+            ops.conv1d_fft(fft)
             for dst, src in zip(state, snap):
                 dst.copy_(src)
             for dst, src in zip(moving, moving0):
@@ -380,20 +397,24 @@ def test_train_step_with_the_bf16x6_context_conv_matches_the_fp32_one(setup):
             torch.cuda.synchronize()
             names = [r[0] for r in kt.records]
             results.append((float(lc), float(lg), opt.critic_opti.flat.grad.detach().clone(),
-                            opt.gen_opti.flat.grad.detach().clone(), names.count('ptts_conv1d_bf16x6')))
+                            opt.gen_opti.flat.grad.detach().clone(), names.count('ptts_conv1d_bf16x6'),
+                            sum(1 for r in kt.records if r[0] == 'ptts_dense_bf16x6_batched' and r[1] and r[1][0] == 'freq')))
     finally:
         opt.cfg.train_wgan_split_bf16 = None
         ops.conv1d_split(None)
+        ops.conv1d_fft(None)
         for dst, src in zip(state, snap):
             dst.copy_(src)
         for dst, src in zip(moving, moving0):
             dst.copy_(src)
         opt.critic_opti.flat.epoch += 1; opt.gen_opti.flat.epoch += 1
-    (lc1, lg1, gc1, gg1, n1), (lc0, lg0, gc0, gg0, n0) = results
-    assert n1 == 3 and n0 == 0, (n1, n0)       # G and D context convs in the critic step, D's again in the generator step
-    assert abs(lc1 - lc0) <= 1e-4 * max(1.0, abs(lc0)) and abs(lg1 - lg0) <= 1e-4 * max(1.0, abs(lg0)), (lc1, lc0, lg1, lg0)
-    assert rel_l2(gc1, gc0) < 3e-4, rel_l2(gc1, gc0)
-    assert rel_l2(gg1, gg0) < 1e-3, rel_l2(gg1, gg0)
+    (lc1, lg1, gc1, gg1, n1, f1), (lc0, lg0, gc0, gg0, n0, f0), (lc2, lg2, gc2, gg2, n2, f2) = results
+    assert n1 == 3 and n0 == 0 and f1 == 0 and f0 == 0, (n1, n0, f1, f0)       # G and D context convs in the critic step, D's again in the generator step
+    assert n2 == 0 and f2 == 3, (n2, f2)         # ... the same three in the frequency domain (the default, round 3)
+    for (lc, lg, gc, gg, what) in ((lc1, lg1, gc1, gg1, 'time-domain split'), (lc2, lg2, gc2, gg2, 'frequency domain')):
+        assert abs(lc - lc0) <= 1e-4 * max(1.0, abs(lc0)) and abs(lg - lg0) <= 1e-4 * max(1.0, abs(lg0)), (what, lc, lc0, lg, lg0)
+        assert rel_l2(gc, gc0) < 3e-4, (what, rel_l2(gc, gc0))
+        assert rel_l2(gg, gg0) < 1e-3, (what, rel_l2(gg, gg0))
 
 
 def test_deterministic_mode_is_bit_reproducible_at_full_size(setup):

@@ -1178,3 +1178,42 @@ def test_dense_weight_gradient_deferred_two_stage_between_2048_and_4096_rows(ops
     e = float((net.w.grad.double().cpu() - dW).norm() / dW.norm())
     assert e < 3e-6, e
     close(net.b.grad, db, rtol=2e-5, atol=2e-4, what='db')
+
+
+@pytest.mark.parametrize('case', [(12, 400, 601, 256, 21), (16, 256, 70, 32, 5), (11, 400, 601, 256, 21), (9, 460, 128, 64, 9)])
+def test_conv1d_frequency_domain_forward(ops, case):
+    """ops._C1FFT (conv1d_fft(True)): the context Conv1D forward as DFT -> per-frequency products -> inverse DFT, each stage a batched
+    bf16x6 split product (ptts_dense_bf16x6_batched), P = T + KW - 1 (no power-of-two transform).  Against the fp64 oracle at the
+    tolerance of the time-domain kernels (fp32 arithmetic; the transforms' twiddles are exact to fp32 rounding), with bias, 'same'
+    padding at both utterance borders, a batch that is no multiple of anything, and the weight gradient through the usual path."""
+    B, T, Cin, N, KW = case
+    g = gen(77 + B)
+    x = torch.randn(B, T, Cin, generator=g, dtype=torch.float64)
+    w = torch.randn(KW, Cin, N, generator=g, dtype=torch.float64) / math.sqrt(KW * Cin)
+    b = torch.randn(N, generator=g, dtype=torch.float64)
+    yr = O.conv1d_ntc(x, w, b)
+    xd, wd, bd = dev(x), dev(w, True), dev(b, True)
+    ops.conv1d_fft(True); ops.conv1d_split(True)
+    try:
+        assert ops._C1FFT.eligible(xd, wd)
+        with ops._hip.KernelTimer() as kt:
+            yd = ops.conv1d(xd, wd, bd)
+        names = [n for n, _, _ in kt.durations_ms()]
+        assert names.count('ptts_dense_bf16x6_batched') == 3 and 'ptts_conv1d_bf16x6' not in names, names
+        scale = float(yr.abs().mean())
+        e = float((yd.double().cpu() - yr).abs().max()) / scale
+        assert e < 2e-5, 'frequency-domain conv1d: max error {:.3e} of mean |y|'.format(e)
+        # the same input again (the critic after the generator): the transform of x is reused
+        with ops._hip.KernelTimer() as kt2:
+            yd2 = ops.conv1d(xd, wd, bd)
+        names2 = [n for n, _, _ in kt2.durations_ms()]
+        assert names2.count('ptts_dense_bf16x6_batched') == 2 and 'ptts_dft_mirror' not in names2, names2
+        assert torch.equal(yd, yd2)
+        dy = torch.randn(B, T, N, generator=g, dtype=torch.float64)
+        yd.backward(dev(dy))
+        wr = ref(w, True)
+        O.conv1d_ntc(x, wr, b).backward(dy)
+        e = float((wd.grad.double().cpu() - wr.grad).norm() / wr.grad.norm())
+        assert e < 2e-5, e
+    finally:
+        ops.conv1d_fft(None); ops.conv1d_split(None)
