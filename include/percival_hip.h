@@ -249,6 +249,9 @@ typedef struct ptts_dense_split_desc {
     int K, N, transposed, reserved;
 } ptts_dense_split_desc;
 int ptts_split3_dense_weight_grouped(const ptts_dense_split_desc* descs, int n, void* stream);
+/* n weights of ONE shape at regular strides: w + i*stride_w (floats) -> planes + i*stride_planes_bytes. */
+int ptts_split3_dense_weight_strided(const float* w, long long stride_w, void* planes, long long stride_planes_bytes, int n,
+                                     long long ldw, int K, int N, int transposed, void* stream);
 int ptts_dense_bf16x6_supported(int M, int N, int K, long long lda, long long ldc);
 /* One weight-gradient product of ptts_gemm_wgrad_grouped (TF's MatMul gradient w.r.t. the kernel of a kl.Dense / LSTM
  * projection, plus the bias gradient) as a bf16x6 split product, in two stages without atomics between workgroups:
@@ -285,6 +288,19 @@ int ptts_dft_mirror(float* Ap, int NB, int B, int Cin, int Kh, void* stream);
  * frequency) of [Wr_f ; Wi_f] [2*Kh][N], W^_f = sum_k w[k] tw[(f,.)][k], for f < NB, from w [KW][Cin][N] (KW in 3, 5, 7, 9, 11, 21) and
  * the twiddle rows tw [2*NB][KW] (row 2f: cos, row 2f+1: -sin of 2 pi f (pl - k) / P).  Once per weight update. */
 int ptts_conv1d_freq_kernel_planes(const float* w, const float* tw, void* planes, int NB, int KW, int Cin, int N, int Kh, void* stream);
+
+/* dst[z][c][r] = src[z][r][c], nb matrices of rows x cols floats. */
+int ptts_transpose_batched(const float* src, float* dst, int nb, int rows, int cols, void* stream);
+/* Frequency-domain context Conv1D, weight gradient, last step: dW[k][c][n] = out2[k][n*2Kh + c] + out2[KW+k][n*2Kh + Kh + c], out2
+ * [2*KW][N*2*Kh] = the product of the inverse twiddles with the per-frequency correlations (TF's Conv1D kernel backprop). */
+int ptts_conv1d_freq_wgrad_combine(const float* out2, float* dW, int KW, int Cin, int N, int Kh, void* stream);
+
+/* ... or both steps in one pass over the correlations Gt [NB][N][2*Kh] (KW in 3, 5, 7, 9, 11, 21; t2 [NB][NBp], NBp >= 2*KW: row f =
+ * the KW cosine then the KW sine coefficients of frequency f): dW[k][c][n] = sum_f t2[f][k] Gt[f][n][c] + t2[f][KW+k] Gt[f][n][Kh+c]; the frequencies are shared out over four groups of workgroups
+ * whose partial sums (workspace) are added in a fixed order: no atomics. */
+size_t ptts_conv1d_freq_wgrad_inverse_workspace_bytes(int KW, int Cin, int N);
+int ptts_conv1d_freq_wgrad_inverse(const float* Gt, const float* t2, float* dW, void* workspace, size_t workspace_bytes,
+                                   int NB, int NBp, int KW, int Cin, int N, int Kh, void* stream);
 
 /* nbatch products of one shape in one launch: C_z[M,N] = A_z[M,K] . B_z (+ bias), A_z = A + z*strideA and C_z = C + z*strideC (floats;
  * strideA = 0 shares the left operand), B_z = the planes at planes + z*stride_planes_bytes (ptts_split3_dense_weight[_grouped] layout).

@@ -688,6 +688,27 @@ extern "C" int ptts_split3_dense_weight_grouped(const ptts_dense_split_desc* des
     return check_launch("split3_dense_weight_grouped");
 }
 
+// n weights of one shape at regular strides (w + i * stride_w floats -> planes + i * stride_planes_bytes): the operands of the
+// batched products, without a descriptor array on the host side
+extern "C" int ptts_split3_dense_weight_strided(const float* w, long long stride_w, void* planes, long long stride_planes_bytes, int n,
+                                                long long ldw, int K, int N, int transposed, void* stream) {
+    PTTS_REQUIRE(w && planes && n > 0, "split3_dense_weight_strided: nothing to split");
+    PTTS_REQUIRE(K > 0 && N > 0 && ldw >= (transposed ? K : N), "split3_dense_weight_strided: bad dims K=%d N=%d ldw=%lld", K, N, ldw);
+    const int NT = (N + NBLK - 1) / NBLK * (NBLK / 16), KS = (K + BK - 1) / BK;
+    const long long total = (long long)NT * KS * 64;
+    for (int base = 0; base < n; base += SPLIT_GROUP) {
+        SplitGroupArgs a;
+        const int m = n - base < SPLIT_GROUP ? n - base : SPLIT_GROUP;
+        for (int i = 0; i < m; ++i) {
+            a.w[i] = w + (long long)(base + i) * stride_w;
+            a.planes[i] = (u16*)((char*)planes + (long long)(base + i) * stride_planes_bytes);
+            a.ldw[i] = ldw; a.K[i] = K; a.N[i] = N; a.transposed[i] = transposed; a.NT[i] = NT; a.KS[i] = KS;
+        }
+        hipLaunchKernelGGL(split3_dense_weight_grouped_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)m), dim3(256), 0, (hipStream_t)stream, a);
+    }
+    return check_launch("split3_dense_weight_strided");
+}
+
 // 1 when ptts_dense_bf16x6 takes the shape
 extern "C" int ptts_dense_bf16x6_supported(int M, int N, int K, long long lda, long long ldc) {
     (void)ldc;                                    // any N / ldc: rows that are no multiple of 4 floats are stored element-wise

@@ -804,6 +804,166 @@ __global__ __launch_bounds__(256) void dft_mirror_kernel(float* __restrict__ Ap,
     }
 }
 
+// dst[z][c][r] = src[z][r][c] for nb matrices of rows x cols floats (32 x 32 tiles through the LDS, both sides coalesced)
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const long long zoff = (long long)blockIdx.z * rows * cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + 8 * i][tx] = src[zoff + (long long)r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (r < rows && c < cols) dst[zoff + (long long)c * rows + r] = tile[tx][ty + 8 * i];
+    }
+}
+
+extern "C" int ptts_transpose_batched(const float* src, float* dst, int nb, int rows, int cols, void* stream) {
+    PTTS_REQUIRE(src && dst && nb > 0 && nb <= 65535 && rows > 0 && cols > 0, "transpose_batched: bad arguments");
+    hipLaunchKernelGGL(transpose_batched_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, nb), dim3(256), 0, (hipStream_t)stream, src, dst, rows, cols);
+    return check_launch("transpose_batched");
+}
+
+// frequency-domain context Conv1D, weight gradient: dW[k][c][n] = out2[k][n 2Kh + c] + out2[KW + k][n 2Kh + Kh + c]
+// (out2 = the inverse-transform product over the frequencies, rows: cosine / sine coefficients of tap k)
+__global__ __launch_bounds__(256) void conv1d_freq_wgrad_combine_kernel(const float* __restrict__ out2, float* __restrict__ dW, int KW,
+                                                                       int Cin, int N, int Kh) {
+    // tile: 32 n x 32 c of one tap; reads contiguous along c, writes contiguous along n
+    __shared__ float tile[32][33];
+    const int k = blockIdx.z, c0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long long row = (long long)N * 2 * Kh;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + ty + 8 * i, c = c0 + tx;
+        if (n < N && c < Cin) {
+            const long long j = (long long)n * 2 * Kh + c;
+            tile[ty + 8 * i][tx] = out2[(long long)k * row + j] + out2[(long long)(KW + k) * row + j + Kh];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, n = n0 + tx;
+        if (n < N && c < Cin) dW[((long long)k * Cin + c) * N + n] = tile[tx][ty + 8 * i];
+    }
+}
+
+// The inverse transform of the per-frequency correlations and the combination above in ONE pass over Gt [NB][N][2 Kh]:
+//     dW[k][c][n] = sum_f  t2[k][f] Gt[f][n][c] + t2[KW + k][f] Gt[f][n][Kh + c]
+// A lane owns four consecutive c of one n and all KW taps (4 KW accumulators); per frequency two 16-byte loads, coalesced along c;
+// FU frequencies' loads are in flight together.  (As a GEMM with M = 2 KW = 42 rows the matrix kernels reached 1.2 TB/s on the
+// 263 MB of Gt: 223 us + 12 for the combination.)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int KW, int FU>
+__global__ __launch_bounds__(256) void conv1d_freq_wgrad_inverse_kernel(const float* __restrict__ Gt, const float* __restrict__ t2,
+                                                                       float* __restrict__ dW, int NB, int NBp, int Cin, int N, int Kh) {
+    // workgroup tile: 16 n x 16 quads of c (64 c); lanes along c for the loads (256-byte runs), along n for the stores (below)
+    __shared__ float tile[64][17];
+    const int q4 = Kh / 4, qt = (q4 + 15) / 16;
+    const int nt = blockIdx.x / qt, ct = blockIdx.x - nt * qt;
+    const int tn = threadIdx.x >> 4, tq = threadIdx.x & 15;
+    const int n = nt * 16 + tn, cq = ct * 16 + tq;
+    const bool live = n < N && cq < q4;
+    const int c = min(cq, q4 - 1) * 4;
+    const float* __restrict__ g0 = Gt + (long long)min(n, N - 1) * 2 * Kh + c;
+    const long long fs = (long long)N * 2 * Kh;
+    f32x4 acc[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the frequencies are shared out over gridDim.y workgroup rows (608 waves for all of them left three SIMDs in four idle);
+    // each writes its partial sums, wgrad_partials_sum_kernel adds them in a fixed order
+    const int per = (NB + gridDim.y - 1) / gridDim.y;
+    const int fbeg = blockIdx.y * per, fend = min(NB, fbeg + per);
+    dW += (long long)blockIdx.y * KW * Cin * N;
+    for (int f0 = fbeg; f0 < fend; f0 += FU) {
+        f32x4 gr[FU], gi[FU];
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int f = min(f0 + u, fend - 1);
+            gr[u] = *reinterpret_cast<const f32x4*>(g0 + f * fs);
+            gi[u] = *reinterpret_cast<const f32x4*>(g0 + f * fs + Kh);
+        }
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            if (f0 + u >= fend) break;                     // wave-uniform
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                // t2 [f][TP]: the 2 KW coefficients of a frequency lie together (uniform address: a few wide scalar loads per f)
+                const float tc = t2[(long long)(f0 + u) * NBp + k], ts = t2[(long long)(f0 + u) * NBp + KW + k];
+                acc[k] += gr[u] * tc + gi[u] * ts;
+            }
+        }
+    }
+    (void)live;
+    // dW[k][c][n]: through the LDS, so that a 16-lane group writes 16 consecutive n of one c (scattered 4-byte stores -- 4 KB apart
+    // from lane to lane -- cost 0.35 ms here)
+    const int wn = threadIdx.x & 15, wc = threadIdx.x >> 4;
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {          // (unrolled: a run-time index into acc would put it into scratch)
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[tq * 4 + e][tn] = acc[k][e];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cl = wc + 16 * i, cc = ct * 64 + cl, nn = nt * 16 + wn;
+            if (cc < Cin && nn < N) dW[((long long)k * Cin + cc) * N + nn] = tile[cl][wn];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_partials_sum_kernel(const float* __restrict__ part, float* __restrict__ out, long long n, int parts) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float s = part[i];
+        for (int p = 1; p < parts; ++p) s += part[(long long)p * n + i];
+        out[i] = s;
+    }
+}
+
+constexpr int WINV_SPLIT = 4;
+extern "C" size_t ptts_conv1d_freq_wgrad_inverse_workspace_bytes(int KW, int Cin, int N) {
+    return (size_t)WINV_SPLIT * KW * Cin * N * sizeof(float);
+}
+
+extern "C" int ptts_conv1d_freq_wgrad_inverse(const float* Gt, const float* t2, float* dW, void* workspace, size_t workspace_bytes,
+                                              int NB, int NBp, int KW, int Cin, int N, int Kh, void* stream) {
+    PTTS_REQUIRE(Gt && t2 && dW && NB > 0 && NBp >= 2 * KW && Cin > 0 && N > 0 && Kh >= Cin && Kh % 4 == 0, "conv1d_freq_wgrad_inverse: bad arguments");
+    PTTS_REQUIRE(((uintptr_t)Gt & 15) == 0, "conv1d_freq_wgrad_inverse: Gt must be 16-byte aligned");
+    const size_t need = ptts_conv1d_freq_wgrad_inverse_workspace_bytes(KW, Cin, N);
+    if (!workspace || workspace_bytes < need) { set_error("conv1d_freq_wgrad_inverse: workspace %zu < %zu", workspace_bytes, need); return PTTS_EWORKSPACE; }
+    const dim3 grid((unsigned)(((N + 15) / 16) * ((Kh / 4 + 15) / 16)), WINV_SPLIT);
+    float* part = (float*)workspace;
+#define WINV(KWv) hipLaunchKernelGGL((conv1d_freq_wgrad_inverse_kernel<KWv, 8>), grid, dim3(256), 0, (hipStream_t)stream, Gt, t2, part, NB, NBp, Cin, N, Kh)
+    switch (KW) {
+        case 3: WINV(3); break;
+        case 5: WINV(5); break;
+        case 7: WINV(7); break;
+        case 9: WINV(9); break;
+        case 11: WINV(11); break;
+        case 21: WINV(21); break;
+        default: set_error("conv1d_freq_wgrad_inverse: KW=%d not instantiated (3, 5, 7, 9, 11, 21)", KW); return PTTS_EINVAL;
+    }
+#undef WINV
+    const long long nw = (long long)KW * Cin * N;
+    long long blocks = (nw + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad_partials_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, part, dW, nw, WINV_SPLIT);
+    return check_launch("conv1d_freq_wgrad_inverse");
+}
+
+extern "C" int ptts_conv1d_freq_wgrad_combine(const float* out2, float* dW, int KW, int Cin, int N, int Kh, void* stream) {
+    PTTS_REQUIRE(out2 && dW && KW > 0 && Cin > 0 && N > 0 && Kh >= Cin, "conv1d_freq_wgrad_combine: bad arguments");
+    hipLaunchKernelGGL(conv1d_freq_wgrad_combine_kernel, dim3((Cin + 31) / 32, (N + 31) / 32, KW), dim3(256), 0, (hipStream_t)stream,
+                       out2, dW, KW, Cin, N, Kh);
+    return check_launch("conv1d_freq_wgrad_combine");
+}
+
 extern "C" int ptts_dft_mirror(float* Ap, int NB, int B, int Cin, int Kh, void* stream) {
     PTTS_REQUIRE(Ap && NB > 0 && B > 0 && Cin > 0 && Kh >= Cin, "dft_mirror: bad arguments");
     const long long total = (long long)NB * B * Cin;

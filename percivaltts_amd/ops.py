@@ -1251,6 +1251,7 @@ class _C1FFT(object):
     default = os.environ.get('PTTS_CONV1D_FFT', '1') == '1'
     enabled = default
     KWS = (3, 5, 7, 9, 11, 21)      # instantiations of conv1d_wdft_planes_kernel<KW>
+    wgrad_enabled = os.environ.get('PTTS_CONV1D_FFT_WGRAD', '1') == '1'
     consts = {}         # (T, KW, device, stream) -> dict of the twiddle operands
     x_src = None; x_key = None; x_hat = None
     w_hat = {}          # (id(w), stream) -> (w, version, epoch, W^ buffer, planes)
@@ -1279,6 +1280,16 @@ class _C1FFT(object):
         return t
 
     @classmethod
+    def _scratch(cls, name, nbytes, dev):
+        """A persistent byte buffer per (name, stream), grown on demand: the transforms' temporaries are hundreds of megabytes a
+        call and would otherwise churn the caching allocator.  Valid until the next call that asks for the same name."""
+        k = ('scratch', name, _hip.stream_id())
+        t = cls.bufs.get(k)
+        if t is None or t.numel() < nbytes:
+            t = cls.bufs[k] = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        return t
+
+    @classmethod
     def const(cls, T, KW, dev):
         key = (T, KW, dev.index, _hip.stream_id())
         c = cls.consts.get(key)
@@ -1302,7 +1313,16 @@ class _C1FFT(object):
         k = torch.arange(KW, dtype=torch.float64).view(1, KW)
         tk = 2.0 * math.pi * torch.remainder(f * (pl - k), P) / P
         Tw = torch.stack([torch.cos(tk), -torch.sin(tk)], dim=1).reshape(R, KW)                  # rows (f, part): Wr, Wi
-        c = {'P': P, 'NB': NB, 'R': R, 'Rp': Rp,
+        NBp = (NB + 3) // 4 * 4
+        T2 = torch.zeros(2 * KW, NBp, dtype=torch.float64)                                      # dW = sum_f T2[., f] (Gr | -Gi)_f
+        ph = 2.0 * math.pi * torch.remainder(f * (k - pl), P) / P                               # [NB, KW]
+        T2[:KW, :NB] = (torch.cos(ph) * cf.view(NB, 1) / P).t()
+        T2[KW:, :NB] = (torch.sin(ph) * cf.view(NB, 1) / P).t()
+        TP = (2 * KW + 15) // 16 * 16
+        T2f = torch.zeros(NB, TP, dtype=torch.float64)                                          # the same, frequency-major (the fused inverse kernel)
+        T2f[:, :2 * KW] = T2[:, :NB].t()
+        c = {'P': P, 'NB': NB, 'R': R, 'Rp': Rp, 'NBp': NBp, 'T2': T2.to(torch.float32).to(dev).contiguous(),
+             'TP': TP, 'T2f': T2f.to(torch.float32).to(dev).contiguous(),
              'D': D.to(torch.float32).to(dev).contiguous(), 'E': E.to(torch.float32).to(dev).contiguous(),
              'Tw': Tw.to(torch.float32).to(dev).contiguous()}
         cls.consts[key] = c
@@ -1320,11 +1340,8 @@ class _C1FFT(object):
         Ap = cls._buf('Ap', (B, T, Cin, KW), NB * 2 * B * 2 * Kh, a.device)                        # pad columns stay zero
         lib = _hip.lib()
         npb = lib.ptts_dense_planes_bytes(Cin, T)
-        xpl = torch.empty(B * npb, dtype=torch.uint8, device=a.device)
-        descs = (_hip.DenseSplitDesc * B)()
-        for b, d in enumerate(descs):
-            d.w, d.planes, d.ldw, d.K, d.N, d.transposed = a.data_ptr() + b * T * Cin * 4, xpl.data_ptr() + b * npb, Cin, T, Cin, 0
-        call('ptts_split3_dense_weight_grouped', ctypes.cast(descs, ctypes.c_void_p), B, stream(), tag=('x', B))
+        xpl = cls._scratch('xpl', B * npb, a.device)
+        call('ptts_split3_dense_weight_strided', ptr(a), T * Cin, ptr(xpl), npb, B, Cin, T, Cin, 0, stream(), tag=('x', B))
         call('ptts_dense_bf16x6_batched', ptr(c['D']), 0, ptr(xpl), npb, None, ptr(Ap), 2 * Kh, B, c['R'], Cin, T, T, B * 2 * Kh, 3, stream(),
              tag=('dft', B, c['R'], Cin, T))
         call('ptts_dft_mirror', ptr(Ap), NB, B, Cin, Kh, stream())
@@ -1355,10 +1372,7 @@ class _C1FFT(object):
             # any other odd kernel size: the twiddle product as a GEMM (pad rows zero), then one grouped split
             What = torch.zeros(c['R'] * Kh * N, dtype=torch.float32, device=w.device)
             gemm_raw(c['Tw'], w.view(KW, Cin * N), What, c['R'], Cin * N, KW, lda=KW, ldb=Cin * N, ldc=Kh * N)
-            descs = (_hip.DenseSplitDesc * NB)()
-            for f, d in enumerate(descs):
-                d.w, d.planes, d.ldw, d.K, d.N, d.transposed = What.data_ptr() + f * 2 * Kh * N * 4, planes.data_ptr() + f * npb, N, 2 * Kh, N, 0
-            call('ptts_split3_dense_weight_grouped', ctypes.cast(descs, ctypes.c_void_p), NB, stream(), tag=('w', NB))
+            call('ptts_split3_dense_weight_strided', ptr(What), 2 * Kh * N, ptr(planes), npb, NB, N, 2 * Kh, N, 0, stream(), tag=('w', NB))
         cls.w_hat[(id(w), sid)] = (w, w._version, epoch, None, planes, (T, NB, Kh))
         return planes
 
@@ -1372,21 +1386,68 @@ class _C1FFT(object):
         Ap = cls.x_transform(a, KW)
         wpl = cls.kernel(w, T)
         npw = lib.ptts_dense_planes_bytes(N, 2 * Kh)
-        Yh = torch.empty(NB * 2 * B * N, dtype=torch.float32, device=a.device)                       # [NB][2][B][N]
+        Yh = cls._scratch('Yh', NB * 2 * B * N * 4, a.device)                                        # [NB][2][B][N] fp32
         call('ptts_dense_bf16x6_batched', ptr(Ap), 2 * B * 2 * Kh, ptr(wpl), npw, None, ptr(Yh), 2 * B * N, NB, 2 * B, N, 2 * Kh,
              2 * Kh, N, 3, stream(), tag=('freq', NB, 2 * B, N, 2 * Kh))
         npy = lib.ptts_dense_planes_bytes(N, c['R'])
-        ypl = torch.empty(B * npy, dtype=torch.uint8, device=a.device)
-        descs = (_hip.DenseSplitDesc * B)()
-        for bb, d in enumerate(descs):
-            d.w, d.planes, d.ldw, d.K, d.N, d.transposed = Yh.data_ptr() + bb * N * 4, ypl.data_ptr() + bb * npy, B * N, c['R'], N, 0
-        call('ptts_split3_dense_weight_grouped', ctypes.cast(descs, ctypes.c_void_p), B, stream(), tag=('y', B))
+        ypl = cls._scratch('ypl', B * npy, a.device)
+        call('ptts_split3_dense_weight_strided', ptr(Yh), N, ptr(ypl), npy, B, B * N, c['R'], N, 0, stream(), tag=('y', B))
         call('ptts_dense_bf16x6_batched', ptr(c['E']), 0, ptr(ypl), npy, ptr(b), ptr(y), T * N, B, T, N, c['Rp'], c['Rp'], N, 3, stream(),
              tag=('idft', B, T, N, c['Rp']))
 
     @classmethod
+    def has_x(cls, a, KW):
+        return a is not None and cls.x_src is a and cls.x_key == (a._version, tuple(a.shape), KW, _hip.stream_id())
+
+    @classmethod
+    def wgrad(cls, a, dy, KW):
+        """dW [KW, Cin, N] of the layer from the transform of its input (kept from the forward) and of dy:
+            G_f [n][(h, c)] = DY'_f^T [N x 2B] . [Xr | -Xi ; Xi | Xr]_f [2B x 2 Kh]  =  (Gr | -Gi)_f^T      for every frequency
+            dW[k][c][n]     = sum_f  T2c[k][f] Gr_f[c][n] + T2s[k][f] (-Gi_f)[c][n]
+        (the correlation theorem: sum_t x[t + k - pl] dy[t] = (1/P) sum_f X_f conj(DY_f) e^{2 pi i f (k - pl) / P})."""
+        B, T, Cin = a.shape
+        N = dy.shape[-1]
+        c = cls.const(T, KW, a.device)
+        P, NB, Kh = cls.geometry(T, KW, Cin)
+        lib = _hip.lib()
+        dev = a.device
+        Ap = cls.x_hat
+        # planes of [Xr | -Xi ; Xi | Xr]_f as the right operand [K = 2B][N' = 2 Kh]: once per input
+        if cls.xw_src is not a or cls.xw_key != cls.x_key or cls.xw_planes is None:
+            npx = lib.ptts_dense_planes_bytes(2 * Kh, 2 * B)
+            xw = cls._scratch('xw', NB * npx, dev)
+            call('ptts_split3_dense_weight_strided', ptr(Ap), 2 * B * 2 * Kh, ptr(xw), npx, NB, 2 * Kh, 2 * B, 2 * Kh, 0, stream(), tag=('xw', NB))
+            cls.xw_src, cls.xw_key, cls.xw_planes = a, cls.x_key, xw
+        npx = lib.ptts_dense_planes_bytes(2 * Kh, 2 * B)
+        # DY' = DFT_t(dy): [NB][2][B][N]
+        npd = lib.ptts_dense_planes_bytes(N, T)
+        dpl = cls._scratch('dpl', B * npd, dev)
+        call('ptts_split3_dense_weight_strided', ptr(dy), T * N, ptr(dpl), npd, B, N, T, N, 0, stream(), tag=('dy', B))
+        DYh = cls._scratch('DYh', NB * 2 * B * N * 4, dev)
+        call('ptts_dense_bf16x6_batched', ptr(c['D']), 0, ptr(dpl), npd, None, ptr(DYh), N, B, c['R'], N, T, T, B * N, 3, stream(),
+             tag=('dft_dy', B, c['R'], N, T))
+        DYt = cls._scratch('DYt', NB * N * 2 * B * 4, dev)                                         # [NB][N][2B] fp32
+        call('ptts_transpose_batched', ptr(DYh), ptr(DYt), NB, 2 * B, N, stream())
+        Gt = cls._scratch('Gt', NB * N * 2 * Kh * 4, dev)                                          # [NB][N][2 Kh] fp32 = (Gr | -Gi)^T
+        call('ptts_dense_bf16x6_batched', ptr(DYt), N * 2 * B, ptr(cls.xw_planes), npx, None, ptr(Gt), N * 2 * Kh, NB, N, 2 * Kh, 2 * B,
+             2 * B, 2 * Kh, 3, stream(), tag=('corr', NB, N, 2 * Kh, 2 * B))
+        dw = torch.empty((KW, Cin, N), dtype=torch.float32, device=dev)
+        if KW in cls.KWS:
+            ws = _workspace(lib.ptts_conv1d_freq_wgrad_inverse_workspace_bytes(KW, Cin, N), dev)
+            call('ptts_conv1d_freq_wgrad_inverse', ptr(Gt), ptr(c['T2f']), ptr(dw), ptr(ws), ws.numel(), NB, c['TP'], KW, Cin, N, Kh, stream(),
+                 tag=(NB, KW, Cin, N))
+        else:
+            out2 = torch.empty(2 * KW * N * 2 * Kh, dtype=torch.float32, device=dev)
+            gemm_raw(c['T2'], Gt, out2, 2 * KW, N * 2 * Kh, NB, lda=c['NBp'], ldb=N * 2 * Kh, ldc=N * 2 * Kh)
+            call('ptts_conv1d_freq_wgrad_combine', ptr(out2), ptr(dw), KW, Cin, N, Kh, stream())
+        return dw
+
+    xw_src = None; xw_key = None; xw_planes = None
+
+    @classmethod
     def clear(cls):
         cls.x_src = cls.x_key = cls.x_hat = None
+        cls.xw_src = cls.xw_key = cls.xw_planes = None
         cls.w_hat = {k: (e[0], None, None, e[3], e[4], e[5]) for k, e in cls.w_hat.items()}
 
 
@@ -1452,7 +1513,11 @@ class Conv1dFn(torch.autograd.Function):
         def padded_frames():
             return saved if ctx.padded else _pad_time(saved, pl, KW - 1 - pl)
 
-        if want_w and _C1Split.enabled and not _Flags.deterministic and dy.is_cuda and _C1Split.eligible_wgrad(KW, N):
+        if want_w and _C1FFT.enabled and _C1FFT.wgrad_enabled and _C1Split.enabled and not _Flags.bf16_products and dy.is_cuda and \
+                _C1FFT.has_x(ctx.x_src, KW) and not ctx.padded and B % 2 == 0:      # (2B is a reduction length: a multiple of 4)
+            # in the frequency domain, from the transform of the input the forward left behind (ops._C1FFT.wgrad)
+            dw = _C1FFT.wgrad(ctx.x_src, dy, KW)
+        elif want_w and _C1Split.enabled and not _Flags.deterministic and dy.is_cuda and _C1Split.eligible_wgrad(KW, N):
             # the weight gradient as a bf16x6 split product over frame-major planes (csrc/split.hip)
             xt, Crows, Pp = _C1Split.frames_t(ctx.x_src, saved, ctx.padded, B, T, Cin, KW)
             yt, _ = _C1Split.transposed(dy, B, T, N, 0, T + KW - 1, Pp)

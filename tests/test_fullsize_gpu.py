@@ -187,7 +187,7 @@ def _conv1d_full_size(fwd):
     with _hip.KernelTimer() as kt:
         y.backward(dy)
     names = [r[0] for r in kt.records]
-    assert 'ptts_conv1d_wgrad_bf16x6' in names, names
+    assert ('ptts_conv1d_wgrad_bf16x6' if fwd == 'time' else 'ptts_conv1d_freq_wgrad_inverse') in names, names
     dy64 = dy.double().cpu().reshape(B * T, N)
     gw = w.grad.detach().double().cpu()
     gscale = float(gw.abs().mean())

@@ -1185,7 +1185,8 @@ def test_conv1d_frequency_domain_forward(ops, case):
     """ops._C1FFT (conv1d_fft(True)): the context Conv1D forward as DFT -> per-frequency products -> inverse DFT, each stage a batched
     bf16x6 split product (ptts_dense_bf16x6_batched), P = T + KW - 1 (no power-of-two transform).  Against the fp64 oracle at the
     tolerance of the time-domain kernels (fp32 arithmetic; the transforms' twiddles are exact to fp32 rounding), with bias, 'same'
-    padding at both utterance borders, a batch that is no multiple of anything, and the weight gradient through the usual path."""
+    padding at both utterance borders, a batch that is no multiple of anything; the weight gradient by the correlation theorem from
+    the same transforms (ops._C1FFT.wgrad) and the bias gradient, against the fp64 oracle as well."""
     B, T, Cin, N, KW = case
     g = gen(77 + B)
     x = torch.randn(B, T, Cin, generator=g, dtype=torch.float64)
@@ -1210,7 +1211,11 @@ def test_conv1d_frequency_domain_forward(ops, case):
         assert names2.count('ptts_dense_bf16x6_batched') == 2 and 'ptts_dft_mirror' not in names2, names2
         assert torch.equal(yd, yd2)
         dy = torch.randn(B, T, N, generator=g, dtype=torch.float64)
-        yd.backward(dev(dy))
+        with ops._hip.KernelTimer() as kt3:
+            yd.backward(dev(dy))
+        # the correlation theorem: dW from X^ and DY^ (an odd batch -- 2B no multiple of 4 -- takes the time-domain kernel)
+        assert ('ptts_conv1d_freq_wgrad_inverse' in [n for n, _, _ in kt3.durations_ms()]) == (B % 2 == 0)
+        close(bd.grad, dy.sum((0, 1)), rtol=2e-5, atol=2e-4, what='db')
         wr = ref(w, True)
         O.conv1d_ntc(x, wr, b).backward(dy)
         e = float((wd.grad.double().cpu() - wr.grad).norm() / wr.grad.norm())

@@ -1,0 +1,8 @@
+LEGS="--no-variants --no-unreduced --no-host-leg --no-reference-shape --no-bf16-leg --no-gated-leg --no-cpu-baseline"
+for i in 1 2 3; do
+python3 bench.py $LEGS --steps 60 --warmup 15 2>/dev/null | python3 -c "
+import json,sys
+j=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('value %.3f M ms/step %.3f critic %.3f gen %.3f' % (j['value']/1e6, j['ms_per_step'], j['critic_step_ms'], j['generator_step_ms']), j['cycle_ms'], j['config']['hipgraph']['critic'], j['config']['hipgraph'].get('tuning_ms'))
+"
+done

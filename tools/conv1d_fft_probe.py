@@ -61,3 +61,16 @@ ref = torch.stack([sum(xp[t + k] @ ws[k] for k in range(KW)) for t in range(50)]
 sc = float(ref.abs().mean())
 print('max error / mean|y|: time domain %.3e   frequency domain %.3e' % (float((y0[3, 150:200].double().cpu() - ref).abs().max()) / sc,
                                                                          float((y1[3, 150:200].double().cpu() - ref).abs().max()) / sc))
+
+# weight gradient: frequency domain against the frame-major time-domain kernel
+dy = torch.randn(B, T, N, generator=g).cuda()
+for wg in (False, True):
+    ops._C1FFT.wgrad_enabled = wg
+    ops.conv1d_fft(True)
+    for rep in range(3):
+        net.w.grad = None; flat.zero_grad()
+        y = ops.conv1d(x, net.w, net.b)
+        with _hip.KernelTimer() as kt:
+            y.backward(dy)
+        d = kt.durations_ms()
+    print('wgrad freq=%d: %.3f ms  ' % (wg, sum(t for _, _, t in d)) + ' '.join('%s %.0f' % (n.replace('ptts_', ''), t * 1e3) for n, _, t in d))
