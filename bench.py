@@ -8,7 +8,10 @@ Workload at N=1 is BASELINE.json configs[1]: [64,400,601] -> [64,400,86] (f0 1 +
 64-sample shard (weak scaling, global batch 64*N) and the flat gradients are all-reduced over RCCL.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline       dominant kernel (the context Conv1D as a bf16x6 split product on the bf16 matrix cores: gemm_bf16x6_kernel), HIP-event timed here
+  roofline       dominant kernel of the critic step, HIP-event timed here: since round 3 the 4 -> 4 Conv2D layer kernel (c2m::fwd_kernel, HBM
+                 roofline, per launch; --dtype bf16: the fused conv2d_chain kernels) -- the context Conv1D went to the frequency domain
+  roofline_conv1d the context Conv1D's big product against the matrix-core peak (frequency domain: batched dense_bf16x6_kernel; time domain:
+                 gemm_bf16x6_kernel / gemm_bf16x1_kernel)
   roofline_conv2d the critic's 2D-conv stack against the HBM roofline, algorithmic bytes of SURVEY.md 8(d)
   cpu_baseline   the CPU oracle (PyTorch-CPU fp32 restatement of the reference path) on a bounded sample
 """
@@ -177,7 +180,7 @@ def roofline_leg(opt, X, Y, args):
     if conv1d_fwd:
         t = sum(conv1d_fwd) / len(conv1d_fwd) * 1e-3
         fl = 2.0 * M * N * K
-        out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_dma_kernel<0, 1> (context Conv1D as implicit GEMM, M={} N={} K={})'.format(M, N, K),
+        out['roofline_conv1d'] = {'bound': 'mfma', 'kernel': 'gemm_dma_kernel<0, 1> (context Conv1D as implicit GEMM, M={} N={} K={})'.format(M, N, K),
                            'achieved': fl / t / 1e12, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                            'frac': fl / t / 1e12 / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
                            'launch_ms': t * 1e3, 'launches_per_critic_step': len(conv1d_fwd)}
@@ -188,11 +191,30 @@ def roofline_leg(opt, X, Y, args):
         fl = 2.0 * M * N * K
         one = bool(getattr(opt.cfg, 'train_wgan_bf16_products', False))
         peak = PEAK_BF16_MFMA_TFLOPS if one else PEAK_BF16_MFMA_TFLOPS / 6.0
-        out['roofline'] = {'bound': 'mfma', 'kernel': ('gemm_bf16x1_kernel (context Conv1D, M={} N={} K={}; bf16 products of the operands\' bf16 roundings, fp32 accumulation)' if one else
+        out['roofline_conv1d'] = {'bound': 'mfma', 'kernel': ('gemm_bf16x1_kernel (context Conv1D, M={} N={} K={}; bf16 products of the operands\' bf16 roundings, fp32 accumulation)' if one else
                                                        'gemm_bf16x6_kernel (context Conv1D, M={} N={} K={}; algorithmic fp32 flop, 6 bf16 MFMA products each)').format(M, N, K),
                            'achieved': fl / t / 1e12, 'peak': peak, 'unit': 'TFLOP/s',
                            'frac': fl / t / 1e12 / peak, 'traffic': None,
                            'launch_ms': t * 1e3, 'launches_per_critic_step': len(conv1d_split)}
+    conv1d_freq = [(tag, d) for (nm, tag, d) in avg if nm == 'ptts_dense_bf16x6_batched' and tag and tag[0] == 'freq']
+    if conv1d_freq:
+        # the context Conv1D in the frequency domain (ops._C1FFT): its big product, NB per-frequency GEMMs [2B x 2Kh] . [2Kh x N].
+        # flops = what THIS formulation executes (the time-domain product it replaces has 2 M N K = 8-10 x more)
+        (_, nb, m2, n2, k2), _ = conv1d_freq[0]
+        t = sum(d for _, d in conv1d_freq) / len(conv1d_freq) * 1e-3
+        fl = 2.0 * nb * m2 * n2 * k2
+        per_conv = {}
+        for nm, tag, d in avg:
+            if nm in ('ptts_dense_bf16x6_batched', 'ptts_split3_dense_weight_strided', 'ptts_dft_mirror', 'ptts_conv1d_freq_kernel_planes',
+                      'ptts_transpose_batched', 'ptts_conv1d_freq_wgrad_inverse'):
+                k = nm.replace('ptts_', '') + ('.' + str(tag[0]) if tag and isinstance(tag[0], str) else '')
+                per_conv[k] = round(per_conv.get(k, 0.0) + d, 4)
+        out['roofline_conv1d'] = {'bound': 'mfma', 'kernel': 'dns::dense_bf16x6_kernel, batched over {} frequencies (context Conv1D in the frequency domain: per-frequency product '
+                                  '[{} x {}] . [{} x {}], fp32 as 6 bf16 MFMA products)'.format(nb, m2, k2, k2, n2),
+                                  'achieved': fl / t / 1e12, 'peak': PEAK_BF16_MFMA_TFLOPS / 6.0, 'unit': 'TFLOP/s', 'frac': fl / t / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 6.0),
+                                  'traffic': None, 'launch_ms': t * 1e3, 'launches_per_critic_step': len(conv1d_freq),
+                                  'flop_per_launch': fl, 'time_domain_flop_per_launch': 2.0 * M * N * K,
+                                  'all_stages_ms_per_critic_step': per_conv}
     if conv1d_bww:
         t = sum(conv1d_bww) / len(conv1d_bww) * 1e-3
         out['conv1d_bwd_weight'] = {'achieved': 2.0 * M * N * K / t / 1e12, 'unit': 'TFLOP/s', 'launch_ms': t * 1e3}
@@ -223,6 +245,25 @@ def roofline_leg(opt, X, Y, args):
                                             'bf16 between the 4->4 layers (6 of 8 maps and their gradients), fp32 at both ends of the stack') if bf16_stack else 'fp32'),
                                   'launches': sorted(set(nm for (nm, _, _) in crit_recs[-1] if nm.startswith('ptts_conv2d')))}
     out['critic_step_kernel_ms'] = {k: round(v, 4) for k, v in sorted(classes.items(), key=lambda kv: -kv[1])}
+    # ---- `roofline`: the dominant kernel of the critic step.  fp32: the 4 -> 4 Conv2D layers on the matrix cores (c2m::fwd_kernel: forward,
+    # masked forward, backward-data), per launch (2 or 3 maps of 16 bytes per time-frequency bin) against the HBM roofline; bf16: the
+    # fused stack (the roofline_conv2d figures: four launches).  Before round 3's frequency-domain Conv1D the context Conv1D was.
+    c2m = [(tag, d) for (nm, tag, d) in crit_recs[-1] if nm == 'ptts_conv2d_mfma_fwd']
+    if bf16_stack is True and 'roofline_conv2d' in out:
+        out['roofline'] = dict(out['roofline_conv2d'])
+        out['roofline']['kernel'] = 'c2c::chain_fwd / chain_bwd / chain_second kernels (critic Conv2D stack, 8 layers per launch, bf16 maps): all launches of a critic step'
+    elif c2m:
+        by = 0.0
+        for tag, d in c2m:
+            Bq, Tq, Fq, _, _, mode, has_om, planes = tag
+            by += Bq * Tq * Fq * 4 * 4.0 * (2 + (1 if (mode == 2 or has_om) else 0))
+        tt = sum(sum(d for (nm, _, d) in r if nm == 'ptts_conv2d_mfma_fwd') for r in crit_recs) / reps * 1e-3
+        out['roofline'] = {'bound': 'hbm', 'kernel': 'c2m::fwd_kernel (4 -> 4 Conv2D 5x5 layer on the matrix cores: forward, masked forward, backward-data; fp32 maps, fp32 arithmetic as 6 bf16 products), '
+                           '{} launches per critic step'.format(len(c2m)),
+                           'achieved': by / tt / 1e9, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': by / tt / 1e9 / PEAK_HBM_GBPS, 'traffic': None,
+                           'algorithmic_bytes_per_launch': by / len(c2m), 'launch_ms': tt / len(c2m) * 1e3, 'launches_per_critic_step': len(c2m)}
+    elif 'roofline_conv1d' in out:
+        out['roofline'] = dict(out['roofline_conv1d'])
     # HBM(+Infinity-Cache) bytes per launch from the separate rocprofv3 PMC passes of the same kernels
     # (tools/profile_round.sh -> tools/summarize_profiles.py -> profiles/<round>_traffic.json; FETCH_SIZE x2 + WRITE_SIZE)
     try:
@@ -233,13 +274,16 @@ def roofline_leg(opt, X, Y, args):
             if conv1d_split:
                 kname = 'gemm_bf16x1_kernel' if bool(getattr(opt.cfg, 'train_wgan_bf16_products', False)) else 'gemm_bf16x6_kernel'
                 key = kname if kname in tr else None
-            if 'roofline' in out and key:
-                out['roofline']['traffic'] = tr[key]['hbm_bytes_per_launch']
-                out['roofline']['traffic_source'] = 'profiles/' + cands[-1]
+            if 'roofline_conv1d' in out and key and (conv1d_split or conv1d_fwd) and not conv1d_freq:
+                out['roofline_conv1d']['traffic'] = tr[key]['hbm_bytes_per_launch']
+                out['roofline_conv1d']['traffic_source'] = 'profiles/' + cands[-1]
             ck = next((k for k in tr if k.startswith('c2m::fwd_kernel<1, 1, false')), None) or next((k for k in tr if k.startswith('conv2d_fwd_kernel<4, 4')), None)
             if 'roofline_conv2d' in out and ck and not bf16_stack:
                 out['roofline_conv2d']['traffic_fwd_4to4_per_launch'] = tr[ck]['hbm_bytes_per_launch']
                 out['roofline_conv2d']['traffic_kernel'] = ck
+                if 'roofline' in out and out['roofline'].get('bound') == 'hbm':
+                    out['roofline']['traffic'] = tr[ck]['hbm_bytes_per_launch']       # the forward variant of the kernel, [64,400,65,4] in and out
+                    out['roofline']['traffic_source'] = 'profiles/' + cands[-1] + ' (' + ck + ')'
     except (OSError, ValueError, KeyError):
         pass
     return out
@@ -494,7 +538,9 @@ def main():
                        'prune_dead_generator_branches_in_critic_step': bool(cfg.train_wgan_prune_dead_branches),
                        'stack_real_fake_critic_pass': bool(cfg.train_wgan_stack_real_fake),
                        'reuse_generator_ctx_conv_within_train_on_batch': bool(cfg.train_wgan_reuse_ctx_conv),
-                       'ctx_conv1d_forward_and_weight_gradient': 'bf16x6 split (bf16 MFMA, fp32 accumulate)' if cfg.train_wgan_split_bf16 else 'fp32 MFMA',
+                       'ctx_conv1d_forward_and_weight_gradient': (('frequency domain (DFT, per-frequency products, inverse DFT; correlation theorem for the weight gradient), every product a '
+                                                                   if (ops._C1FFT.enabled and not cfg.train_wgan_bf16_products) else '') + 'bf16x6 split (bf16 MFMA, fp32 accumulate)'
+                                                                  + (' -- ONE bf16 product (time domain)' if cfg.train_wgan_bf16_products else '')) if cfg.train_wgan_split_bf16 else 'fp32 MFMA',
                        'dense_products': ('forward / backward-data / weight gradients (>= {} frames, two stages): bf16x6 split (bf16 MFMA, fp32 accumulate); 1-wide heads: fp32'.format(2048)
                                           if (cfg.train_wgan_split_bf16 and ops._DenseSplit.enabled) else 'fp32 MFMA'),
                        'collective_backend': (__import__('torch').distributed.get_backend() if world > 1 else None),

@@ -808,7 +808,19 @@ extern "C" int ptts_dense_bf16x6_batched(const float* A, long long strideA, cons
     g.lda = lda; g.ldc = ldc; g.alpha = 0.f; g.out_alpha = 0.f; g.accumulate = 0; g.has_affine = 0; g.vec_out = vec_out;
     g.bsA = strideA; g.bsP = stride_planes_bytes / 2; g.bsC = strideC;
     const int cb = (N + NBLK - 1) / NBLK;
-    const int mt = pick_mt(M, cb * nbatch);
+    // rows per workgroup: every workgroup of a product reads that product's planes, so fewer row tiles = fewer reads of the right
+    // operand, which is most of the traffic of these small-M products
+    int mt = 8; double best_eff = -1.0;
+    {
+        static int forced = -1;
+        if (forced < 0) { const char* e = getenv("PTTS_DENSE_BATCHED_MT"); forced = e ? atoi(e) : 0; }
+        for (int m = 8; m >= 4; --m) {          // least row padding, then the taller tile (measured: 134 / 183 us against 163 / 213 for the
+            const int tiles = (M + 16 * m - 1) / (16 * m);      // round-filling choice of pick_mt on the per-frequency products)
+            const double eff = (double)M / (double)(tiles * 16 * m);
+            if (eff > best_eff + 1e-9) { best_eff = eff; mt = m; }
+        }
+        if (forced >= 4 && forced <= 8) mt = forced;
+    }
     const dim3 grid((unsigned)((M + 16 * mt - 1) / (16 * mt)), (unsigned)cb, (unsigned)nbatch);
     hipStream_t st = (hipStream_t)stream;
     const bool one = planes_count == 1;
