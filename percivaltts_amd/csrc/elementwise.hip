@@ -413,8 +413,20 @@ __global__ __launch_bounds__(EW_THREADS) void bn_stats_fused_kernel(const float*
     const int n2c = 2 * C, G = EW_THREADS / n2c;
     const int j = tid % n2c, g = tid / n2c;
     double t = 0.0;
-    if (g < G)
-        for (int b = g; b < (int)gridDim.x; b += G) t += __builtin_nontemporal_load(partials + (size_t)b * n2c + j);
+    if (g < G) {
+        // eight loads in flight per lane (one at a time -- a load, an add, the next load -- made this tail 15 us of a 32-us kernel);
+        // the order of the additions is fixed by the indices alone
+        const int nbk = (int)gridDim.x;
+        int b = g;
+        for (; b + 7 * G < nbk; b += 8 * G) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partials[(size_t)(b + u * G) * n2c + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += v[u];
+        }
+        for (; b < nbk; b += G) t += partials[(size_t)b * n2c + j];
+    }
     __syncthreads();                                           // sh is free again
     if (g < G) sh[0][g * n2c + j] = t;
     __syncthreads();
@@ -716,7 +728,12 @@ extern "C" int ptts_bn_batch_stats(const float* x, long long rows, int C, const 
     PTTS_REQUIRE(x && scale && shift && counter, "bn_batch_stats: null pointer");
     PTTS_REQUIRE(ptts_bn_batch_stats_supported(rows, C) && al16(x), "bn_batch_stats: unsupported shape rows=%lld C=%d (or x not 16-byte aligned)", rows, C);
     PTTS_REQUIRE(!update_moving || (moving_mean && moving_var), "bn_batch_stats: update needs moving stats");
-    const int nb = colreduce_vec4_blocks(rows, C);
+    // at most one workgroup per CU: every workgroup ends with an atomic on ONE counter, and 813 of them (the row count of the
+    // two-stage kernel) queue up for 16 us there (29 us a launch; 17 with 256, against 17 + 6 for the two-stage path)
+    int nb = colreduce_vec4_blocks(rows, C);
+    static int cap = -1;
+    if (cap < 0) { const char* e = getenv("PTTS_BN_FUSED_BLOCKS"); cap = e ? atoi(e) : 256; }
+    if (nb > cap) nb = cap;
     const size_t need = (size_t)nb * 2 * C * sizeof(double);
     if (!workspace || workspace_bytes < need) { set_error("bn_batch_stats: workspace %zu < %zu", workspace_bytes, need); return PTTS_EWORKSPACE; }
     hipLaunchKernelGGL(bn_stats_fused_kernel, dim3(nb), dim3(EW_THREADS), 0, (hipStream_t)stream, x, rows, C, (double*)workspace, counter,

@@ -20,6 +20,10 @@ echo "conv1d pmc done" >> $OUT/progress.txt
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_dense -- python3 tools/dense_split_probe.py > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_dense -- python3 tools/dense_split_probe.py > /dev/null 2>&1
 echo "dense pmc done" >> $OUT/progress.txt
+# the frequency-domain context Conv1D (tools/conv1d_fft_probe.py: forward with and without a kernel update, weight gradient)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_c1fft -- python3 tools/conv1d_fft_probe.py > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_c1fft -- python3 tools/conv1d_fft_probe.py > /dev/null 2>&1
+echo "conv1d fft pmc done" >> $OUT/progress.txt
 export C2M_ONLY=1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_conv -- python3 tools/conv2d_mfma_probe.py > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_conv -- python3 tools/conv2d_mfma_probe.py > /dev/null 2>&1

@@ -86,6 +86,21 @@ for fdir, wdir in (('pmc_fetch', 'pmc_write'), ('pmc_fetch_conv', 'pmc_write_con
         traffic[k] = {'fetch_bytes_raw': f_kib * 1024, 'fetch_bytes_corrected_x2': 2 * f_kib * 1024, 'write_bytes': w_kib * 1024,
                       'hbm_bytes_per_launch': (2 * f_kib + w_kib) * 1024, 'launches_averaged': len(fe[k])}
 json.dump(traffic, open(outdir + '/%s_traffic.json' % tag, 'w'), indent=1, sort_keys=True)
+# the frequency-domain Conv1D's kernels (tools/conv1d_fft_probe.py), in a file of their own: the batched products share their template
+# names with the Dense layers' launches of other shapes.  Raw and x2-corrected fetch bytes both given (see the chain counters' note).
+if glob.glob(src + '/pmc_fetch_c1fft/runc/*_counter_collection.csv'):
+    fe, wr = pmc('pmc_fetch_c1fft', 'FETCH_SIZE'), pmc('pmc_write_c1fft', 'WRITE_SIZE')
+    c1 = {}
+    for k in fe:
+        if not any(t in k for t in ('dense_bf16x6', 'split3_dense', 'wdft', 'dft_mirror', 'transpose_batched', 'wgrad_inverse', 'wgrad_partials_sum', 'gemm_bf16x6', 'wgrad_bf16x6')):
+            continue
+        f_kib = sum(fe[k]) / len(fe[k])
+        w_kib = sum(wr.get(k, [0.0])) / max(1, len(wr.get(k, [0.0])))
+        c1[k] = {'fetch_bytes_raw': f_kib * 1024, 'fetch_bytes_corrected_x2': 2 * f_kib * 1024, 'write_bytes': w_kib * 1024, 'launches_averaged': len(fe[k])}
+    c1['_note'] = ('tools/conv1d_fft_probe.py at B = 64, T = 400, Cin = 601, N = 256, KW = 21: dense_bf16x6_kernel<0, false, MT, 3> with MT = 8 are the '
+                   'per-frequency products (forward [128 x 1216].[1216 x 256] and correlation [256 x 128].[128 x 1216], averaged together), MT = 7 the DFT of x / dy, '
+                   'MT = 5 the inverse DFT; algorithmic bytes of the forward per-frequency launch: 394 MB of kernel planes + 131 MB of X^ + 27 MB written.')
+    json.dump(c1, open(outdir + '/%s_conv1d_freq_traffic.json' % tag, 'w'), indent=1, sort_keys=True)
 # SQ / LDS counters of the conv2d_mfma kernels (averages per launch)
 sq = {}
 for d in ('pmc_sq_conv', 'pmc_lds_conv'):
