@@ -1373,6 +1373,8 @@ class _C1FFT(object):
             What = torch.zeros(c['R'] * Kh * N, dtype=torch.float32, device=w.device)
             gemm_raw(c['Tw'], w.view(KW, Cin * N), What, c['R'], Cin * N, KW, lda=KW, ldb=Cin * N, ldc=Kh * N)
             call('ptts_split3_dense_weight_strided', ptr(What), 2 * Kh * N, ptr(planes), npb, NB, N, 2 * Kh, N, 0, stream(), tag=('w', NB))
+        if len(cls.w_hat) >= 8 and (id(w), sid) not in cls.w_hat:
+            cls.w_hat = {}                     # kernels of optimisers long gone would otherwise keep their 400-MB plane sets alive
         cls.w_hat[(id(w), sid)] = (w, w._version, epoch, None, planes, (T, NB, Kh))
         return planes
 
