@@ -249,6 +249,10 @@ typedef struct ptts_dense_split_desc {
     int K, N, transposed, reserved;
 } ptts_dense_split_desc;
 int ptts_split3_dense_weight_grouped(const ptts_dense_split_desc* descs, int n, void* stream);
+/* Planes of windows of frame sequences x [B][T][C] (the segments of the overlap-save form of the frequency-domain Conv1D): matrix
+ * z = b*NS + s = the P rows x[b][row_off + s*S + k][:], k < P; rows outside [0, T) and k >= kvalid are zero (never read). */
+int ptts_split3_frame_windows(const float* x, int B, int T, int C, int NS, int S, int row_off, int P, int kvalid,
+                              void* planes, long long stride_planes_bytes, void* stream);
 /* n weights of ONE shape at regular strides: w + i*stride_w (floats) -> planes + i*stride_planes_bytes. */
 int ptts_split3_dense_weight_strided(const float* w, long long stride_w, void* planes, long long stride_planes_bytes, int n,
                                      long long ldw, int K, int N, int transposed, void* stream);

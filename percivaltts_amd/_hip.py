@@ -83,6 +83,7 @@ SIGNATURES = {
     'ptts_dense_planes_bytes': (c_sz, [c_i, c_i]),
     'ptts_split3_dense_weight': (c_i, [c_p, c_ll, c_i, c_i, c_i, c_p, c_p]),
     'ptts_split3_dense_weight_grouped': (c_i, [c_p, c_i, c_p]),
+    'ptts_split3_frame_windows': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_ll, c_p]),
     'ptts_split3_dense_weight_strided': (c_i, [c_p, c_ll, c_p, c_ll, c_i, c_ll, c_i, c_i, c_i, c_p]),
     'ptts_dense_bf16x6_supported': (c_i, [c_i, c_i, c_i, c_ll, c_ll]),
     'ptts_dense_bf16x6': (c_i, [c_p] * 4 + [c_i] * 3 + [c_ll, c_ll, c_i, c_p, c_p, c_p, c_f, c_i, c_p, c_p]),

@@ -94,10 +94,12 @@ struct SplitGroupArgs {
     const float* w[SPLIT_GROUP]; u16* planes[SPLIT_GROUP];
     long long ldw[SPLIT_GROUP];
     int K[SPLIT_GROUP], N[SPLIT_GROUP], transposed[SPLIT_GROUP], NT[SPLIT_GROUP], KS[SPLIT_GROUP];
+    int rlo[SPLIT_GROUP], rhi[SPLIT_GROUP];       // rows k outside [rlo, rhi) are zero and never read (windows of a frame sequence)
 };
 __global__ __launch_bounds__(256) void split3_dense_weight_grouped_kernel(SplitGroupArgs a) {
     const int i = blockIdx.y;
     const int NT = a.NT[i], KS = a.KS[i], K = a.K[i], N = a.N[i], transposed = a.transposed[i];
+    const int rlo = a.rlo[i], rhi = a.rhi[i];
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;        // (nt, ks, lane)
     if (idx >= (long long)NT * KS * 64) return;
     const float* __restrict__ w = a.w[i];
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void split3_dense_weight_grouped_kernel(SplitG
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int k = k0 + e;
-        v[e] = (n < N && k < K) ? (transposed ? w[(long long)n * ldw + k] : w[(long long)k * ldw + n]) : 0.f;
+        v[e] = (n < N && k < K && k >= rlo && k < rhi) ? (transposed ? w[(long long)n * ldw + k] : w[(long long)k * ldw + n]) : 0.f;
     }
     unsigned q[3][4];
 #pragma unroll
@@ -679,6 +681,7 @@ extern "C" int ptts_split3_dense_weight_grouped(const ptts_dense_split_desc* des
             PTTS_REQUIRE(d.w && d.planes, "split3_dense_weight_grouped: null pointer (weight %d)", base + i);
             PTTS_REQUIRE(d.K > 0 && d.N > 0 && d.ldw >= (d.transposed ? d.K : d.N), "split3_dense_weight_grouped: bad dims K=%d N=%d ldw=%lld (weight %d)", d.K, d.N, d.ldw, base + i);
             a.w[i] = d.w; a.planes[i] = (u16*)d.planes; a.ldw[i] = d.ldw; a.K[i] = d.K; a.N[i] = d.N; a.transposed[i] = d.transposed;
+            a.rlo[i] = 0; a.rhi[i] = d.K;
             a.NT[i] = (d.N + NBLK - 1) / NBLK * (NBLK / 16); a.KS[i] = (d.K + BK - 1) / BK;
             const long long total = (long long)a.NT[i] * a.KS[i] * 64;
             if (total > most) most = total;
@@ -703,10 +706,38 @@ extern "C" int ptts_split3_dense_weight_strided(const float* w, long long stride
             a.w[i] = w + (long long)(base + i) * stride_w;
             a.planes[i] = (u16*)((char*)planes + (long long)(base + i) * stride_planes_bytes);
             a.ldw[i] = ldw; a.K[i] = K; a.N[i] = N; a.transposed[i] = transposed; a.NT[i] = NT; a.KS[i] = KS;
+            a.rlo[i] = 0; a.rhi[i] = K;
         }
         hipLaunchKernelGGL(split3_dense_weight_grouped_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)m), dim3(256), 0, (hipStream_t)stream, a);
     }
     return check_launch("split3_dense_weight_strided");
+}
+
+// Planes of WINDOWS of frame sequences x [B][T][C]: matrix z = b NS + s is the P rows x[b][row_off + s S + k][:], k < P, zero for rows
+// outside [0, T) and for k >= kvalid (the segments of an overlap-save convolution: a window of S + KW - 1 input frames per S output
+// frames; a block of S gradient frames zero-padded to P).  planes + z stride_planes_bytes, ptts_dense_planes_bytes(C, P) each.
+extern "C" int ptts_split3_frame_windows(const float* x, int B, int T, int C, int NS, int S, int row_off, int P, int kvalid,
+                                         void* planes, long long stride_planes_bytes, void* stream) {
+    PTTS_REQUIRE(x && planes && B > 0 && T > 0 && C > 0 && NS > 0 && S > 0 && P > 0 && kvalid > 0 && kvalid <= P, "split3_frame_windows: bad arguments");
+    const int NT = (C + NBLK - 1) / NBLK * (NBLK / 16), KS = (P + BK - 1) / BK;
+    const long long total = (long long)NT * KS * 64;
+    const int n = B * NS;
+    for (int base = 0; base < n; base += SPLIT_GROUP) {
+        SplitGroupArgs a;
+        const int m = n - base < SPLIT_GROUP ? n - base : SPLIT_GROUP;
+        for (int i = 0; i < m; ++i) {
+            const int z = base + i, b = z / NS, sgm = z - b * NS;
+            const int r0 = row_off + sgm * S;                              // source row of window row 0 (may be negative)
+            a.w[i] = x + ((long long)b * T + r0) * C;                       // (only rows inside [rlo, rhi) are dereferenced)
+            a.planes[i] = (u16*)((char*)planes + (long long)z * stride_planes_bytes);
+            a.ldw[i] = C; a.K[i] = P; a.N[i] = C; a.transposed[i] = 0; a.NT[i] = NT; a.KS[i] = KS;
+            a.rlo[i] = r0 < 0 ? -r0 : 0;
+            int hi = T - r0; if (hi > kvalid) hi = kvalid; if (hi < 0) hi = 0;
+            a.rhi[i] = hi;
+        }
+        hipLaunchKernelGGL(split3_dense_weight_grouped_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)m), dim3(256), 0, (hipStream_t)stream, a);
+    }
+    return check_launch("split3_frame_windows");
 }
 
 // 1 when ptts_dense_bf16x6 takes the shape

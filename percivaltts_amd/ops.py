@@ -1236,40 +1236,52 @@ def clear_caches():
 
 
 class _C1FFT(object):
-    """Context Conv1D FORWARD in the frequency domain (round 3): y = IDFT_t( DFT_t(x) . DFT(w) ), every stage a batched bf16x6 split
-    product of csrc/dense.hip (fp32 arithmetic: six bf16 MFMA products, fp32 accumulation), i.e. no FFT kernel at all:
-        1  X^[(f,part), b, c]   = D [2 NB x T] . x_b [T x Cin]                      (once per input: generator and critic convolve the same)
-        2  Y^_f [(part,b), n]   = [Xr | -Xi ; Xi | Xr]_f [2B x 2 Kh] . [Wr ; Wi]_f [2 Kh x N]   for the NB = P/2 + 1 frequencies
-        3  y_b [T x N]          = E [T x 2 NB] . Y^_b [2 NB x N] + bias
-    with P = T + KW - 1 rounded up to even (the linear convolution fits one period: no FFT-size constraint, the transforms are
-    matrix products).  KW = 21 taps over Cin = 601 channels cost 2 T KW Cin N flop per sample in the time domain; here the taps
-    are gone from the big product: 2 (2B)(2 Kh) N NB per batch, 8 x fewer at BASELINE size, plus the two transforms (together
-    about as much again).  The kernel's transform [Wr ; Wi]_f = Tw . w is one small GEMM + one grouped split per update.
+    """Context Conv1D in the frequency domain (round 3), overlap-save over segments of S output frames:
+        y[b, sS + t] = sum_k x[b, sS + t + k - pl] w[k]   is, per segment, a circular correlation of length P >= S + KW - 1 of the
+        window xseg = x[b, sS - pl ... sS - pl + P) (zero outside the utterance) with the kernel, i.e.  C^_f = X^_f H_f,
+        H_f = sum_k w[k] e^{+2 pi i f k / P},  valid for t < S.
+    Every stage is a batched bf16x6 split product of csrc/dense.hip (fp32 arithmetic: six bf16 MFMA products, fp32 accumulation) --
+    the transforms are matrix products with the twiddle matrices, so there is no FFT kernel and P need not be a power of two:
+        1  X^[(f,part), z, c]   = D [2 NB x P] . xseg_z [P x Cin]        z = (b, s); once per input: generator and critic convolve the same
+        2  Y^_f [(part,z), n]   = [Xr | -Xi ; Xi | Xr]_f [2 B NS x 2 Kh] . [Hr ; Hi]_f [2 Kh x N]      for the NB = P/2 + 1 frequencies
+        3  y_z [S x N]          = E [S x 2 NB] . Y^_z [2 NB x N] + bias
+    and the weight gradient by the correlation theorem, sum_t xseg[t + k] dyseg[t] = (1/P) sum_f X^_f conj(DY^_f) e^{2 pi i f k / P}:
+        4  DY^ = D . dyseg_z (the S gradient frames of a segment, zero-padded to P);  G_f^T = DY^_f^T [N x 2 B NS] . [..]_f [2 B NS x 2 Kh]
+           = (Gr | -Gi)_f^T;  dW[k] = sum_f T2c[k,f] Gr_f + T2s[k,f] (-(-Gi_f))  (fused inverse transform, ptts_conv1d_freq_wgrad_inverse).
+    KW = 21 taps over Cin = 601 channels cost 2 T KW Cin N flop per sample in the time domain; here the taps are gone from the big
+    product.  Segments (S = 100 at T = 400: P = 120, 61 frequencies instead of 211 for the whole utterance at once) keep the
+    transformed kernel small -- its planes are what the per-frequency product streams: 114 MB instead of 394 -- at 20 % more flops.
     Reference: kl.Conv1D of networktts.py:116-120 (pCNN1D), 'same' padding, cross-correlation as TF computes it.
     On by default for fp32 arithmetic (not in the one-product bf16 mode, whose time-domain kernel is as fast); PTTS_CONV1D_FFT=0 /
-    conv1d_fft(False) select the time-domain kernels."""
+    conv1d_fft(False) select the time-domain kernels; PTTS_CONV1D_FFT_SEG=0 transforms whole utterances (one segment)."""
     default = os.environ.get('PTTS_CONV1D_FFT', '1') == '1'
     enabled = default
-    KWS = (3, 5, 7, 9, 11, 21)      # instantiations of conv1d_wdft_planes_kernel<KW>
+    KWS = (3, 5, 7, 9, 11, 21)      # instantiations of conv1d_wdft_planes_kernel<KW> / conv1d_freq_wgrad_inverse_kernel<KW>
     wgrad_enabled = os.environ.get('PTTS_CONV1D_FFT_WGRAD', '1') == '1'
-    consts = {}         # (T, KW, device, stream) -> dict of the twiddle operands
+    seg_target = int(os.environ.get('PTTS_CONV1D_FFT_SEG', '100'))      # preferred segment length (0: one segment per utterance)
+    consts = {}         # (T, KW, device, stream) -> dict of the geometry and the twiddle operands
     x_src = None; x_key = None; x_hat = None
-    w_hat = {}          # (id(w), stream) -> (w, version, epoch, W^ buffer, planes)
-    bufs = {}           # persistent zero-padded buffers by (name, shape key, stream)
+    xw_src = None; xw_key = None; xw_planes = None
+    w_hat = {}          # (id(w), stream) -> (w, version, epoch, None, planes, geometry)
+    bufs = {}           # persistent buffers by (name, key, stream)
 
     @staticmethod
     def eligible(a, w):
         B, T, Cin = a.shape
         KW, _, N = w.shape
-        return a.is_cuda and B * T >= 4096 and KW >= 5 and KW % 2 == 1 and T % 4 == 0 and N % 4 == 0 and Cin >= 64
+        return a.is_cuda and B * T >= 4096 and KW >= 3 and KW % 2 == 1 and T % 4 == 0 and N % 4 == 0 and Cin >= 64
 
     @classmethod
-    def geometry(cls, T, KW, Cin):
-        P = T + KW - 1
-        P += P & 1
-        NB = P // 2 + 1
-        Kh = (Cin + 7) // 8 * 8            # half of the per-frequency reduction length (2 Kh a multiple of 16)
-        return P, NB, Kh
+    def segment(cls, T, KW):
+        """S: the divisor of T closest to the target (a multiple of 4, at least 2 KW), or T itself."""
+        tgt = cls.seg_target
+        if tgt <= 0:
+            return T
+        best = T
+        for S in range(4, T + 1, 4):
+            if T % S == 0 and S >= 2 * KW and abs(S - tgt) < abs(best - tgt):
+                best = S
+        return best
 
     @classmethod
     def _buf(cls, name, key, nfloats, dev):
@@ -1290,112 +1302,115 @@ class _C1FFT(object):
         return t
 
     @classmethod
-    def const(cls, T, KW, dev):
-        key = (T, KW, dev.index, _hip.stream_id())
+    def const(cls, T, KW, Cin, dev):
+        key = (T, KW, Cin, dev.index, _hip.stream_id(), cls.seg_target)
         c = cls.consts.get(key)
         if c is not None:
             return c
         import math
-        P = T + KW - 1
-        P += P & 1
+        S = cls.segment(T, KW)
+        NS = T // S
+        P = (S + KW - 1 + 3) // 4 * 4            # the window: a reduction length of the first product (a multiple of 4), even
         NB = P // 2 + 1
         pl = (KW - 1) // 2
         f = torch.arange(NB, dtype=torch.float64).view(NB, 1)
-        t = torch.arange(T, dtype=torch.float64).view(1, T)
-        th = 2.0 * math.pi * torch.remainder(f * t, P) / P
-        D = torch.stack([torch.cos(th), -torch.sin(th)], dim=1).reshape(2 * NB, T)               # rows (f, part): Xr, Xi
+        i = torch.arange(P, dtype=torch.float64).view(1, P)
+        th = 2.0 * math.pi * torch.remainder(f * i, P) / P                                       # [NB, P]
+        D = torch.stack([torch.cos(th), -torch.sin(th)], dim=1).reshape(2 * NB, P)               # rows (f, part): Xr, Xi
         cf = torch.full((NB,), 2.0, dtype=torch.float64); cf[0] = 1.0; cf[P // 2] = 1.0
         R = 2 * NB
         Rp = (R + 3) // 4 * 4
-        E = torch.zeros(T, Rp, dtype=torch.float64)                                              # y[t] = sum_r E[t, r] Y^[r]
-        E[:, 0:R:2] = (torch.cos(th) * cf.view(NB, 1) / P).t()
-        E[:, 1:R:2] = (-torch.sin(th) * cf.view(NB, 1) / P).t()
+        E = torch.zeros(S, Rp, dtype=torch.float64)                                              # y[t] = sum_r E[t, r] Y^[r],  t < S
+        E[:, 0:R:2] = (torch.cos(th[:, :S]) * cf.view(NB, 1) / P).t()
+        E[:, 1:R:2] = (-torch.sin(th[:, :S]) * cf.view(NB, 1) / P).t()
         k = torch.arange(KW, dtype=torch.float64).view(1, KW)
-        tk = 2.0 * math.pi * torch.remainder(f * (pl - k), P) / P
-        Tw = torch.stack([torch.cos(tk), -torch.sin(tk)], dim=1).reshape(R, KW)                  # rows (f, part): Wr, Wi
+        tk = 2.0 * math.pi * torch.remainder(f * k, P) / P                                       # [NB, KW]
+        Tw = torch.stack([torch.cos(tk), torch.sin(tk)], dim=1).reshape(R, KW)                   # rows (f, part): Hr, Hi  (H_f = sum_k w[k] e^{+i tk})
         NBp = (NB + 3) // 4 * 4
-        T2 = torch.zeros(2 * KW, NBp, dtype=torch.float64)                                      # dW = sum_f T2[., f] (Gr | -Gi)_f
-        ph = 2.0 * math.pi * torch.remainder(f * (k - pl), P) / P                               # [NB, KW]
-        T2[:KW, :NB] = (torch.cos(ph) * cf.view(NB, 1) / P).t()
-        T2[KW:, :NB] = (torch.sin(ph) * cf.view(NB, 1) / P).t()
+        T2 = torch.zeros(2 * KW, NBp, dtype=torch.float64)                                      # dW[k] = sum_f T2[k, f] Gr_f + T2[KW + k, f] (-Gi)_f ... see wgrad
+        T2[:KW, :NB] = (torch.cos(tk) * cf.view(NB, 1) / P).t()
+        T2[KW:, :NB] = (torch.sin(tk) * cf.view(NB, 1) / P).t()
         TP = (2 * KW + 15) // 16 * 16
         T2f = torch.zeros(NB, TP, dtype=torch.float64)                                          # the same, frequency-major (the fused inverse kernel)
         T2f[:, :2 * KW] = T2[:, :NB].t()
-        c = {'P': P, 'NB': NB, 'R': R, 'Rp': Rp, 'NBp': NBp, 'T2': T2.to(torch.float32).to(dev).contiguous(),
-             'TP': TP, 'T2f': T2f.to(torch.float32).to(dev).contiguous(),
-             'D': D.to(torch.float32).to(dev).contiguous(), 'E': E.to(torch.float32).to(dev).contiguous(),
-             'Tw': Tw.to(torch.float32).to(dev).contiguous()}
+        to = lambda m: m.to(torch.float32).to(dev).contiguous()
+        c = {'S': S, 'NS': NS, 'P': P, 'NB': NB, 'R': R, 'Rp': Rp, 'NBp': NBp, 'TP': TP, 'pl': pl, 'Kh': (Cin + 7) // 8 * 8,
+             'D': to(D), 'E': to(E), 'Tw': to(Tw), 'T2': to(T2), 'T2f': to(T2f)}
         cls.consts[key] = c
         return c
 
     @classmethod
     def x_transform(cls, a, KW):
-        """[Xr | -Xi ; Xi | Xr] per frequency: Ap [NB][2][B][2 Kh] fp32, kept for the tensor it was made from."""
+        """[Xr | -Xi ; Xi | Xr] per frequency: Ap [NB][2][B NS][2 Kh] fp32, kept for the tensor it was made from."""
         B, T, Cin = a.shape
         key = (a._version, tuple(a.shape), KW, _hip.stream_id())
         if cls.x_src is a and cls.x_key == key:
             return cls.x_hat
-        c = cls.const(T, KW, a.device)
-        P, NB, Kh = cls.geometry(T, KW, Cin)
-        Ap = cls._buf('Ap', (B, T, Cin, KW), NB * 2 * B * 2 * Kh, a.device)                        # pad columns stay zero
+        c = cls.const(T, KW, Cin, a.device)
+        NB, Kh, NS, S, P = c['NB'], c['Kh'], c['NS'], c['S'], c['P']
+        Z = B * NS
+        Ap = cls._buf('Ap', (B, T, Cin, KW, S), NB * 2 * Z * 2 * Kh, a.device)                     # pad columns stay zero
         lib = _hip.lib()
-        npb = lib.ptts_dense_planes_bytes(Cin, T)
-        xpl = cls._scratch('xpl', B * npb, a.device)
-        call('ptts_split3_dense_weight_strided', ptr(a), T * Cin, ptr(xpl), npb, B, Cin, T, Cin, 0, stream(), tag=('x', B))
-        call('ptts_dense_bf16x6_batched', ptr(c['D']), 0, ptr(xpl), npb, None, ptr(Ap), 2 * Kh, B, c['R'], Cin, T, T, B * 2 * Kh, 3, stream(),
-             tag=('dft', B, c['R'], Cin, T))
-        call('ptts_dft_mirror', ptr(Ap), NB, B, Cin, Kh, stream())
+        npb = lib.ptts_dense_planes_bytes(Cin, P)
+        xpl = cls._scratch('xpl', Z * npb, a.device)
+        call('ptts_split3_frame_windows', ptr(a), B, T, Cin, NS, S, -c['pl'], P, P, ptr(xpl), npb, stream(), tag=('x', Z))
+        call('ptts_dense_bf16x6_batched', ptr(c['D']), 0, ptr(xpl), npb, None, ptr(Ap), 2 * Kh, Z, c['R'], Cin, P, P, Z * 2 * Kh, 3, stream(),
+             tag=('dft', Z, c['R'], Cin, P))
+        call('ptts_dft_mirror', ptr(Ap), NB, Z, Cin, Kh, stream())
         cls.x_src, cls.x_key, cls.x_hat = a, key, Ap
         return Ap
 
     @classmethod
     def kernel(cls, w, T):
-        """Planes of [Wr ; Wi]_f [2 Kh x N] for all frequencies, rebuilt when the kernel changes."""
+        """Planes of [Hr ; Hi]_f [2 Kh x N] for all frequencies, rebuilt when the kernel changes."""
         KW, Cin, N = w.shape
         flat = getattr(w, '_ptts_flat', None)
         epoch = None if flat is None else flat.epoch
         sid = _hip.stream_id()
+        c = cls.const(T, KW, Cin, w.device)
+        NB, Kh = c['NB'], c['Kh']
+        geo = (c['S'], NB, Kh)
         ent = cls.w_hat.get((id(w), sid))
-        if ent is not None and ent[0] is w and ent[1] == w._version and ent[2] == epoch and flat is not None and ent[5][0] == T:
+        if ent is not None and ent[0] is w and ent[1] == w._version and ent[2] == epoch and flat is not None and ent[5] == geo:
             return ent[4]
-        c = cls.const(T, KW, w.device)
-        P, NB, Kh = cls.geometry(T, KW, Cin)
         lib = _hip.lib()
         npb = lib.ptts_dense_planes_bytes(N, 2 * Kh)
-        if ent is not None and ent[0] is w and ent[5] == (T, NB, Kh):
+        if ent is not None and ent[0] is w and ent[5] == geo:
             planes = ent[4]
         else:
             planes = torch.empty(NB * npb, dtype=torch.uint8, device=w.device)
         if KW in cls.KWS:
             call('ptts_conv1d_freq_kernel_planes', ptr(w), ptr(c['Tw']), ptr(planes), NB, KW, Cin, N, Kh, stream(), tag=(NB, KW, Cin, N))
         else:
-            # any other odd kernel size: the twiddle product as a GEMM (pad rows zero), then one grouped split
+            # any other odd kernel size: the twiddle product as a GEMM (pad rows zero), then one strided split
             What = torch.zeros(c['R'] * Kh * N, dtype=torch.float32, device=w.device)
             gemm_raw(c['Tw'], w.view(KW, Cin * N), What, c['R'], Cin * N, KW, lda=KW, ldb=Cin * N, ldc=Kh * N)
             call('ptts_split3_dense_weight_strided', ptr(What), 2 * Kh * N, ptr(planes), npb, NB, N, 2 * Kh, N, 0, stream(), tag=('w', NB))
         if len(cls.w_hat) >= 8 and (id(w), sid) not in cls.w_hat:
-            cls.w_hat = {}                     # kernels of optimisers long gone would otherwise keep their 400-MB plane sets alive
-        cls.w_hat[(id(w), sid)] = (w, w._version, epoch, None, planes, (T, NB, Kh))
+            cls.w_hat = {}                     # kernels of optimisers long gone would otherwise keep their plane sets alive
+        cls.w_hat[(id(w), sid)] = (w, w._version, epoch, None, planes, geo)
         return planes
 
     @classmethod
     def forward(cls, a, w, b, y):
         B, T, Cin = a.shape
         KW, _, N = w.shape
-        c = cls.const(T, KW, a.device)
-        P, NB, Kh = cls.geometry(T, KW, Cin)
+        c = cls.const(T, KW, Cin, a.device)
+        NB, Kh, NS, S = c['NB'], c['Kh'], c['NS'], c['S']
+        Z = B * NS
         lib = _hip.lib()
         Ap = cls.x_transform(a, KW)
         wpl = cls.kernel(w, T)
         npw = lib.ptts_dense_planes_bytes(N, 2 * Kh)
-        Yh = cls._scratch('Yh', NB * 2 * B * N * 4, a.device)                                        # [NB][2][B][N] fp32
-        call('ptts_dense_bf16x6_batched', ptr(Ap), 2 * B * 2 * Kh, ptr(wpl), npw, None, ptr(Yh), 2 * B * N, NB, 2 * B, N, 2 * Kh,
-             2 * Kh, N, 3, stream(), tag=('freq', NB, 2 * B, N, 2 * Kh))
+        Yh = cls._scratch('Yh', NB * 2 * Z * N * 4, a.device)                                        # [NB][2][Z][N] fp32
+        call('ptts_dense_bf16x6_batched', ptr(Ap), 2 * Z * 2 * Kh, ptr(wpl), npw, None, ptr(Yh), 2 * Z * N, NB, 2 * Z, N, 2 * Kh,
+             2 * Kh, N, 3, stream(), tag=('freq', NB, 2 * Z, N, 2 * Kh))
         npy = lib.ptts_dense_planes_bytes(N, c['R'])
-        ypl = cls._scratch('ypl', B * npy, a.device)
-        call('ptts_split3_dense_weight_strided', ptr(Yh), N, ptr(ypl), npy, B, B * N, c['R'], N, 0, stream(), tag=('y', B))
-        call('ptts_dense_bf16x6_batched', ptr(c['E']), 0, ptr(ypl), npy, ptr(b), ptr(y), T * N, B, T, N, c['Rp'], c['Rp'], N, 3, stream(),
-             tag=('idft', B, T, N, c['Rp']))
+        ypl = cls._scratch('ypl', Z * npy, a.device)
+        call('ptts_split3_dense_weight_strided', ptr(Yh), N, ptr(ypl), npy, Z, Z * N, c['R'], N, 0, stream(), tag=('y', Z))
+        # segment z = (b, s) writes the S frames y[b, s S ...]: consecutive blocks of S N floats (T = NS S)
+        call('ptts_dense_bf16x6_batched', ptr(c['E']), 0, ptr(ypl), npy, ptr(b), ptr(y), S * N, Z, S, N, c['Rp'], c['Rp'], N, 3, stream(),
+             tag=('idft', Z, S, N, c['Rp']))
 
     @classmethod
     def has_x(cls, a, KW):
@@ -1403,36 +1418,33 @@ class _C1FFT(object):
 
     @classmethod
     def wgrad(cls, a, dy, KW):
-        """dW [KW, Cin, N] of the layer from the transform of its input (kept from the forward) and of dy:
-            G_f [n][(h, c)] = DY'_f^T [N x 2B] . [Xr | -Xi ; Xi | Xr]_f [2B x 2 Kh]  =  (Gr | -Gi)_f^T      for every frequency
-            dW[k][c][n]     = sum_f  T2c[k][f] Gr_f[c][n] + T2s[k][f] (-Gi_f)[c][n]
-        (the correlation theorem: sum_t x[t + k - pl] dy[t] = (1/P) sum_f X_f conj(DY_f) e^{2 pi i f (k - pl) / P})."""
+        """dW [KW, Cin, N] of the layer from the transform of its input (kept from the forward) and of dy (see the class comment, 4)."""
         B, T, Cin = a.shape
         N = dy.shape[-1]
-        c = cls.const(T, KW, a.device)
-        P, NB, Kh = cls.geometry(T, KW, Cin)
+        c = cls.const(T, KW, Cin, a.device)
+        NB, Kh, NS, S, P = c['NB'], c['Kh'], c['NS'], c['S'], c['P']
+        Z = B * NS
         lib = _hip.lib()
         dev = a.device
         Ap = cls.x_hat
-        # planes of [Xr | -Xi ; Xi | Xr]_f as the right operand [K = 2B][N' = 2 Kh]: once per input
+        # planes of [Xr | -Xi ; Xi | Xr]_f as the right operand [K = 2Z][N' = 2 Kh]: once per input
+        npx = lib.ptts_dense_planes_bytes(2 * Kh, 2 * Z)
         if cls.xw_src is not a or cls.xw_key != cls.x_key or cls.xw_planes is None:
-            npx = lib.ptts_dense_planes_bytes(2 * Kh, 2 * B)
             xw = cls._scratch('xw', NB * npx, dev)
-            call('ptts_split3_dense_weight_strided', ptr(Ap), 2 * B * 2 * Kh, ptr(xw), npx, NB, 2 * Kh, 2 * B, 2 * Kh, 0, stream(), tag=('xw', NB))
+            call('ptts_split3_dense_weight_strided', ptr(Ap), 2 * Z * 2 * Kh, ptr(xw), npx, NB, 2 * Kh, 2 * Z, 2 * Kh, 0, stream(), tag=('xw', NB))
             cls.xw_src, cls.xw_key, cls.xw_planes = a, cls.x_key, xw
-        npx = lib.ptts_dense_planes_bytes(2 * Kh, 2 * B)
-        # DY' = DFT_t(dy): [NB][2][B][N]
-        npd = lib.ptts_dense_planes_bytes(N, T)
-        dpl = cls._scratch('dpl', B * npd, dev)
-        call('ptts_split3_dense_weight_strided', ptr(dy), T * N, ptr(dpl), npd, B, N, T, N, 0, stream(), tag=('dy', B))
-        DYh = cls._scratch('DYh', NB * 2 * B * N * 4, dev)
-        call('ptts_dense_bf16x6_batched', ptr(c['D']), 0, ptr(dpl), npd, None, ptr(DYh), N, B, c['R'], N, T, T, B * N, 3, stream(),
-             tag=('dft_dy', B, c['R'], N, T))
-        DYt = cls._scratch('DYt', NB * N * 2 * B * 4, dev)                                         # [NB][N][2B] fp32
-        call('ptts_transpose_batched', ptr(DYh), ptr(DYt), NB, 2 * B, N, stream())
+        # DY' = DFT of the segments' gradient frames (S frames, zero-padded to P): [NB][2][Z][N]
+        npd = lib.ptts_dense_planes_bytes(N, P)
+        dpl = cls._scratch('dpl', Z * npd, dev)
+        call('ptts_split3_frame_windows', ptr(dy), B, T, N, NS, S, 0, P, S, ptr(dpl), npd, stream(), tag=('dy', Z))
+        DYh = cls._scratch('DYh', NB * 2 * Z * N * 4, dev)
+        call('ptts_dense_bf16x6_batched', ptr(c['D']), 0, ptr(dpl), npd, None, ptr(DYh), N, Z, c['R'], N, P, P, Z * N, 3, stream(),
+             tag=('dft_dy', Z, c['R'], N, P))
+        DYt = cls._scratch('DYt', NB * N * 2 * Z * 4, dev)                                         # [NB][N][2Z] fp32
+        call('ptts_transpose_batched', ptr(DYh), ptr(DYt), NB, 2 * Z, N, stream())
         Gt = cls._scratch('Gt', NB * N * 2 * Kh * 4, dev)                                          # [NB][N][2 Kh] fp32 = (Gr | -Gi)^T
-        call('ptts_dense_bf16x6_batched', ptr(DYt), N * 2 * B, ptr(cls.xw_planes), npx, None, ptr(Gt), N * 2 * Kh, NB, N, 2 * Kh, 2 * B,
-             2 * B, 2 * Kh, 3, stream(), tag=('corr', NB, N, 2 * Kh, 2 * B))
+        call('ptts_dense_bf16x6_batched', ptr(DYt), N * 2 * Z, ptr(cls.xw_planes), npx, None, ptr(Gt), N * 2 * Kh, NB, N, 2 * Kh, 2 * Z,
+             2 * Z, 2 * Kh, 3, stream(), tag=('corr', NB, N, 2 * Kh, 2 * Z))
         dw = torch.empty((KW, Cin, N), dtype=torch.float32, device=dev)
         if KW in cls.KWS:
             ws = _workspace(lib.ptts_conv1d_freq_wgrad_inverse_workspace_bytes(KW, Cin, N), dev)
@@ -1443,8 +1455,6 @@ class _C1FFT(object):
             gemm_raw(c['T2'], Gt, out2, 2 * KW, N * 2 * Kh, NB, lda=c['NBp'], ldb=N * 2 * Kh, ldc=N * 2 * Kh)
             call('ptts_conv1d_freq_wgrad_combine', ptr(out2), ptr(dw), KW, Cin, N, Kh, stream())
         return dw
-
-    xw_src = None; xw_key = None; xw_planes = None
 
     @classmethod
     def clear(cls):
@@ -1516,7 +1526,7 @@ class Conv1dFn(torch.autograd.Function):
             return saved if ctx.padded else _pad_time(saved, pl, KW - 1 - pl)
 
         if want_w and _C1FFT.enabled and _C1FFT.wgrad_enabled and _C1Split.enabled and not _Flags.bf16_products and dy.is_cuda and \
-                _C1FFT.has_x(ctx.x_src, KW) and not ctx.padded and B % 2 == 0:      # (2B is a reduction length: a multiple of 4)
+                _C1FFT.has_x(ctx.x_src, KW) and not ctx.padded and (B * (T // _C1FFT.segment(T, KW))) % 2 == 0:      # (2 B NS is a reduction length: a multiple of 4)
             # in the frequency domain, from the transform of the input the forward left behind (ops._C1FFT.wgrad)
             dw = _C1FFT.wgrad(ctx.x_src, dy, KW)
         elif want_w and _C1Split.enabled and not _Flags.deterministic and dy.is_cuda and _C1Split.eligible_wgrad(KW, N):

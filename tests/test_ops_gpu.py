@@ -1180,10 +1180,12 @@ def test_dense_weight_gradient_deferred_two_stage_between_2048_and_4096_rows(ops
     close(net.b.grad, db, rtol=2e-5, atol=2e-4, what='db')
 
 
-@pytest.mark.parametrize('case', [(12, 400, 601, 256, 21), (16, 256, 70, 32, 5), (11, 400, 601, 256, 21), (9, 460, 128, 64, 9)])
-def test_conv1d_frequency_domain_forward(ops, case):
+@pytest.mark.parametrize('seg', [100, 0], ids=['segments', 'whole'])
+@pytest.mark.parametrize('case', [(12, 400, 601, 256, 21), (16, 256, 70, 32, 5), (11, 400, 601, 256, 21), (9, 460, 128, 64, 9), (5, 1000, 64, 16, 3)])
+def test_conv1d_frequency_domain_forward(ops, case, seg):
     """ops._C1FFT (conv1d_fft(True)): the context Conv1D forward as DFT -> per-frequency products -> inverse DFT, each stage a batched
-    bf16x6 split product (ptts_dense_bf16x6_batched), P = T + KW - 1 (no power-of-two transform).  Against the fp64 oracle at the
+    bf16x6 split product (ptts_dense_bf16x6_batched), overlap-save over segments of S frames with windows of P = S + KW - 1 (no
+    power-of-two transform) or over whole utterances.  Against the fp64 oracle at the
     tolerance of the time-domain kernels (fp32 arithmetic; the transforms' twiddles are exact to fp32 rounding), with bias, 'same'
     padding at both utterance borders, a batch that is no multiple of anything; the weight gradient by the correlation theorem from
     the same transforms (ops._C1FFT.wgrad) and the bias gradient, against the fp64 oracle as well."""
@@ -1195,6 +1197,8 @@ def test_conv1d_frequency_domain_forward(ops, case):
     yr = O.conv1d_ntc(x, w, b)
     xd, wd, bd = dev(x), dev(w, True), dev(b, True)
     ops.conv1d_fft(True); ops.conv1d_split(True)
+    seg0 = ops._C1FFT.seg_target
+    ops._C1FFT.seg_target = seg                  # overlap-save over segments of about 100 frames (the default), or whole utterances
     try:
         assert ops._C1FFT.eligible(xd, wd)
         with ops._hip.KernelTimer() as kt:
@@ -1213,12 +1217,15 @@ def test_conv1d_frequency_domain_forward(ops, case):
         dy = torch.randn(B, T, N, generator=g, dtype=torch.float64)
         with ops._hip.KernelTimer() as kt3:
             yd.backward(dev(dy))
-        # the correlation theorem: dW from X^ and DY^ (an odd batch -- 2B no multiple of 4 -- takes the time-domain kernel)
-        assert ('ptts_conv1d_freq_wgrad_inverse' in [n for n, _, _ in kt3.durations_ms()]) == (B % 2 == 0)
+        # the correlation theorem: dW from X^ and DY^ (an odd number of segments in the batch -- 2 B NS no multiple of 4 -- takes the
+        # time-domain kernel)
+        nseg = B * (T // ops._C1FFT.segment(T, KW))
+        assert ('ptts_conv1d_freq_wgrad_inverse' in [n for n, _, _ in kt3.durations_ms()]) == (nseg % 2 == 0)
         close(bd.grad, dy.sum((0, 1)), rtol=2e-5, atol=2e-4, what='db')
         wr = ref(w, True)
         O.conv1d_ntc(x, wr, b).backward(dy)
         e = float((wd.grad.double().cpu() - wr.grad).norm() / wr.grad.norm())
         assert e < 2e-5, e
     finally:
+        ops._C1FFT.seg_target = seg0
         ops.conv1d_fft(None); ops.conv1d_split(None)
