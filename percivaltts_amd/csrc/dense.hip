@@ -168,6 +168,52 @@ __global__ __launch_bounds__(256) void conv1d_wdft_planes_kernel(const float* __
     }
 }
 
+// ... and for matrices at REGULAR strides / windows of frame sequences (blockIdx.y = matrix, any number of them in one launch: the
+// descriptor form above carries 32 per launch, and the frequency-domain Conv1D splits 256 at a time)
+struct SplitStridedArgs {
+    const float* w; u16* planes;
+    long long stride_w, stride_p, ldw;            // floats, u16 elements, floats
+    int K, N, transposed, NT, KS;
+    int windows;                                  // 1: matrix z = (b, s) is the window x[b][row_off + s S + k][:] of a frame sequence
+    int T, NS, S, row_off, kvalid;
+};
+__global__ __launch_bounds__(256) void split3_dense_weight_strided_kernel(SplitStridedArgs a) {
+    const int z = blockIdx.y;
+    const int NT = a.NT, KS = a.KS, K = a.K, N = a.N, transposed = a.transposed;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;        // (nt, ks, lane)
+    if (idx >= (long long)NT * KS * 64) return;
+    const float* __restrict__ w;
+    int rlo = 0, rhi = K;
+    if (a.windows) {
+        const int b = z / a.NS, sg = z - b * a.NS;
+        const int r0 = a.row_off + sg * a.S;                                // source row of window row 0 (may be negative)
+        w = a.w + ((long long)b * a.T + r0) * a.ldw;                        // (only rows inside [rlo, rhi) are dereferenced)
+        rlo = r0 < 0 ? -r0 : 0;
+        rhi = min(a.kvalid, a.T - r0);
+    } else {
+        w = a.w + (long long)z * a.stride_w;
+    }
+    u16* __restrict__ planes = a.planes + (long long)z * a.stride_p;
+    const long long ldw = a.ldw;
+    const int lane = (int)(idx & 63);
+    const long long t = idx >> 6;
+    const int ks = (int)(t % KS), nt = (int)(t / KS);
+    const int n = nt * 16 + (lane & 15), k0 = ks * 32 + (lane >> 4) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = k0 + e;
+        v[e] = (n < N && k < K && k >= rlo && k < rhi) ? (transposed ? w[(long long)n * ldw + k] : w[(long long)k * ldw + n]) : 0.f;
+    }
+    unsigned q[3][4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) split3_pair(v[2 * h], v[2 * h + 1], q[0][h], q[1][h], q[2][h]);
+    const size_t ps = (size_t)NT * KS * 512;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+        *reinterpret_cast<uint4*>(planes + p * ps + (size_t)idx * 8) = make_uint4(q[p][0], q[p][1], q[p][2], q[p][3]);
+}
+
 struct DenseArgs {
     const float* A; const float* mask_src; const float* in_scale; const float* in_shift;
     const u16* planes; const float* bias; const float* out_mask; float* C;
@@ -695,21 +741,16 @@ extern "C" int ptts_split3_dense_weight_grouped(const ptts_dense_split_desc* des
 // batched products, without a descriptor array on the host side
 extern "C" int ptts_split3_dense_weight_strided(const float* w, long long stride_w, void* planes, long long stride_planes_bytes, int n,
                                                 long long ldw, int K, int N, int transposed, void* stream) {
-    PTTS_REQUIRE(w && planes && n > 0, "split3_dense_weight_strided: nothing to split");
+    PTTS_REQUIRE(w && planes && n > 0 && n <= 65535, "split3_dense_weight_strided: nothing to split (or more than 65535 matrices)");
     PTTS_REQUIRE(K > 0 && N > 0 && ldw >= (transposed ? K : N), "split3_dense_weight_strided: bad dims K=%d N=%d ldw=%lld", K, N, ldw);
-    const int NT = (N + NBLK - 1) / NBLK * (NBLK / 16), KS = (K + BK - 1) / BK;
-    const long long total = (long long)NT * KS * 64;
-    for (int base = 0; base < n; base += SPLIT_GROUP) {
-        SplitGroupArgs a;
-        const int m = n - base < SPLIT_GROUP ? n - base : SPLIT_GROUP;
-        for (int i = 0; i < m; ++i) {
-            a.w[i] = w + (long long)(base + i) * stride_w;
-            a.planes[i] = (u16*)((char*)planes + (long long)(base + i) * stride_planes_bytes);
-            a.ldw[i] = ldw; a.K[i] = K; a.N[i] = N; a.transposed[i] = transposed; a.NT[i] = NT; a.KS[i] = KS;
-            a.rlo[i] = 0; a.rhi[i] = K;
-        }
-        hipLaunchKernelGGL(split3_dense_weight_grouped_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)m), dim3(256), 0, (hipStream_t)stream, a);
-    }
+    PTTS_REQUIRE(stride_planes_bytes % 16 == 0, "split3_dense_weight_strided: the planes' stride must keep 16-byte alignment");
+    SplitStridedArgs a;
+    a.w = w; a.planes = (u16*)planes; a.stride_w = stride_w; a.stride_p = stride_planes_bytes / 2; a.ldw = ldw;
+    a.K = K; a.N = N; a.transposed = transposed;
+    a.NT = (N + NBLK - 1) / NBLK * (NBLK / 16); a.KS = (K + BK - 1) / BK;
+    a.windows = 0; a.T = a.NS = a.S = a.row_off = a.kvalid = 0;
+    const long long total = (long long)a.NT * a.KS * 64;
+    hipLaunchKernelGGL(split3_dense_weight_strided_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("split3_dense_weight_strided");
 }
 
@@ -719,24 +760,14 @@ extern "C" int ptts_split3_dense_weight_strided(const float* w, long long stride
 extern "C" int ptts_split3_frame_windows(const float* x, int B, int T, int C, int NS, int S, int row_off, int P, int kvalid,
                                          void* planes, long long stride_planes_bytes, void* stream) {
     PTTS_REQUIRE(x && planes && B > 0 && T > 0 && C > 0 && NS > 0 && S > 0 && P > 0 && kvalid > 0 && kvalid <= P, "split3_frame_windows: bad arguments");
-    const int NT = (C + NBLK - 1) / NBLK * (NBLK / 16), KS = (P + BK - 1) / BK;
-    const long long total = (long long)NT * KS * 64;
-    const int n = B * NS;
-    for (int base = 0; base < n; base += SPLIT_GROUP) {
-        SplitGroupArgs a;
-        const int m = n - base < SPLIT_GROUP ? n - base : SPLIT_GROUP;
-        for (int i = 0; i < m; ++i) {
-            const int z = base + i, b = z / NS, sgm = z - b * NS;
-            const int r0 = row_off + sgm * S;                              // source row of window row 0 (may be negative)
-            a.w[i] = x + ((long long)b * T + r0) * C;                       // (only rows inside [rlo, rhi) are dereferenced)
-            a.planes[i] = (u16*)((char*)planes + (long long)z * stride_planes_bytes);
-            a.ldw[i] = C; a.K[i] = P; a.N[i] = C; a.transposed[i] = 0; a.NT[i] = NT; a.KS[i] = KS;
-            a.rlo[i] = r0 < 0 ? -r0 : 0;
-            int hi = T - r0; if (hi > kvalid) hi = kvalid; if (hi < 0) hi = 0;
-            a.rhi[i] = hi;
-        }
-        hipLaunchKernelGGL(split3_dense_weight_grouped_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)m), dim3(256), 0, (hipStream_t)stream, a);
-    }
+    PTTS_REQUIRE((long long)B * NS <= 65535 && stride_planes_bytes % 16 == 0, "split3_frame_windows: more than 65535 windows, or a planes stride off 16-byte alignment");
+    SplitStridedArgs a;
+    a.w = x; a.planes = (u16*)planes; a.stride_w = 0; a.stride_p = stride_planes_bytes / 2; a.ldw = C;
+    a.K = P; a.N = C; a.transposed = 0;
+    a.NT = (C + NBLK - 1) / NBLK * (NBLK / 16); a.KS = (P + BK - 1) / BK;
+    a.windows = 1; a.T = T; a.NS = NS; a.S = S; a.row_off = row_off; a.kvalid = kvalid;
+    const long long total = (long long)a.NT * a.KS * 64;
+    hipLaunchKernelGGL(split3_dense_weight_strided_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)(B * NS)), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("split3_frame_windows");
 }
 
