@@ -1452,7 +1452,7 @@ class _C1FFT(object):
                  tag=(NB, KW, Cin, N))
         else:
             out2 = torch.empty(2 * KW * N * 2 * Kh, dtype=torch.float32, device=dev)
-            gemm_raw(c['T2'], Gt, out2, 2 * KW, N * 2 * Kh, NB, lda=c['NBp'], ldb=N * 2 * Kh, ldc=N * 2 * Kh)
+            gemm_raw(c['T2'], Gt[:NB * N * 2 * Kh * 4].view(torch.float32), out2, 2 * KW, N * 2 * Kh, NB, lda=c['NBp'], ldb=N * 2 * Kh, ldc=N * 2 * Kh)
             call('ptts_conv1d_freq_wgrad_combine', ptr(out2), ptr(dw), KW, Cin, N, Kh, stream())
         return dw
 

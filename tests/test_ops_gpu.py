@@ -1181,7 +1181,7 @@ def test_dense_weight_gradient_deferred_two_stage_between_2048_and_4096_rows(ops
 
 
 @pytest.mark.parametrize('seg', [100, 0], ids=['segments', 'whole'])
-@pytest.mark.parametrize('case', [(12, 400, 601, 256, 21), (16, 256, 70, 32, 5), (11, 400, 601, 256, 21), (9, 460, 128, 64, 9), (5, 1000, 64, 16, 3)])
+@pytest.mark.parametrize('case', [(12, 400, 601, 256, 21), (16, 256, 70, 32, 5), (11, 400, 601, 256, 21), (9, 460, 128, 64, 9), (5, 1000, 64, 16, 3), (8, 512, 96, 48, 13)])
 def test_conv1d_frequency_domain_forward(ops, case, seg):
     """ops._C1FFT (conv1d_fft(True)): the context Conv1D forward as DFT -> per-frequency products -> inverse DFT, each stage a batched
     bf16x6 split product (ptts_dense_bf16x6_batched), overlap-save over segments of S frames with windows of P = S + KW - 1 (no
@@ -1220,7 +1220,8 @@ def test_conv1d_frequency_domain_forward(ops, case, seg):
         # the correlation theorem: dW from X^ and DY^ (an odd number of segments in the batch -- 2 B NS no multiple of 4 -- takes the
         # time-domain kernel)
         nseg = B * (T // ops._C1FFT.segment(T, KW))
-        assert ('ptts_conv1d_freq_wgrad_inverse' in [n for n, _, _ in kt3.durations_ms()]) == (nseg % 2 == 0)
+        last = 'ptts_conv1d_freq_wgrad_inverse' if KW in ops._C1FFT.KWS else 'ptts_conv1d_freq_wgrad_combine'      # (KW = 13: the un-fused fallback)
+        assert (last in [n for n, _, _ in kt3.durations_ms()]) == (nseg % 2 == 0)
         close(bd.grad, dy.sum((0, 1)), rtol=2e-5, atol=2e-4, what='db')
         wr = ref(w, True)
         O.conv1d_ntc(x, wr, b).backward(dy)
