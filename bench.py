@@ -42,6 +42,7 @@ def parse():
     ap.add_argument('--ctx', type=int, default=601)
     ap.add_argument('--errtype', default='WLSWGAN')
     ap.add_argument('--graph', action='store_true', help='capture each step once and replay it as a hipGraph (single stream)')
+    ap.add_argument('--no-hoist', action='store_true', help="do not launch the generator's forward before the critic step of a batch that trains both (cfg.train_wgan_hoist_generator)")
     ap.add_argument('--no-graph', action='store_true', help="never replay a step as a hipGraph (the default, cfg.train_wgan_hipgraph = 'tune', times eager launches against a replay per step kind on the first batch and keeps the faster)")
     ap.add_argument('--eager', action='store_true', help='(default) eager launches; kept for compatibility')
     ap.add_argument('--no-prune', action='store_true', help="also run G's f0/noise branches in the critic step")
@@ -306,6 +307,7 @@ def build_optimizer(args, ctx, spec, nm, batch, errtype, gated=False, bf16=None,
     cfg.train_wgan_stack_real_fake = not args.no_stack
     cfg.train_wgan_reuse_ctx_conv = not args.no_ctx_reuse
     cfg.train_wgan_early_critic = not args.no_early_critic
+    cfg.train_wgan_hoist_generator = (not args.no_hoist) and os.environ.get('PTTS_HOIST', '1') == '1'
     cfg.train_wgan_side_backward_first = os.environ.get('PTTS_SIDE_BWD_FIRST', '0') == '1'     # (A/B switch) the BLSTM's autograd node created last
     cfg.train_wgan_split_bf16 = not args.fp32_mfma
     cfg.train_sync_batchnorm = bool(getattr(args, 'sync_bn', False))
@@ -412,14 +414,16 @@ def main():
     # the same loop with every exact work reduction off: the TF graph's own amount and order of work
     if not args.no_unreduced and not (args.no_prune and args.no_stack and args.no_ctx_reuse and args.no_early_critic):
         saved = (opt._gen_spec, opt.cfg.train_wgan_stack_real_fake, opt.cfg.train_wgan_reuse_ctx_conv, opt.cfg.train_wgan_early_critic)
+        hoist_saved = opt.cfg.train_wgan_hoist_generator
         opt._gen_spec = None
-        opt.cfg.train_wgan_stack_real_fake = opt.cfg.train_wgan_reuse_ctx_conv = opt.cfg.train_wgan_early_critic = False
+        opt.cfg.train_wgan_stack_real_fake = opt.cfg.train_wgan_reuse_ctx_conv = opt.cfg.train_wgan_early_critic = opt.cfg.train_wgan_hoist_generator = False
         opt.cfg.train_wgan_hipgraph = False
         dtu, _ = timed_loop(opt, batches, short, 6, dev)
         opt.cfg.train_wgan_hipgraph = graph_mode
         opt._gen_spec, opt.cfg.train_wgan_stack_real_fake, opt.cfg.train_wgan_reuse_ctx_conv, opt.cfg.train_wgan_early_critic = saved
+        opt.cfg.train_wgan_hoist_generator = hoist_saved
         extra['all_exact_work_reductions_off'] = {
-            'what': "--no-prune --no-stack --no-ctx-reuse --no-early-critic: G's f0/noise branches run in the critic step, critic(real) and "
+            'what': "--no-prune --no-stack --no-ctx-reuse --no-early-critic --no-hoist: G's f0/noise branches run in the critic step, critic(real) and "
                     'critic(fake) as two passes, the generator step recomputes its context Conv1D and waits for the BLSTM before the critic',
             'value': short * B * T * world / dtu, 'unit': 'frames/s', 'ms_per_step': dtu / short * 1e3, 'steps': short}
 
@@ -538,6 +542,7 @@ def main():
                        'prune_dead_generator_branches_in_critic_step': bool(cfg.train_wgan_prune_dead_branches),
                        'stack_real_fake_critic_pass': bool(cfg.train_wgan_stack_real_fake),
                        'reuse_generator_ctx_conv_within_train_on_batch': bool(cfg.train_wgan_reuse_ctx_conv),
+                       'generator_forward_hoisted_before_the_critic_step': bool(cfg.train_wgan_hoist_generator),
                        'ctx_conv1d_forward_and_weight_gradient': (('frequency domain (DFT, per-frequency products, inverse DFT; correlation theorem for the weight gradient), every product a '
                                                                    if (ops._C1FFT.enabled and not cfg.train_wgan_bf16_products) else '') + 'bf16x6 split (bf16 MFMA, fp32 accumulate)'
                                                                   + (' -- ONE bf16 product (time domain)' if cfg.train_wgan_bf16_products else '')) if cfg.train_wgan_split_bf16 else 'fp32 MFMA',

@@ -583,7 +583,9 @@ class Model(nn.Module):
             vals = [values[id(p)] for p in n.parents]
             if use_side and getattr(n, 'stream', 0):
                 if side is None:
-                    side = self._variant_streams(2)[0]
+                    # a stream of its own kind: the branch may still be running when the caller evaluates ANOTHER model on the variant
+                    # streams (the generator's forward hoisted in front of the critic step, optimizertts_wgan.device_step)
+                    side = side_streams(1, 'branch')[0]
                     cur = torch.cuda.current_stream()
                 if id(n) in pre:
                     # launched in the earlier call; this one only creates the autograd node (no kernel reads the parents now)

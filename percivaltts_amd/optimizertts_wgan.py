@@ -137,6 +137,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         cfg.train_wgan_stack_real_fake = True        # critic(real) and critic(fake) as one stacked 2B pass (exact: no BatchNorm)
         cfg.train_wgan_reuse_ctx_conv = True         # generator step reuses the critic step's G-context-Conv1D product (same batch)
         cfg.train_wgan_early_critic = True           # generator step: critic starts on the spectral branch, BLSTM joins for the LS term
+        cfg.train_wgan_hoist_generator = True        # a batch that trains both: G's forward (it does not depend on the critic) is launched BEFORE the critic step -- its BLSTM chain runs under that step -- and the critic step takes its fake sample from it
         cfg.train_wgan_graph_split = False           # hipGraph of forward + backward only, update launched eagerly (what data parallelism uses; settable for tests)
         cfg.train_wgan_async_update = None           # all-reduce + Adam on a communication stream, overlapped with the next forward that does not need the weights (None: on when world > 1)
         cfg.train_sync_batchnorm = False             # data parallelism: BatchNorm statistics over all ranks (SyncBN) instead of per rank
@@ -272,21 +273,50 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             self._critic_per_sample = ok
         return ok
 
-    def generator_loss(self, X, Y, training=True):
+    def _can_split_generator(self):
+        m = self._model.kerasmodel
+        return getattr(self, '_gen_spec', None) is not None and getattr(self._model, 'node_spec', None) is not None and m.single_output and \
+            bool(getattr(self.cfg, 'train_wgan_early_critic', True))
+
+    def generator_forward_early(self, X, training=True):
+        """The generator's forward up to (not including) its final concatenation, with the autograd tape: everything of the generator
+        step that does not depend on the critic.  `device_step` launches it BEFORE the critic step of a batch that trains both networks
+        (reference optimizertts_wgan.py:225-240: critic step, then generator step, on the same batch; G is not touched by the critic's
+        update, so the values are the same): the BLSTM's 400-step chain on its side stream then runs under the critic step instead of in
+        front of the generator step's critic evaluation, and the critic step's fake sample -- G's spectral branch on the same batch and
+        weights -- is taken from it instead of being computed again."""
+        m = self._model.kerasmodel
+        self._wait_update('generator')
+        feed = {id(m.inputs[0]): X}
+        values = m._run(feed, training, None, hold={id(m.outputs[0])})
+        return feed, values
+
+    def fake_from_early(self, X, pre):
+        """The critic step's fake sample from the hoisted forward (the spectral branch, detached; the other columns are not read)."""
+        _, values = pre
+        spec = kl.to_tensor(values[id(self._model.node_spec)]).detach()
+        voc = self._model.vocoder
+        fake = torch.zeros(X.shape[0], X.shape[1], voc.featuressize(), dtype=torch.float32, device=X.device)
+        fake[:, :, 1:1 + voc.specsize()] = spec
+        return fake
+
+    def generator_loss(self, X, Y, training=True, pre=None):
         m = self._model.kerasmodel
         node_spec = getattr(self._model, 'node_spec', None)
         self._wait_update('generator')
-        if getattr(self, '_gen_spec', None) is not None and node_spec is not None and m.single_output and \
-                bool(getattr(self.cfg, 'train_wgan_early_critic', True)):
+        if self._can_split_generator():
             # The critic reads the spectral columns only (the condition under which the critic step prunes the other
             # branches).  It is therefore fed the spectral branch as soon as that exists, while the latency-bound f0
             # branch (BLSTM, side stream) still runs; the final concatenation -- the join with the side stream -- is
             # needed by the least-squares term alone and comes last.  Same values.  (cfg.train_wgan_side_backward_first creates
             # the BLSTM's autograd node last -- launches first, layers.Model._run -- so that its backward chain is enqueued
             # first: the chain then ends 1 ms earlier but the step does not, tools/gen_timeline.py events; off.)
-            feed = {id(m.inputs[0]): X}
             out_node = m.outputs[0]
-            values = m._run(feed, training, None, hold={id(out_node)})
+            if pre is not None:
+                feed, values = pre
+            else:
+                feed = {id(m.inputs[0]): X}
+                values = m._run(feed, training, None, hold={id(out_node)})
             ops._lstm_mark('G_spec_fwd_end')
             spec = kl.to_tensor(values[id(node_spec)])
             if ops.lstm_trace is not None and spec.requires_grad:
@@ -351,8 +381,9 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             run()
             self._pending[kind] = self._comm.record_event()
 
-    def _critic_grads(self, X, Y, alpha=None):
-        fake = self._fake_sample(X, True)      # first: it does not need the critic's weights (a pending update may still run)
+    def _critic_grads(self, X, Y, alpha=None, fake=None):
+        if fake is None:
+            fake = self._fake_sample(X, True)      # first: it does not need the critic's weights (a pending update may still run)
         self._wait_update('critic')
         self.critic_opti.zero_grad()
         with ops.deferred_weight_grads():       # the Dense layers' weight gradients run as one grouped launch at exit
@@ -360,19 +391,19 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             total.backward()
         return total.detach()
 
-    def critic_step(self, X, Y, alpha=None):
-        total = self._critic_grads(X, Y, alpha)
+    def critic_step(self, X, Y, alpha=None, fake=None):
+        total = self._critic_grads(X, Y, alpha, fake)
         self._update('critic')
         return total
 
-    def _generator_grads(self, X, Y):
+    def _generator_grads(self, X, Y, pre=None):
         self._wait_update('generator')
         self.gen_opti.zero_grad()
         cps = self.critic_opti.flat.params
         for p in cps: p.requires_grad_(False)      # frozen critic (:160-161)
         try:
             with ops.deferred_weight_grads():
-                total, _ = self.generator_loss(X, Y, training=True)
+                total, _ = self.generator_loss(X, Y, training=True, pre=pre)
                 ops._lstm_mark('loss')
                 total.backward()
                 ops._lstm_mark('bwd_enqueued')
@@ -381,8 +412,8 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             for p in cps: p.requires_grad_(True)
         return total.detach()
 
-    def generator_step(self, X, Y):
-        total = self._generator_grads(X, Y)
+    def generator_step(self, X, Y, pre=None):
+        total = self._generator_grads(X, Y, pre)
         self._update('generator')
         return total
 
@@ -438,20 +469,24 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         return self._graph_choice[key]
 
     # hipGraph replay of a whole step: static input buffers, one capture per (kind, shape)
-    def _graphed(self, kind, X, Y, alpha=None):
+    def _graphed(self, kind, X, Y, alpha=None, fake=None):
         """hipGraph replay of a step.  One process: the whole step (forward, backward, Adam) is one graph.  Data parallel: the
-        graph ends with the backward pass -- the gradient all-reduce cannot be captured -- and the update follows eagerly."""
+        graph ends with the backward pass -- the gradient all-reduce cannot be captured -- and the update follows eagerly.
+        `fake` (critic step): the fake sample is an INPUT of the graph (a second graph per shape, without the frozen generator's
+        forward) -- the batches on which the generator's forward was hoisted in front of the critic step."""
         whole = self.world == 1 and not bool(getattr(self.cfg, 'train_wgan_graph_split', False))
-        key = (kind, tuple(X.shape), tuple(Y.shape), whole)
+        with_fake = kind == 'critic' and fake is not None
+        key = (kind, tuple(X.shape), tuple(Y.shape), whole, with_fake)
         ent = self._graphs.get(key)
         if ent is None:
             snap = self._state_snapshot()       # the warm-up below runs real steps: the state is put back before the first replay
             sX, sY = X.clone(), Y.clone()
             sA = torch.rand(X.shape[0], device=X.device, dtype=torch.float32)
+            sF = fake.detach().clone() if with_fake else None
             if whole:
-                fn = (lambda: self.critic_step(sX, sY, sA)) if kind == 'critic' else (lambda: self.generator_step(sX, sY))
+                fn = (lambda: self.critic_step(sX, sY, sA, sF)) if kind == 'critic' else (lambda: self.generator_step(sX, sY))
             else:
-                fn = (lambda: self._critic_grads(sX, sY, sA)) if kind == 'critic' else (lambda: self._generator_grads(sX, sY))
+                fn = (lambda: self._critic_grads(sX, sY, sA, sF)) if kind == 'critic' else (lambda: self._generator_grads(sX, sY))
             from . import layers
             # the graph is captured on one stream: the evaluations' side streams would become cross-stream edges of the capture
             saved_streams = (self.cfg.train_wgan_parallel_streams, getattr(self._model.kerasmodel, 'parallel_branches', False))
@@ -475,11 +510,13 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
                 out = fn()
             ops.clear_caches()         # ... and the graph's private copies are not for eager code
             self.cfg.train_wgan_parallel_streams, self._model.kerasmodel.parallel_branches = saved_streams
-            ent = (g, sX, sY, sA, out)
+            ent = (g, sX, sY, sA, out, sF)
             self._graphs[key] = ent
             self._state_restore(snap)
-        g, sX, sY, sA, out = ent
+        g, sX, sY, sA, out, sF = ent
         sX.copy_(X); sY.copy_(Y)
+        if sF is not None:
+            sF.copy_(fake)
         if kind == 'critic':
             if alpha is None: sA.uniform_(0.0, 1.0)
             else: sA.copy_(alpha.reshape(-1))
@@ -526,10 +563,17 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         use_graph = graph_c or graph_g
         ops.conv1d_cache(gen_too and not use_graph and bool(getattr(self.cfg, 'train_wgan_reuse_ctx_conv', True)))
         try:
-            lc = self._graphed('critic', X, Y, alpha) if graph_c else self.critic_step(X, Y, alpha)
+            pre = fake = None
+            if gen_too and not graph_g and bool(getattr(self.cfg, 'train_wgan_hoist_generator', True)) and self._can_split_generator():
+                # G's forward first (see generator_forward_early); inside deferred_weight_grads() so that its layers note their
+                # gradient targets as they do inside the generator step
+                with ops.deferred_weight_grads():
+                    pre = self.generator_forward_early(X, training=True)
+                fake = self.fake_from_early(X, pre)
+            lc = self._graphed('critic', X, Y, alpha, fake) if graph_c else self.critic_step(X, Y, alpha, fake)
             lg = None
             if gen_too:
-                lg = self._graphed('generator', X, Y) if graph_g else self.generator_step(X, Y)
+                lg = self._graphed('generator', X, Y) if graph_g else self.generator_step(X, Y, pre)
                 self.generator_updates += 1
         finally:
             ops.conv1d_cache(False)

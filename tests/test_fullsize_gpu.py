@@ -346,6 +346,7 @@ def test_generator_step_reuses_the_context_conv_of_the_critic_step(setup):
     snap = snapshot()
     torch.manual_seed(7)
     results = []
+    opt.cfg.train_wgan_hoist_generator = False      # (the plain order: with the generator's forward hoisted -- the default, tested below -- there is nothing left to reuse)
     for reuse in (True, False):
         restore(snap)
         for (k, t), (_, t0) in zip([(k, t) for k, t in opt._model.kerasmodel.weights() if 'moving' in k], bn_state):
@@ -360,6 +361,7 @@ def test_generator_step_reuses_the_context_conv_of_the_critic_step(setup):
                     (name == 'ptts_dense_bf16x6_batched' and tag[0] == 'freq'))
         results.append((opt.gen_opti.flat.grad.detach().clone(), opt.critic_opti.flat.grad.detach().clone(), nconv))
     opt.cfg.train_wgan_reuse_ctx_conv = True
+    opt.cfg.train_wgan_hoist_generator = True
     restore(snap)
     assert results[0][2] == results[1][2] - 1, 'one context-Conv1D forward fewer with the cache: {} vs {}'.format(results[0][2], results[1][2])
     # the gradients the two Adam steps consumed (still in the flat buffers).  Two runs of the same step already differ by
@@ -367,6 +369,51 @@ def test_generator_step_reuses_the_context_conv_of_the_critic_step(setup):
     # themselves are a poor yardstick here: Adam's first step moves every weight by lr*sign(g)
     assert rel_l2(results[0][1], results[1][1]) < 1e-4          # the critic's gradient does not depend on the cache
     assert rel_l2(results[0][0], results[1][0]) < 5e-4          # the generator's gradient
+
+
+def test_hoisted_generator_forward_gives_the_same_train_step(setup):
+    """cfg.train_wgan_hoist_generator (default on): on a batch that trains both networks the generator's forward -- it does not depend
+    on the critic -- is launched before the critic step (its BLSTM chain then runs under that step), and the critic step takes its fake
+    sample from it.  Same arithmetic on the same operands: both losses, both gradients and the BatchNorm moving statistics as with
+    the plain order critic step -> generator step (reference optimizertts_wgan.py:225-240), within the run-to-run spread of a step."""
+    from percivaltts_amd import ops, _hip
+    cfg, opt, crit, X, Y = setup
+    state = (opt.critic_opti.flat.flat, opt.critic_opti.m, opt.critic_opti.v, opt.critic_opti.step_count,
+             opt.gen_opti.flat.flat, opt.gen_opti.m, opt.gen_opti.v, opt.gen_opti.step_count)
+    snap = [t.detach().clone() for t in state]
+    moving = [t for k, t in opt._model.kerasmodel.weights() if 'moving' in k]
+    moving0 = [t.detach().clone() for t in moving]
+    results = []
+    try:
+        for hoist in (True, False):
+            for dst, src in zip(state, snap):
+                dst.copy_(src)
+            for dst, src in zip(moving, moving0):
+                dst.copy_(src)
+            opt.critic_opti.flat.epoch += 1; opt.gen_opti.flat.epoch += 1
+            opt.cfg.train_wgan_hoist_generator = hoist
+            torch.manual_seed(5)                       # same interpolation weights
+            with _hip.KernelTimer() as kt:
+                lc, lg = opt.device_step(0, X, Y)      # batchid 0: critic step + generator step
+            torch.cuda.synchronize()
+            names = [r[0] for r in kt.records]
+            results.append((float(lc), float(lg), opt.critic_opti.flat.grad.detach().clone(), opt.gen_opti.flat.grad.detach().clone(),
+                            [t.detach().clone() for t in moving], names.count('ptts_lstm_fwd'), names.count('ptts_conv2d_fwd')))
+    finally:
+        opt.cfg.train_wgan_hoist_generator = True
+        for dst, src in zip(state, snap):
+            dst.copy_(src)
+        for dst, src in zip(moving, moving0):
+            dst.copy_(src)
+        opt.critic_opti.flat.epoch += 1; opt.gen_opti.flat.epoch += 1
+    (lc1, lg1, gc1, gg1, mv1, nl1, nc1), (lc0, lg0, gc0, gg0, mv0, nl0, nc0) = results
+    assert nl1 == 1 and nl0 == 1                      # the BLSTM forward runs once either way ...
+    assert nc1 < nc0, (nc1, nc0)                      # ... and the hoisted form does not evaluate G's spectral branch a second time for the fake sample
+    assert abs(lc1 - lc0) <= 1e-4 * max(1.0, abs(lc0)) and abs(lg1 - lg0) <= 1e-4 * max(1.0, abs(lg0)), (lc1, lc0, lg1, lg0)
+    assert rel_l2(gc1, gc0) < 3e-4, rel_l2(gc1, gc0)
+    assert rel_l2(gg1, gg0) < 1e-3, rel_l2(gg1, gg0)
+    for a, b in zip(mv1, mv0):
+        close(a, b, 1e-5, 1e-6, 'BatchNorm moving statistics after the step')
 
 
 def test_train_step_with_the_bf16x6_context_conv_matches_the_fp32_one(setup):

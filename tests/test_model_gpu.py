@@ -269,7 +269,7 @@ def test_hipgraph_replay_matches_eager():
             opt._graphed('critic', Xd, Yd)
             crit.model.set_weights([w.numpy() for w in cw])
             opt.critic_opti.m.zero_(); opt.critic_opti.v.zero_(); opt.critic_opti.step_count.zero_()
-            g, sX, sY, sA, out = opt._graphs[('critic', tuple(Xd.shape), tuple(Yd.shape), True)]
+            g, sX, sY, sA, out, _ = opt._graphs[('critic', tuple(Xd.shape), tuple(Yd.shape), True, False)]
             losses = []
             for _ in range(3):
                 sA.copy_(ald); g.replay(); losses.append(float(out.item()))
