@@ -541,14 +541,18 @@ class Model(nn.Module):
                     s |= self.deps[id(p)]
                 self.deps[id(n)] = s
 
-    def _run(self, feed, training, memo, values=None, only_dep=None, hold=None):
+    def _run(self, feed, training, memo, values=None, only_dep=None, hold=None, cut_side=False):
         """Evaluate the nodes not yet in `values`.  `hold` (ids of nodes): these and everything that depends on them is
         left for a later call with the same `values` -- e.g. the generator's final concatenation, so that the critic can
         start on the spectral part while the side-stream branch still runs; the side-stream bookkeeping travels in
         values['__side__'].  Nodes tagged `stream = 1` (an independent branch such as the
         generator's latency-bound BLSTM) are enqueued on a side HIP stream when `self.parallel_branches` is set, so
         that they overlap with the rest of the graph; autograd replays the same streams in the backward pass (and,
-        processing nodes in reverse creation order, enqueues the main-stream backward first)."""
+        processing nodes in reverse creation order, enqueues the main-stream backward first).
+        `cut_side`: a side branch gets its main-stream inputs as detached leaves (values['__cuts__'] = [(input tensor, leaf)]), so that
+        the caller can run the branch's backward pass on its own, early, and hand the leaves' gradients to the rest of the graph later
+        (optimizertts_wgan.generator_forward_early); values['__side_ev__'] marks the end of the branch's FORWARD on its stream -- the
+        join then waits for that event, not for whatever else the caller has put on the stream since."""
         values = {} if values is None else values
         use_side = bool(getattr(self, 'parallel_branches', False)) and torch.cuda.is_available()
         side, cur, pending = None, None, False
@@ -601,7 +605,23 @@ class Model(nn.Module):
                         side.wait_event(start_ev)
                     else:
                         side.wait_stream(cur)
-                if late and hold and torch.is_grad_enabled() and hasattr(n.layer, 'precompute'):
+                if cut_side and torch.is_grad_enabled() and not any(id(p) in on_side for p in n.parents):
+                    cvals = []
+                    for p, v in zip(n.parents, vals):
+                        t = v.tensor() if isinstance(v, LazyConcat) else to_tensor(v)
+                        if torch.is_tensor(t) and t.requires_grad:
+                            # the main graph goes on through an injection node (later consumers of this value take it from there):
+                            # the gradient of the cut branch is added where the engine reaches that node, and only there does the
+                            # main stream wait for the branch
+                            holder = {}
+                            t = ops.grad_inject(t, holder)
+                            values[id(p)] = t
+                            leaf = t.detach().requires_grad_(True)
+                            values.setdefault('__cuts__', []).append((t, leaf, holder))
+                            t = leaf
+                        cvals.append(t)
+                    vals = cvals
+                if late and hold and not cut_side and torch.is_grad_enabled() and hasattr(n.layer, 'precompute'):
                     # a later call finishes the graph (`hold`): launch now, create the node then -- after everything the caller
                     # evaluates in between (the critic), i.e. with the highest priority of the backward pass
                     with torch.cuda.stream(side):
@@ -615,7 +635,11 @@ class Model(nn.Module):
                 pending = True
                 continue
             if pending and any(id(p) in on_side for p in n.parents):
-                cur.wait_stream(side)
+                ev = values.pop('__side_ev__', None)
+                if ev is not None:
+                    cur.wait_event(ev)
+                else:
+                    cur.wait_stream(side)
                 pending = False
                 for p in n.parents:
                     if id(p) in on_side:
@@ -627,6 +651,8 @@ class Model(nn.Module):
         if held:
             values['__side__'] = (on_side, pending, side, cur)      # the join happens in the call that finishes the graph
             values['__pre__'] = pre
+            if cut_side and pending and side is not None:
+                values['__side_ev__'] = side.record_event()
         elif pending:
             cur.wait_stream(side)
         return values

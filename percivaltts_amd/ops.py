@@ -146,6 +146,26 @@ def deferred_weight_grads():
         _Deferred.streams = []
 
 
+def deferred_detach():
+    """Take the queued weight-gradient products and the list of streams to join out of the current deferred_weight_grads() context
+    (they are handed to a later context with deferred_attach): the early backward pass of a side branch must not make the main stream
+    wait for that branch when its context closes."""
+    st = (_Deferred.items, _Deferred.conv_items, _Deferred.streams)
+    _Deferred.items, _Deferred.conv_items, _Deferred.streams = [], [], []
+    return st
+
+
+def deferred_attach(st):
+    if st is None:
+        return
+    items, conv_items, streams = st
+    _Deferred.items = list(items) + _Deferred.items
+    _Deferred.conv_items = list(conv_items) + _Deferred.conv_items
+    for q in streams:
+        if all(q.cuda_stream != r.cuda_stream for r in _Deferred.streams):
+            _Deferred.streams.append(q)
+
+
 def grad_target(p):
     """The persistent gradient buffer behind parameter `p` (a leaf with .grad allocated, or a contiguous row slice of
     one), as a tensor view with p's shape -- or None."""
@@ -1767,6 +1787,31 @@ class _GradGateFn(torch.autograd.Function):
 
 def grad_gate(x):
     return _GradGateFn.apply(x)
+
+
+class _GradInjectFn(torch.autograd.Function):
+    """Identity in the forward pass; in the backward pass the gradient that another, EARLIER backward pass left in `holder`
+    (holder['grad'], made on another stream: holder['event']) is added to the incoming one.  The wait for that stream happens here,
+    when the engine reaches this node -- not before the whole backward pass."""
+    @staticmethod
+    def forward(ctx, x, holder):
+        ctx.holder = holder
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        h = ctx.holder
+        extra = h.get('grad')
+        if extra is None:
+            return g, None
+        if h.get('event') is not None:
+            torch.cuda.current_stream().wait_event(h['event'])
+        h['grad'] = None
+        return (extra if g is None else g + extra), None
+
+
+def grad_inject(x, holder):
+    return _GradInjectFn.apply(x, holder)
 
 
 def lstm_launch(x, W, U, b, reverse=False):

@@ -137,6 +137,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         cfg.train_wgan_stack_real_fake = True        # critic(real) and critic(fake) as one stacked 2B pass (exact: no BatchNorm)
         cfg.train_wgan_reuse_ctx_conv = True         # generator step reuses the critic step's G-context-Conv1D product (same batch)
         cfg.train_wgan_early_critic = True           # generator step: critic starts on the spectral branch, BLSTM joins for the LS term
+        cfg.train_wgan_hoist_side_backward = False   # ... and the BLSTM branch's BACKWARD too (its output is read by the least-squares term only: the branch is cut out of the tape, run on its own, its gradient injected at the cut).  Measured +1 %: the chains then contend with the critic step; opt-in
         cfg.train_wgan_hoist_generator = True        # a batch that trains both: G's forward (it does not depend on the critic) is launched BEFORE the critic step -- its BLSTM chain runs under that step -- and the critic step takes its fake sample from it
         cfg.train_wgan_graph_split = False           # hipGraph of forward + backward only, update launched eagerly (what data parallelism uses; settable for tests)
         cfg.train_wgan_async_update = None           # all-reduce + Adam on a communication stream, overlapped with the next forward that does not need the weights (None: on when world > 1)
@@ -278,7 +279,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         return getattr(self, '_gen_spec', None) is not None and getattr(self._model, 'node_spec', None) is not None and m.single_output and \
             bool(getattr(self.cfg, 'train_wgan_early_critic', True))
 
-    def generator_forward_early(self, X, training=True):
+    def generator_forward_early(self, X, Y=None, training=True):
         """The generator's forward up to (not including) its final concatenation, with the autograd tape: everything of the generator
         step that does not depend on the critic.  `device_step` launches it BEFORE the critic step of a batch that trains both networks
         (reference optimizertts_wgan.py:225-240: critic step, then generator step, on the same batch; G is not touched by the critic's
@@ -288,7 +289,39 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         m = self._model.kerasmodel
         self._wait_update('generator')
         feed = {id(m.inputs[0]): X}
-        values = m._run(feed, training, None, hold={id(m.outputs[0])})
+        early_bwd = Y is not None and self._errtype == 'WLSWGAN' and bool(getattr(m, 'parallel_branches', False)) and \
+            bool(getattr(self.cfg, 'train_wgan_hoist_side_backward', False))
+        values = m._run(feed, training, None, hold={id(m.outputs[0])}, cut_side=early_bwd)
+        self._gen_cuts = []
+        if early_bwd and values.get('__cuts__') and '__side__' in values:
+            # The side branch's BACKWARD as well: its output (f0) is read by the least-squares term only -- the critic slices the
+            # spectral columns -- and that term is a mean of per-element squares, so d loss / d f0 needs nothing but f0 and Y.
+            # The term is evaluated on a tensor with the branch's output in its columns and zeros elsewhere (the value is
+            # discarded, the gradient w.r.t. the branch's columns is the true one), on the branch's stream, and backpropagated to
+            # the cut: the whole 2 x 400-step recurrence chain then runs under the critic step.  The leaves' gradients join the
+            # rest of the graph in _generator_grads.
+            on_side, pending, side, cur = values['__side__']
+            out_node = m.outputs[0]
+            sp = [p for p in out_node.parents if id(p) in on_side]
+            if sp and all(id(p) in values for p in out_node.parents if id(p) in on_side):
+                with torch.cuda.stream(side):
+                    cols = []
+                    for p in out_node.parents:
+                        if id(p) in on_side:
+                            cols.append(kl.to_tensor(values[id(p)]))
+                        else:
+                            cols.append(torch.zeros(X.shape[0], X.shape[1], int(p.shape[-1]), dtype=torch.float32, device=X.device))
+                    pred_tmp = torch.cat(cols, dim=-1)
+                    l_tmp = specweighted_lse_loss(Y, pred_tmp, self._w_ls)
+                    l_tmp.backward()
+                    for p in sp:                               # the branch is done with: the join sees constants
+                        values[id(p)] = kl.to_tensor(values[id(p)]).detach()
+                    ev = side.record_event()
+                    for t, leaf, holder in values['__cuts__']:
+                        if leaf.grad is not None:
+                            holder['grad'], holder['event'] = leaf.grad, ev
+                            self._gen_cuts.append(t)
+        values.pop('__cuts__', None)
         return feed, values
 
     def fake_from_early(self, X, pre):
@@ -398,14 +431,25 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
 
     def _generator_grads(self, X, Y, pre=None):
         self._wait_update('generator')
-        self.gen_opti.zero_grad()
+        if pre is None:
+            self.gen_opti.zero_grad()          # (a hoisted forward may already have run a side branch's backward: device_step zeroed before it)
         cps = self.critic_opti.flat.params
         for p in cps: p.requires_grad_(False)      # frozen critic (:160-161)
         try:
             with ops.deferred_weight_grads():
+                if pre is not None:
+                    ops.deferred_attach(getattr(self, '_gen_deferred', None))
+                    self._gen_deferred = None
                 total, _ = self.generator_loss(X, Y, training=True, pre=pre)
                 ops._lstm_mark('loss')
-                total.backward()
+                cuts = getattr(self, '_gen_cuts', None) if pre is not None else None
+                if cuts:
+                    # the injection nodes at the side branch's cut add the gradient its early backward left behind; as extra roots (with a
+                    # zero gradient) they are reached even if no later layer consumed them
+                    torch.autograd.backward([total] + cuts, [None] + [torch.zeros_like(t) for t in cuts])
+                    self._gen_cuts = None
+                else:
+                    total.backward()
                 ops._lstm_mark('bwd_enqueued')
             ops._lstm_mark('wgrads_flushed')
         finally:
@@ -567,10 +611,14 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             if gen_too and not graph_g and bool(getattr(self.cfg, 'train_wgan_hoist_generator', True)) and self._can_split_generator():
                 # G's forward first (see generator_forward_early); inside deferred_weight_grads() so that its layers note their
                 # gradient targets as they do inside the generator step
+                self.gen_opti.zero_grad()
                 with ops.deferred_weight_grads():
-                    pre = self.generator_forward_early(X, training=True)
+                    pre = self.generator_forward_early(X, Y, training=True)
+                    self._gen_deferred = ops.deferred_detach()      # (joined and flushed by the generator step's own context)
                 fake = self.fake_from_early(X, pre)
+            ops._lstm_mark('critic_step_begin')
             lc = self._graphed('critic', X, Y, alpha, fake) if graph_c else self.critic_step(X, Y, alpha, fake)
+            ops._lstm_mark('critic_step_end')
             lg = None
             if gen_too:
                 lg = self._graphed('generator', X, Y) if graph_g else self.generator_step(X, Y, pre)

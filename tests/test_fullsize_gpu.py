@@ -384,14 +384,19 @@ def test_hoisted_generator_forward_gives_the_same_train_step(setup):
     moving = [t for k, t in opt._model.kerasmodel.weights() if 'moving' in k]
     moving0 = [t.detach().clone() for t in moving]
     results = []
+    branches0 = opt._model.kerasmodel.parallel_branches
     try:
-        for hoist in (True, False):
+        # hoisted with the BLSTM branch on its side stream (then its BACKWARD pass is hoisted as well: the branch is cut out of the
+        # tape and run on its own, the cut's gradient joins the main backward pass as an extra root), hoisted on one stream, plain
+        for hoist, branches in ((True, True), (True, False), (False, False)):
             for dst, src in zip(state, snap):
                 dst.copy_(src)
             for dst, src in zip(moving, moving0):
                 dst.copy_(src)
             opt.critic_opti.flat.epoch += 1; opt.gen_opti.flat.epoch += 1
             opt.cfg.train_wgan_hoist_generator = hoist
+            opt.cfg.train_wgan_hoist_side_backward = branches        # (opt-in; needs the branch on its side stream)
+            opt._model.kerasmodel.parallel_branches = branches
             torch.manual_seed(5)                       # same interpolation weights
             with _hip.KernelTimer() as kt:
                 lc, lg = opt.device_step(0, X, Y)      # batchid 0: critic step + generator step
@@ -401,19 +406,22 @@ def test_hoisted_generator_forward_gives_the_same_train_step(setup):
                             [t.detach().clone() for t in moving], names.count('ptts_lstm_fwd'), names.count('ptts_conv2d_fwd')))
     finally:
         opt.cfg.train_wgan_hoist_generator = True
+        opt.cfg.train_wgan_hoist_side_backward = False
+        opt._model.kerasmodel.parallel_branches = branches0
         for dst, src in zip(state, snap):
             dst.copy_(src)
         for dst, src in zip(moving, moving0):
             dst.copy_(src)
         opt.critic_opti.flat.epoch += 1; opt.gen_opti.flat.epoch += 1
-    (lc1, lg1, gc1, gg1, mv1, nl1, nc1), (lc0, lg0, gc0, gg0, mv0, nl0, nc0) = results
-    assert nl1 == 1 and nl0 == 1                      # the BLSTM forward runs once either way ...
-    assert nc1 < nc0, (nc1, nc0)                      # ... and the hoisted form does not evaluate G's spectral branch a second time for the fake sample
-    assert abs(lc1 - lc0) <= 1e-4 * max(1.0, abs(lc0)) and abs(lg1 - lg0) <= 1e-4 * max(1.0, abs(lg0)), (lc1, lc0, lg1, lg0)
-    assert rel_l2(gc1, gc0) < 3e-4, rel_l2(gc1, gc0)
-    assert rel_l2(gg1, gg0) < 1e-3, rel_l2(gg1, gg0)
-    for a, b in zip(mv1, mv0):
-        close(a, b, 1e-5, 1e-6, 'BatchNorm moving statistics after the step')
+    (lc0, lg0, gc0, gg0, mv0, nl0, nc0) = results[2]
+    for what, (lc1, lg1, gc1, gg1, mv1, nl1, nc1) in zip(('hoisted, branch backward hoisted too', 'hoisted'), results[:2]):
+        assert nl1 == 1 and nl0 == 1                      # the BLSTM forward runs once either way ...
+        assert nc1 < nc0, (what, nc1, nc0)                # ... and the hoisted form does not evaluate G's spectral branch a second time for the fake sample
+        assert abs(lc1 - lc0) <= 1e-4 * max(1.0, abs(lc0)) and abs(lg1 - lg0) <= 1e-4 * max(1.0, abs(lg0)), (what, lc1, lc0, lg1, lg0)
+        assert rel_l2(gc1, gc0) < 3e-4, (what, rel_l2(gc1, gc0))
+        assert rel_l2(gg1, gg0) < 1e-3, (what, rel_l2(gg1, gg0))
+        for a, b in zip(mv1, mv0):
+            close(a, b, 1e-5, 1e-6, 'BatchNorm moving statistics after the step (' + what + ')')
 
 
 def test_train_step_with_the_bf16x6_context_conv_matches_the_fp32_one(setup):
