@@ -617,11 +617,17 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
                     self._gen_deferred = ops.deferred_detach()      # (joined and flushed by the generator step's own context)
                 fake = self.fake_from_early(X, pre)
             ops._lstm_mark('critic_step_begin')
-            lc = self._graphed('critic', X, Y, alpha, fake) if graph_c else self.critic_step(X, Y, alpha, fake)
+            if graph_c:
+                lc = self._graphed('critic', X, Y, alpha, fake)
+            else:
+                lc = self.critic_step(X, Y, alpha) if fake is None else self.critic_step(X, Y, alpha, fake)
             ops._lstm_mark('critic_step_end')
             lg = None
             if gen_too:
-                lg = self._graphed('generator', X, Y) if graph_g else self.generator_step(X, Y, pre)
+                if graph_g:
+                    lg = self._graphed('generator', X, Y)
+                else:
+                    lg = self.generator_step(X, Y) if pre is None else self.generator_step(X, Y, pre)
                 self.generator_updates += 1
         finally:
             ops.conv1d_cache(False)
