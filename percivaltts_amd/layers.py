@@ -587,9 +587,12 @@ class Model(nn.Module):
             vals = [values[id(p)] for p in n.parents]
             if use_side and getattr(n, 'stream', 0):
                 if side is None:
-                    # a stream of its own kind: the branch may still be running when the caller evaluates ANOTHER model on the variant
-                    # streams (the generator's forward hoisted in front of the critic step, optimizertts_wgan.device_step)
-                    side = side_streams(1, 'branch')[0]
+                    # NOT the first side stream: the branch may still be running when the caller evaluates ANOTHER model whose variants use
+                    # it (the generator's forward hoisted in front of the critic step, optimizertts_wgan.device_step; the stacked critic
+                    # pass needs one).  The second of the shared pool, not a stream of a kind of its own: one more HIP stream in the
+                    # process (the fifth busy one) halved the speed of the step that runs the BLSTM in every critic step
+                    # (bench.py's all_exact_work_reductions_off: 17.8 against 10.9 ms).
+                    side = side_streams(2)[1]
                     cur = torch.cuda.current_stream()
                 if id(n) in pre:
                     # launched in the earlier call; this one only creates the autograd node (no kernel reads the parents now)
