@@ -1814,6 +1814,34 @@ def grad_inject(x, holder):
     return _GradInjectFn.apply(x, holder)
 
 
+class _LSTMRing(object):
+    """Address-stable buffers for the recurrences when they are replayed as hipGraphs (ptts_set_lstm_graph / PTTS_LSTM_GRAPH=1: the
+    graphs are keyed on the operands' addresses, and buffers taken from the caching allocator come back at other addresses in a third of
+    the calls).  Two sets per shape and stream, used in turn; a set is handed out again only when every view given out of it is dead
+    (weak references) -- otherwise fresh memory is used, which merely costs a capture."""
+    enabled = os.environ.get('PTTS_LSTM_GRAPH', '0') == '1'
+    slots = {}
+
+    @classmethod
+    def take(cls, key, shapes, dev):
+        import weakref
+        ring = cls.slots.setdefault(key, {'i': 0, 'sets': [None, None]})
+        i = ring['i']
+        ring['i'] = 1 - i
+        st = ring['sets'][i]
+        n = [int(torch.Size(sh).numel()) for sh in shapes]
+        if st is not None and any(r() is not None for r in st['refs']):
+            return [torch.empty(sh, dtype=torch.float32, device=dev) for sh in shapes]       # still in use: not this time
+        if st is None:
+            st = ring['sets'][i] = {'buf': torch.empty(sum(n), dtype=torch.float32, device=dev), 'refs': []}
+        out, off = [], 0
+        for sh, k in zip(shapes, n):
+            out.append(st['buf'][off:off + k].view(sh))
+            off += k
+        st['refs'] = [weakref.ref(t) for t in out]
+        return out
+
+
 def lstm_launch(x, W, U, b, reverse=False):
     """The forward launches of LSTMFn (input projection + the T-step recurrence) with no autograd node: (h, c, gates)."""
     f32c(x, 'lstm.x'); f32c(W); f32c(U); f32c(b)
@@ -1821,11 +1849,15 @@ def lstm_launch(x, W, U, b, reverse=False):
     ndir, H, G4 = U.shape
     assert G4 == 4 * H and W.shape == (In, ndir * G4)
     dev = x.device
-    xproj = torch.empty((B, T, ndir * G4), dtype=torch.float32, device=dev)
+    if _LSTMRing.enabled:
+        xproj, h, c, gates = _LSTMRing.take(('fwd', B, T, ndir, H, _hip.stream_id()),
+                                            [(B, T, ndir * G4), (B, T, ndir * H), (B, T, ndir * H), (B, T, ndir * G4)], dev)
+    else:
+        xproj = torch.empty((B, T, ndir * G4), dtype=torch.float32, device=dev)
+        h = torch.empty((B, T, ndir * H), dtype=torch.float32, device=dev)
+        c = torch.empty((B, T, ndir * H), dtype=torch.float32, device=dev)
+        gates = torch.empty((B, T, ndir * G4), dtype=torch.float32, device=dev)
     gemm_raw(x, W, xproj, B * T, ndir * G4, In, bias=b)
-    h = torch.empty((B, T, ndir * H), dtype=torch.float32, device=dev)
-    c = torch.empty((B, T, ndir * H), dtype=torch.float32, device=dev)
-    gates = torch.empty((B, T, ndir * G4), dtype=torch.float32, device=dev)
     wsf = _workspace(_hip.lib().ptts_lstm_fwd_workspace_bytes(B, T, H, ndir), dev)
     _lstm_mark('fwd0')
     call('ptts_lstm_fwd', ptr(xproj), ptr(U), ptr(h), ptr(gates), ptr(c), ptr(wsf), wsf.numel(), B, T, H, ndir, int(reverse), stream())
@@ -1857,7 +1889,12 @@ class LSTMFn(torch.autograd.Function):
         ndir, H, G4 = U.shape
         dev = x.device
         dh = dh.contiguous()
-        dgates = torch.empty_like(gates)
+        if _LSTMRing.enabled:
+            dh_s, dgates = _LSTMRing.take(('bwd', B, T, ndir, H, _hip.stream_id()), [tuple(dh.shape), tuple(gates.shape)], dev)
+            dh_s.copy_(dh)
+            dh = dh_s
+        else:
+            dgates = torch.empty_like(gates)
         nws = _hip.lib().ptts_lstm_bwd_workspace_bytes(B, T, H, ndir)
         ws = _workspace(nws, dev)
         _lstm_mark('bwd0')
