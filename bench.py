@@ -393,6 +393,9 @@ def main():
                        'mode': cfg.train_wgan_hipgraph,
                        'tuning_ms': {k[0]: {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in opt._graph_tuning.items()}}
     dt, cyc = timed_loop(opt, batches, args.steps, args.warmup, dev)
+    # (a batch that trains both networks may run as ONE graph: decided on the first such batch, inside the warm-up)
+    hipgraph_choice['batch_that_trains_both_as_one_graph'] = bool(opt._graph_choice.get(('batch', tuple(batches[0][0].shape), tuple(batches[0][1].shape)), False))
+    hipgraph_choice['tuning_ms'] = {k[0]: {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in opt._graph_tuning.items()}
     extra = {}
     if cyc:
         extra['cycle_ms'] = dict(cyc, what='HIP-event spacing of 5-step cycles (5 critic + 1 generator step) inside the timed region')

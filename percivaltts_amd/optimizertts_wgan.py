@@ -138,6 +138,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         cfg.train_wgan_reuse_ctx_conv = True         # generator step reuses the critic step's G-context-Conv1D product (same batch)
         cfg.train_wgan_early_critic = True           # generator step: critic starts on the spectral branch, BLSTM joins for the LS term
         cfg.train_wgan_hoist_side_backward = False   # ... and the BLSTM branch's BACKWARD too (its output is read by the least-squares term only: the branch is cut out of the tape, run on its own, its gradient injected at the cut).  Measured +1 %: the chains then contend with the critic step; opt-in
+        cfg.train_wgan_batch_graph = False           # 'tune': a batch that trains both networks may be replayed as ONE hipGraph (BLSTM fork kept), if that times faster.  It does not: 29.6 ms against 14.0 for the separate steps (cross-stream edges of a graph replay at half speed on this runtime) -- off, so that the timing runs are not made either
         cfg.train_wgan_hoist_generator = True        # a batch that trains both: G's forward (it does not depend on the critic) is launched BEFORE the critic step -- its BLSTM chain runs under that step -- and the critic step takes its fake sample from it
         cfg.train_wgan_graph_split = False           # hipGraph of forward + backward only, update launched eagerly (what data parallelism uses; settable for tests)
         cfg.train_wgan_async_update = None           # all-reduce + Adam on a communication stream, overlapped with the next forward that does not need the weights (None: on when world > 1)
@@ -532,14 +533,21 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             sX, sY = X.clone(), Y.clone()
             sA = torch.rand(X.shape[0], device=X.device, dtype=torch.float32)
             sF = fake.detach().clone() if with_fake else None
-            if whole:
+            if kind == 'batch':
+                assert whole, 'the whole-batch graph is a one-process form'
+                fn = lambda: self._batch_steps(sX, sY, sA, True, False, False)
+            elif whole:
                 fn = (lambda: self.critic_step(sX, sY, sA, sF)) if kind == 'critic' else (lambda: self.generator_step(sX, sY))
             else:
                 fn = (lambda: self._critic_grads(sX, sY, sA, sF)) if kind == 'critic' else (lambda: self._generator_grads(sX, sY))
             from . import layers
             # the graph is captured on one stream: the evaluations' side streams would become cross-stream edges of the capture
             saved_streams = (self.cfg.train_wgan_parallel_streams, getattr(self._model.kerasmodel, 'parallel_branches', False))
-            if not bool(getattr(self.cfg, 'train_wgan_graph_streams', False)):
+            if kind == 'batch':
+                # one fork: the generator's BLSTM branch stays on its side stream (its chain runs beside the critic step); the critic's
+                # three evaluations go on one stream (a capture with their cross-stream edges replayed at half the speed)
+                self.cfg.train_wgan_parallel_streams = False
+            elif not bool(getattr(self.cfg, 'train_wgan_graph_streams', False)):
                 self.cfg.train_wgan_parallel_streams = False
                 self._model.kerasmodel.parallel_branches = False
             side = layers.side_streams(1, 'capture')[0]
@@ -566,7 +574,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         sX.copy_(X); sY.copy_(Y)
         if sF is not None:
             sF.copy_(fake)
-        if kind == 'critic':
+        if kind in ('critic', 'batch'):
             if alpha is None: sA.uniform_(0.0, 1.0)
             else: sA.copy_(alpha.reshape(-1))
         self.wait_updates()            # the replay reads (and, in one process, writes) both networks' weights
@@ -574,7 +582,8 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         if whole:
             # the replayed Adam / clip kernels changed the weights behind every weight-keyed cache (bf16 planes, Toeplitz
             # tables): the Python-side epoch bump of KerasAdam.step() is not part of the graph
-            (self.critic_opti if kind == 'critic' else self.gen_opti).flat.epoch += 1
+            if kind in ('critic', 'batch'): self.critic_opti.flat.epoch += 1
+            if kind in ('generator', 'batch'): self.gen_opti.flat.epoch += 1
         else:
             self._update(kind)
         return out
@@ -612,6 +621,23 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         use_graph = graph_c or graph_g
         ops.conv1d_cache(gen_too and not use_graph and bool(getattr(self.cfg, 'train_wgan_reuse_ctx_conv', True)))
         try:
+            if gen_too and not graph_g and self._use_batch_graph(X, Y, graph_c):
+                # the whole train_on_batch of this batch (hoisted generator forward, critic step, generator step) as ONE hipGraph with
+                # the BLSTM branch's fork / join kept: no host time at all
+                lc, lg = self._graphed('batch', X, Y, alpha)
+                self.generator_updates += 1
+                return lc, lg
+            lc, lg = self._batch_steps(X, Y, alpha, gen_too, graph_c, graph_g)
+            if gen_too:
+                self.generator_updates += 1
+        finally:
+            ops.conv1d_cache(False)
+        return lc, lg
+
+    def _batch_steps(self, X, Y, alpha, gen_too, graph_c, graph_g):
+        """The steps of one train_on_batch: critic step, and the generator step when `gen_too` (its forward hoisted in front of the
+        critic step, see generator_forward_early)."""
+        if True:
             pre = fake = None
             if gen_too and not graph_g and bool(getattr(self.cfg, 'train_wgan_hoist_generator', True)) and self._can_split_generator():
                 # G's forward first (see generator_forward_early); inside deferred_weight_grads() so that its layers note their
@@ -633,10 +659,39 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
                     lg = self._graphed('generator', X, Y)
                 else:
                     lg = self.generator_step(X, Y) if pre is None else self.generator_step(X, Y, pre)
-                self.generator_updates += 1
-        finally:
-            ops.conv1d_cache(False)
         return lc, lg
+
+    def _use_batch_graph(self, X, Y, graph_c):
+        """cfg.train_wgan_hipgraph = 'tune' (one process): is a batch that trains both networks replayed as ONE graph?  Timed on the first
+        such batch against the separate steps (critic step as chosen, eager generator step with its forward hoisted)."""
+        if self.cfg.train_wgan_hipgraph != 'tune' or self.world != 1 or not bool(getattr(self.cfg, 'train_wgan_batch_graph', False)):
+            return False
+        if X.shape[0] * X.shape[1] <= int(getattr(self.cfg, 'train_wgan_hipgraph_maxframes', 8192)):
+            return False
+        key = ('batch', tuple(X.shape), tuple(Y.shape))
+        if key in self._graph_choice:
+            return self._graph_choice[key]
+        snap = self._state_snapshot()
+        gu = self.generator_updates
+        def timed(fn, n=3):
+            torch.cuda.synchronize()
+            t = time.time()
+            for _ in range(n): fn()
+            torch.cuda.synchronize()
+            return (time.time() - t) / n
+        sep = lambda: self._batch_steps(X, Y, None, True, graph_c, False)
+        one = lambda: self._graphed('batch', X, Y)
+        for _ in range(2): sep()
+        one()
+        t_sep, t_one = [], []
+        for _ in range(2):
+            t_sep.append(timed(sep)); t_one.append(timed(one))
+        t_sep, t_one = min(t_sep), min(t_one)
+        self._state_restore(snap)
+        self.generator_updates = gu
+        self._graph_choice[key] = bool(t_one < t_sep)
+        self._graph_tuning[key] = {'separate_steps_ms': t_sep * 1e3, 'one_graph_ms': t_one * 1e3, 'graph': bool(t_one < t_sep)}
+        return self._graph_choice[key]
 
     # ---- the reference's hooks --------------------------------------------------------------------------------------
     def train_on_batch(self, batchid, X_trab, Y_trab):
