@@ -637,28 +637,27 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
     def _batch_steps(self, X, Y, alpha, gen_too, graph_c, graph_g):
         """The steps of one train_on_batch: critic step, and the generator step when `gen_too` (its forward hoisted in front of the
         critic step, see generator_forward_early)."""
-        if True:
-            pre = fake = None
-            if gen_too and not graph_g and bool(getattr(self.cfg, 'train_wgan_hoist_generator', True)) and self._can_split_generator():
-                # G's forward first (see generator_forward_early); inside deferred_weight_grads() so that its layers note their
-                # gradient targets as they do inside the generator step
-                self.gen_opti.zero_grad()
-                with ops.deferred_weight_grads():
-                    pre = self.generator_forward_early(X, Y, training=True)
-                    self._gen_deferred = ops.deferred_detach()      # (joined and flushed by the generator step's own context)
-                fake = self.fake_from_early(X, pre)
-            ops._lstm_mark('critic_step_begin')
-            if graph_c:
-                lc = self._graphed('critic', X, Y, alpha, fake)
+        pre = fake = None
+        if gen_too and not graph_g and bool(getattr(self.cfg, 'train_wgan_hoist_generator', True)) and self._can_split_generator():
+            # G's forward first (see generator_forward_early); inside deferred_weight_grads() so that its layers note their
+            # gradient targets as they do inside the generator step
+            self.gen_opti.zero_grad()
+            with ops.deferred_weight_grads():
+                pre = self.generator_forward_early(X, Y, training=True)
+                self._gen_deferred = ops.deferred_detach()      # (joined and flushed by the generator step's own context)
+            fake = self.fake_from_early(X, pre)
+        ops._lstm_mark('critic_step_begin')
+        if graph_c:
+            lc = self._graphed('critic', X, Y, alpha, fake)
+        else:
+            lc = self.critic_step(X, Y, alpha) if fake is None else self.critic_step(X, Y, alpha, fake)
+        ops._lstm_mark('critic_step_end')
+        lg = None
+        if gen_too:
+            if graph_g:
+                lg = self._graphed('generator', X, Y)
             else:
-                lc = self.critic_step(X, Y, alpha) if fake is None else self.critic_step(X, Y, alpha, fake)
-            ops._lstm_mark('critic_step_end')
-            lg = None
-            if gen_too:
-                if graph_g:
-                    lg = self._graphed('generator', X, Y)
-                else:
-                    lg = self.generator_step(X, Y) if pre is None else self.generator_step(X, Y, pre)
+                lg = self.generator_step(X, Y) if pre is None else self.generator_step(X, Y, pre)
         return lc, lg
 
     def _use_batch_graph(self, X, Y, graph_c):
