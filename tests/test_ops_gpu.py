@@ -1230,3 +1230,48 @@ def test_conv1d_frequency_domain_forward(ops, case, seg):
     finally:
         ops._C1FFT.seg_target = seg0
         ops.conv1d_fft(None); ops.conv1d_split(None)
+
+
+@pytest.mark.parametrize('case', [(3, 400, 601, 4, 100, -10, 120, 120), (3, 400, 256, 4, 100, 0, 120, 100), (2, 460, 70, 5, 92, -4, 100, 100),
+                                  (5, 37, 13, 1, 37, -1, 40, 40)])
+def test_frame_window_and_strided_planes_bit_for_bit(ops, case):
+    """csrc/dense.hip, split3_dense_weight_strided_kernel (ptts_split3_frame_windows / ptts_split3_dense_weight_strided): the planes of
+    the overlap-save windows of a frame sequence -- window z = (b, s) = rows x[b][row_off + s S + k], zero outside the utterance and
+    for k >= kvalid -- BIT FOR BIT against oracle.np_split3_bf16 of the windows built on the host, in the fragment order of the
+    batched products; and the strided form against the same matrices laid out at a regular stride."""
+    B, T, C, NS, S, row_off, P, kvalid = case
+    np = O.np
+    lib = ops._hip.lib()
+    g = gen(3 + C)
+    x = torch.randn(B, T, C, generator=g, dtype=torch.float64).float()
+    xd = x.cuda()
+    Z = B * NS
+    nb = lib.ptts_dense_planes_bytes(C, P)
+    planes = torch.full((Z * nb,), 0xAB, dtype=torch.uint8, device='cuda')
+    ops.call('ptts_split3_frame_windows', ops.ptr(xd), B, T, C, NS, S, row_off, P, kvalid, ops.ptr(planes), nb, ops.stream())
+    NT, KS = -(-C // 256) * 16, -(-P // 32)
+    got = planes.view(torch.bfloat16).float().view(Z, 3, NT, KS, 64, 8).cpu().numpy()
+    win = np.zeros((Z, P, C), dtype=np.float32)
+    xn = x.numpy()
+    for b in range(B):
+        for s in range(NS):
+            for k in range(min(P, kvalid)):
+                t = row_off + s * S + k
+                if 0 <= t < T:
+                    win[b * NS + s, k] = xn[b, t]
+
+    def frag(mat):                                   # planes of mat [K][N] in fragment order [3][NT][KS][64][8]
+        want = np.zeros((3, NT * 16, KS * 32), dtype=np.float32)
+        for p, pl in enumerate(O.np_split3_bf16(mat)):
+            want[p, :mat.shape[1], :mat.shape[0]] = pl.T
+        return want.reshape(3, NT, 16, KS, 4, 8).transpose(0, 1, 3, 4, 2, 5).reshape(3, NT, KS, 64, 8)
+
+    for z in range(Z):
+        ref = frag(win[z])
+        assert (got[z] == ref).all(), 'window {}: planes differ in {} entries'.format(z, int((got[z] != ref).sum()))
+    # the strided form on the same matrices stored one after the other
+    wd = torch.from_numpy(win).cuda()
+    planes2 = torch.full((Z * nb,), 0xCD, dtype=torch.uint8, device='cuda')
+    ops.call('ptts_split3_dense_weight_strided', ops.ptr(wd), P * C, ops.ptr(planes2), nb, Z, C, P, C, 0, ops.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(planes, planes2)
