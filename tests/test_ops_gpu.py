@@ -1275,3 +1275,73 @@ def test_frame_window_and_strided_planes_bit_for_bit(ops, case):
     ops.call('ptts_split3_dense_weight_strided', ops.ptr(wd), P * C, ops.ptr(planes2), nb, Z, C, P, C, 0, ops.stream())
     torch.cuda.synchronize()
     assert torch.equal(planes, planes2)
+
+
+def test_frequency_domain_building_blocks(ops):
+    """The C-ABI pieces of the frequency-domain Conv1D on their own (ops._C1FFT composes them): ptts_dense_bf16x6_batched (products of
+    one shape at regular strides, shared or per-member left operand, bias) against fp64 products; ptts_transpose_batched and
+    ptts_dft_mirror exactly; ptts_conv1d_freq_kernel_planes against the fp64 twiddle product (the three planes summed);
+    ptts_conv1d_freq_wgrad_inverse against the fp64 sum over the frequencies."""
+    import ctypes
+    np = O.np
+    lib = ops._hip.lib()
+    g = gen(91)
+    # ---- batched products: C_z = A_z . B_z + bias, A shared (stride 0) and per member
+    nbat, M, N, K = 5, 100, 70, 132
+    A = torch.randn(nbat, M, K, generator=g, dtype=torch.float64).float().cuda()
+    Bm = (torch.randn(nbat, K, N, generator=g, dtype=torch.float64) / K ** 0.5).float().cuda()
+    bias = torch.randn(N, generator=g, dtype=torch.float64).float().cuda()
+    npb = lib.ptts_dense_planes_bytes(N, K)
+    planes = torch.empty(nbat * npb, dtype=torch.uint8, device='cuda')
+    ops.call('ptts_split3_dense_weight_strided', ops.ptr(Bm), K * N, ops.ptr(planes), npb, nbat, N, K, N, 0, ops.stream())
+    for shared in (False, True):
+        C = torch.full((nbat, M, N), float('nan'), device='cuda')
+        ops.call('ptts_dense_bf16x6_batched', ops.ptr(A), 0 if shared else M * K, ops.ptr(planes), npb, ops.ptr(bias), ops.ptr(C), M * N, nbat,
+                 M, N, K, K, N, 3, ops.stream())
+        for z in range(nbat):
+            want = A[0 if shared else z].double().cpu() @ Bm[z].double().cpu() + bias.double().cpu()
+            e = float((C[z].double().cpu() - want).abs().max() / want.abs().mean())
+            assert e < 2e-5, ('batched product', shared, z, e)
+    # ---- batched transpose, exactly
+    src = torch.randn(7, 45, 70, generator=g).cuda()
+    dst = torch.empty(7, 70, 45, device='cuda')
+    ops.call('ptts_transpose_batched', ops.ptr(src), ops.ptr(dst), 7, 45, 70, ops.stream())
+    assert torch.equal(dst, src.transpose(1, 2).contiguous())
+    # ---- mirror: rows [Xr | .], [Xi | .] -> [Xr | -Xi], [Xi | Xr]
+    NB, Z, Cin, Kh = 4, 6, 13, 16
+    Ap = torch.zeros(NB, 2, Z, 2 * Kh, device='cuda')
+    Ap[:, :, :, :Cin] = torch.randn(NB, 2, Z, Cin, generator=g).cuda()
+    ref = Ap.clone()
+    ref[:, 0, :, Kh:Kh + Cin] = -Ap[:, 1, :, :Cin]
+    ref[:, 1, :, Kh:Kh + Cin] = Ap[:, 0, :, :Cin]
+    ops.call('ptts_dft_mirror', ops.ptr(Ap), NB, Z, Cin, Kh, ops.stream())
+    assert torch.equal(Ap, ref)
+    # ---- the kernel's transform into planes: the planes summed = the twiddle product (fp32 rounding)
+    KW, Cin, N, Kh, NB = 5, 13, 20, 16, 6
+    w = (torch.randn(KW, Cin, N, generator=g, dtype=torch.float64) * 0.3).float().cuda()
+    tw = torch.randn(2 * NB, KW, generator=g, dtype=torch.float64).float().cuda()
+    npw = lib.ptts_dense_planes_bytes(N, 2 * Kh)
+    pl = torch.empty(NB * npw, dtype=torch.uint8, device='cuda')
+    ops.call('ptts_conv1d_freq_kernel_planes', ops.ptr(w), ops.ptr(tw), ops.ptr(pl), NB, KW, Cin, N, Kh, ops.stream())
+    NT, KS = -(-N // 256) * 16, -(-(2 * Kh) // 32)
+    got = pl.view(torch.bfloat16).float().view(NB, 3, NT, KS, 4, 16, 8).sum(1).cpu().numpy()     # [f][nt][ks][lg][li][e]
+    what = np.einsum('rk,kcn->rcn', tw.double().cpu().numpy(), w.double().cpu().numpy()).reshape(NB, 2, Cin, N)
+    for f in range(NB):
+        for part in range(2):
+            for c in (0, 5, Cin - 1):
+                for n in (0, 7, N - 1):
+                    k = part * Kh + c
+                    v = got[f, n // 16, k // 32, (k % 32) // 8, n % 16, k % 8]
+                    assert abs(v - what[f, part, c, n]) < 2e-6 * (1 + abs(what[f, part, c, n])), (f, part, c, n, v, what[f, part, c, n])
+    assert float(np.abs(got[:, :, :, :, :, :][..., 0]).sum()) > 0
+    # ---- the inverse transform of the weight gradient: dW[k][c][n] = sum_f t2[f][k] Gt[f][n][c] + t2[f][KW + k] Gt[f][n][Kh + c]
+    KW, Cin, N, Kh, NB, TP = 5, 13, 20, 16, 9, 16
+    Gt = torch.randn(NB, N, 2 * Kh, generator=g, dtype=torch.float64).float().cuda()
+    t2 = torch.zeros(NB, TP, device='cuda')
+    t2[:, :2 * KW] = torch.randn(NB, 2 * KW, generator=g).cuda()
+    dW = torch.empty(KW, Cin, N, device='cuda')
+    ws = torch.empty(lib.ptts_conv1d_freq_wgrad_inverse_workspace_bytes(KW, Cin, N), dtype=torch.uint8, device='cuda')
+    ops.call('ptts_conv1d_freq_wgrad_inverse', ops.ptr(Gt), ops.ptr(t2), ops.ptr(dW), ops.ptr(ws), ws.numel(), NB, TP, KW, Cin, N, Kh, ops.stream())
+    G64, t64 = Gt.double().cpu().numpy(), t2.double().cpu().numpy()
+    want = np.einsum('fk,fnc->kcn', t64[:, :KW], G64[:, :, :Cin]) + np.einsum('fk,fnc->kcn', t64[:, KW:2 * KW], G64[:, :, Kh:Kh + Cin])
+    assert float(np.abs(dW.double().cpu().numpy() - want).max()) < 1e-5 * (1 + float(np.abs(want).max()))
