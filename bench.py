@@ -308,7 +308,7 @@ def build_optimizer(args, ctx, spec, nm, batch, errtype, gated=False, bf16=None,
     cfg.train_wgan_reuse_ctx_conv = not args.no_ctx_reuse
     cfg.train_wgan_early_critic = not args.no_early_critic
     cfg.train_wgan_hoist_generator = (not args.no_hoist) and os.environ.get('PTTS_HOIST', '1') == '1'
-    cfg.train_wgan_hoist_side_backward = os.environ.get('PTTS_HOIST_SIDE_BWD', '0') == '1'      # (A/B switch)
+    cfg.train_wgan_hoist_side_backward = os.environ.get('PTTS_HOIST_SIDE_BWD', '1') == '1'      # (A/B switch)
     cfg.train_wgan_side_backward_first = os.environ.get('PTTS_SIDE_BWD_FIRST', '0') == '1'     # (A/B switch) the BLSTM's autograd node created last
     cfg.train_wgan_split_bf16 = not args.fp32_mfma
     cfg.train_sync_batchnorm = bool(getattr(args, 'sync_bn', False))

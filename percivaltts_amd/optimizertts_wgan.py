@@ -137,7 +137,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         cfg.train_wgan_stack_real_fake = True        # critic(real) and critic(fake) as one stacked 2B pass (exact: no BatchNorm)
         cfg.train_wgan_reuse_ctx_conv = True         # generator step reuses the critic step's G-context-Conv1D product (same batch)
         cfg.train_wgan_early_critic = True           # generator step: critic starts on the spectral branch, BLSTM joins for the LS term
-        cfg.train_wgan_hoist_side_backward = False   # ... and the BLSTM branch's BACKWARD too (its output is read by the least-squares term only: the branch is cut out of the tape, run on its own, its gradient injected at the cut).  Measured +1 %: the chains then contend with the critic step; opt-in
+        cfg.train_wgan_hoist_side_backward = True    # ... and the BLSTM branch's BACKWARD too (its output is read by the least-squares term only: the branch is cut out of the tape, run on its own, its gradient injected at the cut).  Measured + 1 % (three A/B pairs, fp32 and bf16): both chains then run under the critic step
         cfg.train_wgan_batch_graph = False           # 'tune': a batch that trains both networks may be replayed as ONE hipGraph (BLSTM fork kept), if that times faster.  It does not: 29.6 ms against 14.0 for the separate steps (cross-stream edges of a graph replay at half speed on this runtime) -- off, so that the timing runs are not made either
         cfg.train_wgan_hoist_generator = True        # a batch that trains both: G's forward (it does not depend on the critic) is launched BEFORE the critic step -- its BLSTM chain runs under that step -- and the critic step takes its fake sample from it
         cfg.train_wgan_graph_split = False           # hipGraph of forward + backward only, update launched eagerly (what data parallelism uses; settable for tests)
@@ -291,7 +291,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         self._wait_update('generator')
         feed = {id(m.inputs[0]): X}
         early_bwd = Y is not None and self._errtype == 'WLSWGAN' and bool(getattr(m, 'parallel_branches', False)) and \
-            bool(getattr(self.cfg, 'train_wgan_hoist_side_backward', False))
+            bool(getattr(self.cfg, 'train_wgan_hoist_side_backward', True))
         values = m._run(feed, training, None, hold={id(m.outputs[0])}, cut_side=early_bwd)
         self._gen_cuts = []
         if early_bwd and values.get('__cuts__') and '__side__' in values:

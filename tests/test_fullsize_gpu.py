@@ -395,7 +395,7 @@ def test_hoisted_generator_forward_gives_the_same_train_step(setup):
                 dst.copy_(src)
             opt.critic_opti.flat.epoch += 1; opt.gen_opti.flat.epoch += 1
             opt.cfg.train_wgan_hoist_generator = hoist
-            opt.cfg.train_wgan_hoist_side_backward = branches        # (opt-in; needs the branch on its side stream)
+            opt.cfg.train_wgan_hoist_side_backward = branches        # (needs the branch on its side stream)
             opt._model.kerasmodel.parallel_branches = branches
             torch.manual_seed(5)                       # same interpolation weights
             with _hip.KernelTimer() as kt:
@@ -406,7 +406,7 @@ def test_hoisted_generator_forward_gives_the_same_train_step(setup):
                             [t.detach().clone() for t in moving], names.count('ptts_lstm_fwd'), names.count('ptts_conv2d_fwd')))
     finally:
         opt.cfg.train_wgan_hoist_generator = True
-        opt.cfg.train_wgan_hoist_side_backward = False
+        opt.cfg.train_wgan_hoist_side_backward = True
         opt._model.kerasmodel.parallel_branches = branches0
         for dst, src in zip(state, snap):
             dst.copy_(src)
