@@ -54,9 +54,11 @@ constexpr int NPART = KT * KF * 16 + 4 + 8;   // row of partial sums: the layout
 constexpr int DT_IN = 1, DT_OUT = 2, DT_DY = 4;
 
 // measurement hooks (tools/conv2d_mfma_probe.py): bit 0 skip the staging, bit 1 skip the MFMA phase, bit 2 skip the
-// stores, bit 3 write s_memtime stamps of the phases of every workgroup to dbg_buf[block][8], bit 5 MFMA operands from
-// registers instead of the LDS, bit 6 no barriers (the last two make garbage: timing only)
-constexpr int DBG_NOSTAGE = 1, DBG_NOMFMA = 2, DBG_NOSTORE = 4, DBG_STAMPS = 8, DBG_NOLDS = 32, DBG_NOBAR = 64;
+// stores, bit 3 write s_memtime stamps of the phases of every workgroup to dbg_buf[block][8], bit 6 no barriers (garbage: timing
+// only).  (A bit-5 hook that made the MFMA operands up in registers was removed: its run-time branch sat inside the kernel-row
+// loop, and the compiler executed its 61 constant moves per 24 MFMAs on the normal path too and issued the LDS reads of row
+// kt + 1 AFTER the MFMAs of row kt instead of before them.)
+constexpr int DBG_NOSTAGE = 1, DBG_NOMFMA = 2, DBG_NOSTORE = 4, DBG_STAMPS = 8, DBG_NOBAR = 64;
 static int g_dbg = 0;
 static unsigned long long* g_dbg_buf = nullptr;
 __device__ __forceinline__ void stamp(unsigned long long* buf, int dbg, int slot) {
@@ -346,7 +348,7 @@ __device__ __forceinline__ void pref_commit(const Pref<ST::NB, MODE == PTTS_IN_M
 template <class ST, int DIL, int N, bool OUTMASK, int NPL>
 __device__ __forceinline__ void fwd_pass(const u16* __restrict__ planes, const u16* __restrict__ wl, int g0, int lane,
                                          f32x4 bv, const void* __restrict__ mrow, void* __restrict__ yrow, bool out_bf16,
-                                         int fbase, int F, bool rowok, float alpha, bool store, bool nolds = false) {
+                                         int fbase, int F, bool rowok, float alpha, bool store) {
     const int li = lane & 15, lg = lane >> 4;
     f32x4 acc[N], mv[OUTMASK ? N : 1];
 #pragma unroll
@@ -370,16 +372,6 @@ __device__ __forceinline__ void fwd_pass(const u16* __restrict__ planes, const u
     // per kernel row.
     bf16x8 a[2][NPL], bq[2][N][NPL];
     auto read_row = [&](int kt, bf16x8 (&ar)[NPL], bf16x8 (&br)[N][NPL]) {
-        if (nolds) {                       // measurement hook: operands made up in registers
-            const bf16x8 c = __builtin_bit_cast(bf16x8, (u32x4v){(unsigned)(lane + kt), 0x3c003c00u, (unsigned)lane, 0x3c003c00u});
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) ar[q] = c;
-#pragma unroll
-            for (int j = 0; j < N; ++j)
-#pragma unroll
-                for (int p = 0; p < NPL; ++p) br[j][p] = c;
-            return;
-        }
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
             const u16* wp = wa + (kt * NPL + q) * TKP;
@@ -423,7 +415,7 @@ __device__ __forceinline__ void fwd_pass(const u16* __restrict__ planes, const u
 template <class ST, int DIL, bool OUTMASK, bool MASK, int NPL>
 __device__ __forceinline__ void fwd_piece(const u16* __restrict__ planes, const u16* __restrict__ wl, const TilePos& cur, const Shape& s,
                                           int wave, int lane, int it, f32x4 bv, const void* __restrict__ out_mask, void* __restrict__ y,
-                                          bool out_bf16, float alpha, bool store, bool nomfma, bool nolds = false) {
+                                          bool out_bf16, float alpha, bool store, bool nomfma) {
     const int per = cur.ng >> 2, rem = cur.ng & 3, wr = (wave + it) & 3;
     int gl = wr * per + min(wr, rem);
     int n = per + (wr < rem ? 1 : 0);
@@ -438,7 +430,7 @@ __device__ __forceinline__ void fwd_piece(const u16* __restrict__ planes, const 
     const int fbase = 4 * cur.g_base;
     while (n > 0) {
         const int m = (n + npass - 1) / npass;
-#define C2M_PASS(NN) fwd_pass<ST, DIL, NN, OUTMASK, NPL>(planes, wl, gl, lane, bv, mrow, yrow, out_bf16, fbase, s.F, rowok, alpha, store, nolds)
+#define C2M_PASS(NN) fwd_pass<ST, DIL, NN, OUTMASK, NPL>(planes, wl, gl, lane, bv, mrow, yrow, out_bf16, fbase, s.F, rowok, alpha, store)
         switch (m) {
             case 1: C2M_PASS(1); break;
             case 2: C2M_PASS(2); break;
@@ -477,7 +469,7 @@ __global__ __launch_bounds__(THREADS, NBUF == 2 ? 2 : (DIL == 1 ? 3 : (DIL == 2 
     Work work = next_work(s, sc, wg, item, nitems);
     Pref<ST::NB, MASK> pf;
     TilePos pos = work_pos(s, work);
-    const bool stage = !(dbg & DBG_NOSTAGE), nomfma = (dbg & DBG_NOMFMA) != 0, nolds = (dbg & DBG_NOLDS) != 0, nobar = (dbg & DBG_NOBAR) != 0;
+    const bool stage = !(dbg & DBG_NOSTAGE), nomfma = (dbg & DBG_NOMFMA) != 0, nobar = (dbg & DBG_NOBAR) != 0;
     if (work.ng > 0 && stage)
         pref_load<ST, MASK>(pf, sl, x, mask_src, in_bf16, pos.img, pos.t0 - s.pad_t, 4 * pos.g_base - 2, s.T, s.F, s.F, 4 * pos.ng + 4);
     stamp(dbg_buf, dbg, 5);
@@ -546,7 +538,7 @@ __global__ __launch_bounds__(THREADS, NBUF == 2 ? 2 : (DIL == 1 ? 3 : (DIL == 2 
                 }
             };
             if (!late) stage_next();
-            fwd_piece<ST, DIL, OUTMASK, MASK, NPL>(pcur, wl, cur, s, wave, lane, it, bv, out_mask, y, out_bf16, alpha, store, nomfma, nolds);
+            fwd_piece<ST, DIL, OUTMASK, MASK, NPL>(pcur, wl, cur, s, wave, lane, it, bv, out_mask, y, out_bf16, alpha, store, nomfma);
             if (late) stage_next();
             if (it == 0) stamp(dbg_buf, dbg, 3);
             if (!nobar) __syncthreads();

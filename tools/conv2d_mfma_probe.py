@@ -127,7 +127,7 @@ lib.ptts_conv2d_mfma_debug(0, None)
 nblk = B * ((T + 15) // 16)
 def phases(name, fn):
     out = []
-    for flags, what in ((0, 'all'), (5, 'mfma+lds+barrier'), (5 | 32, 'mfma+barrier'), (5 | 64, 'mfma+lds'), (5 | 32 | 64, 'mfma only'), (1, 'no stage'), (2, 'no mfma'), (4, 'no store'), (3, 'skeleton+store'), (7, 'skeleton')):
+    for flags, what in ((0, 'all'), (5, 'mfma+lds+barrier'), (5 | 64, 'mfma+lds'), (1, 'no stage'), (2, 'no mfma'), (4, 'no store'), (3, 'skeleton+store'), (7, 'skeleton')):
         lib.ptts_conv2d_mfma_debug(flags, None)
         out.append('{} {:.1f}'.format(what, timeit(fn)))
     lib.ptts_conv2d_mfma_debug(0, None)
