@@ -345,8 +345,8 @@ __device__ __forceinline__ void pref_commit(const Pref<ST::NB, MODE == PTTS_IN_M
 // one pass of a wave over N consecutive bin groups g0 .. g0+N-1 of the staged block: straight-line code (a branch around
 // an MFMA group makes the compiler carry the accumulators through register copies), one LDS base register per parity of
 // the group, everything else immediates
-template <class ST, int DIL, int N, bool OUTMASK, int NPL>
-__device__ __forceinline__ void fwd_pass(const u16* __restrict__ planes, const u16* __restrict__ wl, int g0, int lane,
+template <class ST, int DIL, int N, bool OUTMASK, int NPL, bool WREG>
+__device__ __forceinline__ void fwd_pass(const u16* __restrict__ planes, const u16* __restrict__ wl, const bf16x8 (&wf)[KT][NPL], int g0, int lane,
                                          f32x4 bv, const void* __restrict__ mrow, void* __restrict__ yrow, bool out_bf16,
                                          int fbase, int F, bool rowok, float alpha, bool store) {
     const int li = lane & 15, lg = lane >> 4;
@@ -372,10 +372,12 @@ __device__ __forceinline__ void fwd_pass(const u16* __restrict__ planes, const u
     // per kernel row.
     bf16x8 a[2][NPL], bq[2][N][NPL];
     auto read_row = [&](int kt, bf16x8 (&ar)[NPL], bf16x8 (&br)[N][NPL]) {
+        if (!WREG) {
 #pragma unroll
-        for (int q = 0; q < NPL; ++q) {
-            const u16* wp = wa + (kt * NPL + q) * TKP;
-            ar[q] = cat(*reinterpret_cast<const bf16x4*>(wp), *reinterpret_cast<const bf16x4*>(wp + 4));
+            for (int q = 0; q < NPL; ++q) {
+                const u16* wp = wa + (kt * NPL + q) * TKP;
+                ar[q] = cat(*reinterpret_cast<const bf16x4*>(wp), *reinterpret_cast<const bf16x4*>(wp + 4));
+            }
         }
 #pragma unroll
         for (int j = 0; j < N; ++j)
@@ -390,7 +392,8 @@ __device__ __forceinline__ void fwd_pass(const u16* __restrict__ planes, const u
         // product-major: consecutive MFMAs go to different accumulators
 #define C2M_MM(PA, PW)                                                                                  \
         _Pragma("unroll") for (int j = 0; j < N; ++j)                                                   \
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kt & 1][PW < NPL ? PW : 0], bq[kt & 1][j][PA < NPL ? PA : 0], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WREG ? wf[kt][PW < NPL ? PW : 0] : a[kt & 1][PW < NPL ? PW : 0],                \
+                                                             bq[kt & 1][j][PA < NPL ? PA : 0], acc[j], 0, 0, 0);
         C2M_PRODUCTS_NPL(NPL, C2M_MM);
 #undef C2M_MM
     }
@@ -412,8 +415,8 @@ __device__ __forceinline__ void fwd_pass(const u16* __restrict__ planes, const u
 // the MFMA phase of one staged piece: the wave's share of its bin groups, a contiguous run, in passes of at most NMAX groups
 // of nearly equal size (register budget: a pass keeps N x 3 activation fragments).  The wave that takes the odd group
 // changes from piece to piece: the waves of a workgroup sit on different SIMDs.
-template <class ST, int DIL, bool OUTMASK, bool MASK, int NPL>
-__device__ __forceinline__ void fwd_piece(const u16* __restrict__ planes, const u16* __restrict__ wl, const TilePos& cur, const Shape& s,
+template <class ST, int DIL, bool OUTMASK, bool MASK, int NPL, bool WREG>
+__device__ __forceinline__ void fwd_piece(const u16* __restrict__ planes, const u16* __restrict__ wl, const bf16x8 (&wf)[KT][NPL], const TilePos& cur, const Shape& s,
                                           int wave, int lane, int it, f32x4 bv, const void* __restrict__ out_mask, void* __restrict__ y,
                                           bool out_bf16, float alpha, bool store, bool nomfma) {
     const int per = cur.ng >> 2, rem = cur.ng & 3, wr = (wave + it) & 3;
@@ -430,7 +433,7 @@ __device__ __forceinline__ void fwd_piece(const u16* __restrict__ planes, const 
     const int fbase = 4 * cur.g_base;
     while (n > 0) {
         const int m = (n + npass - 1) / npass;
-#define C2M_PASS(NN) fwd_pass<ST, DIL, NN, OUTMASK, NPL>(planes, wl, gl, lane, bv, mrow, yrow, out_bf16, fbase, s.F, rowok, alpha, store)
+#define C2M_PASS(NN) fwd_pass<ST, DIL, NN, OUTMASK, NPL, WREG>(planes, wl, wf, gl, lane, bv, mrow, yrow, out_bf16, fbase, s.F, rowok, alpha, store)
         switch (m) {
             case 1: C2M_PASS(1); break;
             case 2: C2M_PASS(2); break;
@@ -447,7 +450,7 @@ __device__ __forceinline__ void fwd_piece(const u16* __restrict__ planes, const 
 // NBUF == 2 (dilation 1): the planes are double-buffered -- the piece i+1 is activated, split and written to the other
 // buffer by the same waves that multiply piece i, ONE barrier per piece, and the two workgroups of a CU (86 -> 76 KB of LDS
 // each with the compact table) drift against each other, so that one's vector work runs under the other's MFMAs.
-template <int DIL, int MODE, bool OUTMASK, int NPL, int NBUF>
+template <int DIL, int MODE, bool OUTMASK, int NPL, int NBUF, bool WREG_ = false>
 __global__ __launch_bounds__(THREADS, NBUF == 2 ? 2 : (DIL == 1 ? 3 : (DIL == 2 ? 2 : 1))) void fwd_kernel(
     const void* __restrict__ x, const u16* __restrict__ tab, const float* __restrict__ bias,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, const void* __restrict__ mask_src,
@@ -473,9 +476,26 @@ __global__ __launch_bounds__(THREADS, NBUF == 2 ? 2 : (DIL == 1 ? 3 : (DIL == 2 
     if (work.ng > 0 && stage)
         pref_load<ST, MASK>(pf, sl, x, mask_src, in_bf16, pos.img, pos.t0 - s.pad_t, 4 * pos.g_base - 2, s.T, s.F, s.F, 4 * pos.ng + 4);
     stamp(dbg_buf, dbg, 5);
-    // the table: KT * NPL * 352 bytes, once per workgroup
-    for (int i = tid; i < KT * NPL * TKP / 8; i += THREADS)
-        *reinterpret_cast<bf16x8*>(wl + (size_t)i * 8) = *reinterpret_cast<const bf16x8*>(tab + (size_t)i * 8);
+    // the table.  Dilation 1, double-buffered (WREG): a lane's 5 x NPL operand fragments -- they do not depend on the tile -- are read from the table in
+    // global memory once and stay in registers for the whole launch; out of the LDS, as before, they were a third of the
+    // matrix phase's LDS reads (6 of 18 sixteen-byte reads per kernel row and pass), and the LDS pipe, not the matrix pipe, bounds
+    // that phase.  The dilated kernels have no registers to spare: KT * NPL * 352 bytes into the LDS, once per workgroup.
+    constexpr bool WREG = WREG_ && DIL == 1 && NBUF == 2;           // (the single-buffered form runs three workgroups per CU: 168 registers)
+    bf16x8 wf[KT][NPL];
+    if (WREG) {
+        const int li = lane & 15, lg = lane >> 4;
+        const u16* wa = tab + (li & 3) * TROW + (2 * lg - (li >> 2) + 3) * C;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) {
+                const u16* wp = wa + (kt * NPL + q) * TKP;
+                wf[kt][q] = cat(*reinterpret_cast<const bf16x4*>(wp), *reinterpret_cast<const bf16x4*>(wp + 4));
+            }
+    } else {
+        for (int i = tid; i < KT * NPL * TKP / 8; i += THREADS)
+            *reinterpret_cast<bf16x8*>(wl + (size_t)i * 8) = *reinterpret_cast<const bf16x8*>(tab + (size_t)i * 8);
+    }
     stamp(dbg_buf, dbg, 6);
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias) bv = *reinterpret_cast<const f32x4*>(bias);
@@ -495,7 +515,7 @@ __global__ __launch_bounds__(THREADS, NBUF == 2 ? 2 : (DIL == 1 ? 3 : (DIL == 2 
                 if (stage)
                     pref_load<ST, MASK>(pf, sl, x, mask_src, in_bf16, pos.img, pos.t0 - s.pad_t, 4 * pos.g_base - 2, s.T, s.F, s.F, 4 * pos.ng + 4);
             }
-            fwd_piece<ST, DIL, OUTMASK, MASK, NPL>(planes, wl, cur, s, wave, lane, it, bv, out_mask, y, out_bf16, alpha, store, nomfma);
+            fwd_piece<ST, DIL, OUTMASK, MASK, NPL, WREG>(planes, wl, wf, cur, s, wave, lane, it, bv, out_mask, y, out_bf16, alpha, store, nomfma);
             if (it == 0) stamp(dbg_buf, dbg, 3);
             __syncthreads();       // the planes are free again
             ++it;
@@ -538,7 +558,7 @@ __global__ __launch_bounds__(THREADS, NBUF == 2 ? 2 : (DIL == 1 ? 3 : (DIL == 2 
                 }
             };
             if (!late) stage_next();
-            fwd_piece<ST, DIL, OUTMASK, MASK, NPL>(pcur, wl, cur, s, wave, lane, it, bv, out_mask, y, out_bf16, alpha, store, nomfma);
+            fwd_piece<ST, DIL, OUTMASK, MASK, NPL, WREG>(pcur, wl, wf, cur, s, wave, lane, it, bv, out_mask, y, out_bf16, alpha, store, nomfma);
             if (late) stage_next();
             if (it == 0) stamp(dbg_buf, dbg, 3);
             if (!nobar) __syncthreads();
@@ -798,6 +818,13 @@ bool fwd_double_buffered() {
     if (v < 0) { const char* e = getenv("PTTS_C2M_DOUBLE"); v = e ? atoi(e) : 1; }
     return v != 0;
 }
+// the dilation-1 double-buffered kernel with its operand table in registers (the default) or in the LDS (PTTS_C2M_WREG=0):
+// same box, whole train step: critic step 5.07 -> 4.97 ms with the registers
+bool fwd_table_in_registers() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PTTS_C2M_WREG"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
 template <int DIL, int NPL, int NB> constexpr size_t lds_fwd() { return ((size_t)NB * NPL * Stage<4 * GPB + 4, 16 + (KT - 1) * DIL>::PS + (size_t)KT * NPL * TKP) * sizeof(u16); }
 template <int DIL, int NPL> constexpr size_t lds_wgrad() {
     const size_t planes = (size_t)NPL * (Stage<4 * (GPB + 1) + 4, 16 + (KT - 1) * DIL>::PS + Stage<4 * (GPB + 1) + 4, 16>::PS) * sizeof(u16);
@@ -861,18 +888,21 @@ extern "C" int ptts_conv2d_mfma_fwd(const void* x, const void* table, const floa
     hipStream_t st = (hipStream_t)stream;
     const bool om = out_mask != nullptr;
     const int dt = (in_bf16 ? DT_IN : 0) | (out_bf16 ? DT_OUT : 0);
-#define C2M_LB(DIL, MODE, OM, NPL, NB)                                                                                   \
+#define C2M_LB(DIL, MODE, OM, NPL, NB, WR)                                                                               \
     do {                                                                                                                 \
         constexpr size_t lds = lds_fwd<DIL, NPL, NB>();                                                                  \
         static_assert(lds <= LDS_MAX, "tile does not fit the LDS");                                                      \
         static bool attr = false;                                                                                        \
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_kernel<DIL, MODE, OM, NPL, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX); attr = true; } \
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_kernel<DIL, MODE, OM, NPL, NB, WR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX); attr = true; } \
         const Sched sc = sched_for(s.ntiles, lds, NB == 2 ? 2 : (DIL == 1 ? 3 : (DIL == 2 ? 2 : 1)), 1);                  \
-        hipLaunchKernelGGL((fwd_kernel<DIL, MODE, OM, NPL, NB>), dim3(sc.G), dim3(THREADS), lds, st, x, (const u16*)table, bias, \
+        hipLaunchKernelGGL((fwd_kernel<DIL, MODE, OM, NPL, NB, WR>), dim3(sc.G), dim3(THREADS), lds, st, x, (const u16*)table, bias, \
                            in_scale, in_shift, mask_src, out_mask, y, dt, s, sc, alpha, g_dbg, g_dbg_buf);               \
     } while (0)
 #define C2M_L(DIL, MODE, OM, NPL)                                                                                        \
-    do { if (DIL == 1 && fwd_double_buffered()) C2M_LB(1, MODE, OM, NPL, 2); else C2M_LB(DIL, MODE, OM, NPL, 1); } while (0)
+    do {                                                                                                                 \
+        if (DIL == 1 && fwd_double_buffered()) { if (fwd_table_in_registers()) C2M_LB(1, MODE, OM, NPL, 2, true); else C2M_LB(1, MODE, OM, NPL, 2, false); } \
+        else C2M_LB(DIL, MODE, OM, NPL, 1, false);                                                                       \
+    } while (0)
 #define C2M_M(DIL, NPL)                                                                                                  \
     do {                                                                                                                 \
         if (in_mode == PTTS_IN_LRELU) { if (om) C2M_L(DIL, PTTS_IN_LRELU, true, NPL); else C2M_L(DIL, PTTS_IN_LRELU, false, NPL); } \
