@@ -259,7 +259,7 @@ def roofline_leg(opt, X, Y, args):
             Bq, Tq, Fq, _, _, mode, has_om, planes = tag
             by += Bq * Tq * Fq * 4 * 4.0 * (2 + (1 if (mode == 2 or has_om) else 0))
         tt = sum(sum(d for (nm, _, d) in r if nm == 'ptts_conv2d_mfma_fwd') for r in crit_recs) / reps * 1e-3
-        out['roofline'] = {'bound': 'hbm', 'kernel': 'c2m::fwd_kernel (4 -> 4 Conv2D 5x5 layer on the matrix cores: forward, masked forward, backward-data; fp32 maps, fp32 arithmetic as 6 bf16 products), '
+        out['roofline'] = {'bound': 'hbm', 'kernel': 'c2m::fwd_ws_kernel (4 -> 4 Conv2D 5x5 layer on the matrix cores, wave-specialised: forward, masked forward, backward-data; fp32 maps, fp32 arithmetic as 6 bf16 products), '
                            '{} launches per critic step'.format(len(c2m)),
                            'achieved': by / tt / 1e9, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': by / tt / 1e9 / PEAK_HBM_GBPS, 'traffic': None,
                            'algorithmic_bytes_per_launch': by / len(c2m), 'launch_ms': tt / len(c2m) * 1e3, 'launches_per_critic_step': len(c2m)}
@@ -278,7 +278,7 @@ def roofline_leg(opt, X, Y, args):
             if 'roofline_conv1d' in out and key and (conv1d_split or conv1d_fwd) and not conv1d_freq:
                 out['roofline_conv1d']['traffic'] = tr[key]['hbm_bytes_per_launch']
                 out['roofline_conv1d']['traffic_source'] = 'profiles/' + cands[-1]
-            ck = next((k for k in tr if k.startswith('c2m::fwd_kernel<1, 1, false')), None) or next((k for k in tr if k.startswith('conv2d_fwd_kernel<4, 4')), None)
+            ck = next((k for k in tr if k.startswith('c2m::fwd_ws_kernel<1, false')), None) or next((k for k in tr if k.startswith('c2m::fwd_kernel<1, 1, false')), None) or next((k for k in tr if k.startswith('conv2d_fwd_kernel<4, 4')), None)
             if 'roofline_conv2d' in out and ck and not bf16_stack:
                 out['roofline_conv2d']['traffic_fwd_4to4_per_launch'] = tr[ck]['hbm_bytes_per_launch']
                 out['roofline_conv2d']['traffic_kernel'] = ck

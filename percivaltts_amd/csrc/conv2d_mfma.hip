@@ -236,10 +236,10 @@ template <class ST>
 struct Slots {
     int rc[ST::NB];        // r << 8 | c, or -1 for a slot beyond the tile
     int dst[ST::NB];       // LDS element offset inside a plane
-    __device__ __forceinline__ void init() {
+    __device__ __forceinline__ void init(int t = threadIdx.x) {
 #pragma unroll
         for (int u = 0; u < ST::NB; ++u) {
-            const int idx = threadIdx.x + u * THREADS;
+            const int idx = t + u * THREADS;
             const int r = idx / ST::SB, c = idx - r * ST::SB;
             rc[u] = idx < ST::TOTAL ? (r << 8 | c) : -1;
             dst[u] = r * ST::RS + bin_off(c);
@@ -415,15 +415,16 @@ __device__ __forceinline__ void fwd_pass(const u16* __restrict__ planes, const u
 // the MFMA phase of one staged piece: the wave's share of its bin groups, a contiguous run, in passes of at most NMAX groups
 // of nearly equal size (register budget: a pass keeps N x 3 activation fragments).  The wave that takes the odd group
 // changes from piece to piece: the waves of a workgroup sit on different SIMDs.
-template <class ST, int DIL, bool OUTMASK, bool MASK, int NPL, bool WREG>
+template <class ST, int DIL, bool OUTMASK, bool MASK, int NPL, bool WREG, int NW = 4, int NMAXO = 0>
 __device__ __forceinline__ void fwd_piece(const u16* __restrict__ planes, const u16* __restrict__ wl, const bf16x8 (&wf)[KT][NPL], const TilePos& cur, const Shape& s,
                                           int wave, int lane, int it, f32x4 bv, const void* __restrict__ out_mask, void* __restrict__ y,
                                           bool out_bf16, float alpha, bool store, bool nomfma) {
-    const int per = cur.ng >> 2, rem = cur.ng & 3, wr = (wave + it) & 3;
+    static_assert(NW == 4 || NW == 8, "waves that share a piece");
+    const int per = cur.ng / NW, rem = cur.ng & (NW - 1), wr = (wave + it) & (NW - 1);
     int gl = wr * per + min(wr, rem);
     int n = per + (wr < rem ? 1 : 0);
     if (nomfma) n = 0;
-    constexpr int NMAX = (OUTMASK || MASK) ? 4 : 5;       // (five with the mask values as well fits the register-table form but measured 1 us slower)
+    constexpr int NMAX = NMAXO > 0 ? NMAXO : ((OUTMASK || MASK) ? 4 : 5);       // (five with the mask values as well fits the register-table form but measured 1 us slower)
     int npass = (n + NMAX - 1) / NMAX;
     const int t = cur.t0 + row_of_lane(lane & 15);
     const bool rowok = t < s.T;
@@ -436,10 +437,10 @@ __device__ __forceinline__ void fwd_piece(const u16* __restrict__ planes, const 
 #define C2M_PASS(NN) fwd_pass<ST, DIL, NN, OUTMASK, NPL, WREG>(planes, wl, wf, gl, lane, bv, mrow, yrow, out_bf16, fbase, s.F, rowok, alpha, store)
         switch (m) {
             case 1: C2M_PASS(1); break;
-            case 2: C2M_PASS(2); break;
-            case 3: C2M_PASS(3); break;
-            case 4: C2M_PASS(4); break;
-            default: if (NMAX >= 5) C2M_PASS(NMAX >= 5 ? 5 : 4); break;
+            case 2: if (NMAX >= 2) C2M_PASS(NMAX >= 2 ? 2 : 1); break;
+            case 3: if (NMAX >= 3) C2M_PASS(NMAX >= 3 ? 3 : 1); break;
+            case 4: if (NMAX >= 4) C2M_PASS(NMAX >= 4 ? 4 : 1); break;
+            default: if (NMAX >= 5) C2M_PASS(NMAX >= 5 ? 5 : 1); break;
         }
 #undef C2M_PASS
         gl += m; n -= m; --npass;
@@ -565,6 +566,99 @@ __global__ __launch_bounds__(THREADS, NBUF == 2 ? 2 : (DIL == 1 ? 3 : (DIL == 2 
             cur = nxt; have = more;
             ++it;
         }
+    }
+    stamp(dbg_buf, dbg, 4);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Dilation 1, WAVE-SPECIALISED (the default since the end of round 3): one workgroup of EIGHT waves per CU -- two per SIMD, as with two
+// four-wave workgroups -- whose waves 4..7 only STAGE (global loads of piece i + 2 -> registers; activation, three-way split and
+// ds_write of piece i + 1 into the other plane buffer) and whose waves 0..3 only MULTIPLY piece i (LDS reads, MFMAs, stores), one
+// barrier per piece.  Every SIMD then always has one wave of each kind: the vector work of the split runs in the issue gaps of the
+// other wave's MFMAs instead of before or after them (in the four-wave form a workgroup's phases alternate and the two workgroups of a
+// CU overlap only when they happen to be in opposite phases), and a workgroup walks twice as many tiles behind one prologue.
+// Same tiles, same pass structure, same arithmetic as fwd_kernel<1, ...>: results are bit-identical.
+// ------------------------------------------------------------------------------------------------------------
+template <int MODE, bool OUTMASK, int NPL, int NMW>
+__global__ __launch_bounds__((NMW + 4) * 64, 1) void fwd_ws_kernel(
+    const void* __restrict__ x, const u16* __restrict__ tab, const float* __restrict__ bias,
+    const float* __restrict__ in_scale, const float* __restrict__ in_shift, const void* __restrict__ mask_src,
+    const void* __restrict__ out_mask, void* __restrict__ y, int dt, Shape s, Sched sc, float alpha, int dbg, unsigned long long* dbg_buf) {
+    constexpr int DIL = 1;
+    typedef Stage<4 * GPB + 4, 16 + (KT - 1) * DIL> ST;
+    extern __shared__ __attribute__((aligned(16))) u16 lds[];
+    stamp(dbg_buf, dbg, 0);
+    u16* planes = lds;
+    const bool in_bf16 = NPL == 1 && (dt & DT_IN) != 0, out_bf16 = NPL == 1 && (dt & DT_OUT) != 0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool stager = wave8 >= NMW;
+    const int wave = wave8 & (NMW - 1);
+    constexpr bool MASK = MODE == PTTS_IN_MASKMUL;
+    const bool stage = !(dbg & DBG_NOSTAGE), nomfma = (dbg & DBG_NOMFMA) != 0, store = !(dbg & DBG_NOSTORE);
+
+    Slots<ST> sl;
+    Pref<ST::NB, MASK> pf;
+    bf16x8 wf[KT][NPL];
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    const int wg = blockIdx.x, nitems = sched_items(sc, wg);
+    int item = -1;
+    Work w0 = next_work(s, sc, wg, item, nitems);
+    bool havecur = w0.ng > 0;
+    TilePos cur = work_pos(s, w0), nxt = cur;
+    bool havenxt = false;
+    if (havecur) {
+        const Work w1 = next_work(s, sc, wg, item, nitems);
+        havenxt = w1.ng > 0;
+        if (havenxt) nxt = work_pos(s, w1);
+    }
+    if (stager) {
+        sl.init(tid - NMW * 64);
+        if (havecur && stage) {
+            pref_load<ST, MASK>(pf, sl, x, mask_src, in_bf16, cur.img, cur.t0 - s.pad_t, 4 * cur.g_base - 2, s.T, s.F, s.F, 4 * cur.ng + 4);
+            pref_commit<ST, MODE, NPL>(pf, sl, planes, cur.t0 - s.pad_t, 4 * cur.g_base - 2, s.T, s.F, in_scale, in_shift, alpha, 0, 0, nullptr);
+        }
+        if (havenxt && stage)
+            pref_load<ST, MASK>(pf, sl, x, mask_src, in_bf16, nxt.img, nxt.t0 - s.pad_t, 4 * nxt.g_base - 2, s.T, s.F, s.F, 4 * nxt.ng + 4);
+    } else {
+        const int li = lane & 15, lg = lane >> 4;
+        const u16* wa = tab + (li & 3) * TROW + (2 * lg - (li >> 2) + 3) * C;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) {
+                const u16* wp = wa + (kt * NPL + q) * TKP;
+                wf[kt][q] = cat(*reinterpret_cast<const bf16x4*>(wp), *reinterpret_cast<const bf16x4*>(wp + 4));
+            }
+        if (bias) bv = *reinterpret_cast<const f32x4*>(bias);
+    }
+    stamp(dbg_buf, dbg, 1);
+    __syncthreads();
+    stamp(dbg_buf, dbg, 2);
+    int it = 0;
+    while (havecur) {
+        // piece it + 2 (every wave walks the same list)
+        bool have2 = false;
+        TilePos p2 = nxt;
+        if (havenxt) {
+            const Work w2 = next_work(s, sc, wg, item, nitems);
+            have2 = w2.ng > 0;
+            if (have2) p2 = work_pos(s, w2);
+        }
+        if (stager) {
+            u16* pnxt = planes + ((it + 1) & 1) * NPL * ST::PS;       // every multiplying wave left it at the last barrier
+            if (havenxt && stage)
+                pref_commit<ST, MODE, NPL>(pf, sl, pnxt, nxt.t0 - s.pad_t, 4 * nxt.g_base - 2, s.T, s.F, in_scale, in_shift, alpha, 0, 0, nullptr);
+            if (have2 && stage)
+                pref_load<ST, MASK>(pf, sl, x, mask_src, in_bf16, p2.img, p2.t0 - s.pad_t, 4 * p2.g_base - 2, s.T, s.F, s.F, 4 * p2.ng + 4);
+        } else {
+            const u16* pcur = planes + (it & 1) * NPL * ST::PS;
+            fwd_piece<ST, DIL, OUTMASK, MASK, NPL, true, NMW, (NMW == 8 ? 2 : 0)>(pcur, nullptr, wf, cur, s, wave, lane, it, bv, out_mask, y, out_bf16, alpha, store, nomfma);
+        }
+        if (it == 0) stamp(dbg_buf, dbg, 3);
+        __syncthreads();
+        cur = nxt; havecur = havenxt; nxt = p2; havenxt = have2;
+        ++it;
     }
     stamp(dbg_buf, dbg, 4);
 }
@@ -818,6 +912,18 @@ bool fwd_double_buffered() {
     if (v < 0) { const char* e = getenv("PTTS_C2M_DOUBLE"); v = e ? atoi(e) : 1; }
     return v != 0;
 }
+// dilation 1, fp32 (three planes): the wave-specialised eight-wave kernel (PTTS_C2M_WS, default on) or the four-wave forms below
+int fwd_wave_specialised() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PTTS_C2M_WS"); v = e ? atoi(e) : 1; }
+    return v;           // 0 never, 1 always, 2 only the layers without a BatchNorm affine on their input (the critic's)
+}
+// multiplying waves of the wave-specialised kernel: 4 (one per SIMD) or 8 (two per SIMD, at most two bin groups per pass: 170 registers)
+int fwd_ws_waves() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PTTS_C2M_WS_WAVES"); v = e ? atoi(e) : 4; }
+    return v == 8 ? 8 : 4;
+}
 // the dilation-1 double-buffered kernel with its operand table in registers (the default) or in the LDS (PTTS_C2M_WREG=0):
 // same box, whole train step: critic step 5.07 -> 4.97 ms with the registers
 bool fwd_table_in_registers() {
@@ -898,9 +1004,20 @@ extern "C" int ptts_conv2d_mfma_fwd(const void* x, const void* table, const floa
         hipLaunchKernelGGL((fwd_kernel<DIL, MODE, OM, NPL, NB, WR>), dim3(sc.G), dim3(THREADS), lds, st, x, (const u16*)table, bias, \
                            in_scale, in_shift, mask_src, out_mask, y, dt, s, sc, alpha, g_dbg, g_dbg_buf);               \
     } while (0)
+#define C2M_WSN(MODE, OM, NPL, NMW)                                                                                      \
+    do {                                                                                                                 \
+        constexpr size_t lds = lds_fwd<1, NPL, 2>();                                                                     \
+        static bool attr = false;                                                                                        \
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_ws_kernel<MODE, OM, NPL, NMW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX); attr = true; } \
+        const Sched sc = sched_for(s.ntiles, lds, 1, 1);                                                                 \
+        hipLaunchKernelGGL((fwd_ws_kernel<MODE, OM, NPL, NMW>), dim3(sc.G), dim3((NMW + 4) * 64), lds, st, x, (const u16*)table, bias, \
+                           in_scale, in_shift, mask_src, out_mask, y, dt, s, sc, alpha, g_dbg, g_dbg_buf);               \
+    } while (0)
+#define C2M_WS(MODE, OM, NPL) do { if (fwd_ws_waves() == 8) C2M_WSN(MODE, OM, NPL, 8); else C2M_WSN(MODE, OM, NPL, 4); } while (0)
 #define C2M_L(DIL, MODE, OM, NPL)                                                                                        \
     do {                                                                                                                 \
-        if (DIL == 1 && fwd_double_buffered()) { if (fwd_table_in_registers()) C2M_LB(1, MODE, OM, NPL, 2, true); else C2M_LB(1, MODE, OM, NPL, 2, false); } \
+        if (DIL == 1 && NPL == 3 && (fwd_wave_specialised() == 1 || (fwd_wave_specialised() == 2 && !in_scale))) C2M_WS(MODE, OM, NPL);                                       \
+        else if (DIL == 1 && fwd_double_buffered()) { if (fwd_table_in_registers()) C2M_LB(1, MODE, OM, NPL, 2, true); else C2M_LB(1, MODE, OM, NPL, 2, false); } \
         else C2M_LB(DIL, MODE, OM, NPL, 1, false);                                                                       \
     } while (0)
 #define C2M_M(DIL, NPL)                                                                                                  \
@@ -913,6 +1030,8 @@ extern "C" int ptts_conv2d_mfma_fwd(const void* x, const void* table, const floa
     else if (dil_t == 1) C2M_M(1, 3); else if (dil_t == 2) C2M_M(2, 3); else if (dil_t == 4) C2M_M(4, 3); else C2M_M(8, 3);
 #undef C2M_M
 #undef C2M_L
+#undef C2M_WS
+#undef C2M_WSN
     return check_launch("conv2d_mfma_fwd");
 }
 
