@@ -129,7 +129,8 @@ int ptts_conv2d_reduce_grouped(const ptts_conv2d_reduce_desc* descs, int n, void
  *                             ptts_conv2d_bwd_partials (rows of *npart_out floats behind a 4096-byte head), reduced in a
  *                             fixed order inside a workgroup (no atomics); ptts_conv2d_reduce_grouped adds them up.
  *   ptts_conv2d_mfma_debug    measurement hook of tools/conv2d_mfma_probe.py (phase switches, per-workgroup stamps);
- *                             flags 0 = the product path.
+ *                             flags 0 = the product path; bit 16 alone keeps the results and launches the four-wave form of
+ *                             the dilation-1 fp32 forward kernel instead of the wave-specialised default (A/B in tests).
  * ------------------------------------------------------------------------------------- */
 int ptts_conv2d_mfma_supported(int F, int Cin, int Cout, int KT, int KF, int dil_t);
 size_t ptts_conv2d_mfma_table_bytes(int KT);

@@ -59,6 +59,7 @@ constexpr int DT_IN = 1, DT_OUT = 2, DT_DY = 4;
 // loop, and the compiler executed its 61 constant moves per 24 MFMAs on the normal path too and issued the LDS reads of row
 // kt + 1 AFTER the MFMAs of row kt instead of before them.)
 constexpr int DBG_NOSTAGE = 1, DBG_NOMFMA = 2, DBG_NOSTORE = 4, DBG_STAMPS = 8, DBG_NOBAR = 64;
+constexpr int DBG_FOUR_WAVES = 1 << 16;      // host side only: launch the four-wave form although the wave-specialised one is the default (A/B in tests)
 static int g_dbg = 0;
 static unsigned long long* g_dbg_buf = nullptr;
 __device__ __forceinline__ void stamp(unsigned long long* buf, int dbg, int slot) {
@@ -1016,7 +1017,7 @@ extern "C" int ptts_conv2d_mfma_fwd(const void* x, const void* table, const floa
 #define C2M_WS(MODE, OM, NPL) do { if (fwd_ws_waves() == 8) C2M_WSN(MODE, OM, NPL, 8); else C2M_WSN(MODE, OM, NPL, 4); } while (0)
 #define C2M_L(DIL, MODE, OM, NPL)                                                                                        \
     do {                                                                                                                 \
-        if (DIL == 1 && NPL == 3 && (fwd_wave_specialised() == 1 || (fwd_wave_specialised() == 2 && !in_scale))) C2M_WS(MODE, OM, NPL);                                       \
+        if (DIL == 1 && NPL == 3 && !(g_dbg & DBG_FOUR_WAVES) && (fwd_wave_specialised() == 1 || (fwd_wave_specialised() == 2 && !in_scale))) C2M_WS(MODE, OM, NPL);                                       \
         else if (DIL == 1 && fwd_double_buffered()) { if (fwd_table_in_registers()) C2M_LB(1, MODE, OM, NPL, 2, true); else C2M_LB(1, MODE, OM, NPL, 2, false); } \
         else C2M_LB(DIL, MODE, OM, NPL, 1, false);                                                                       \
     } while (0)

@@ -210,6 +210,39 @@ def test_conv2d_mfma_against_the_oracle_and_the_fp32_stencil(ops, case):
         close(got_s, want, rtol=rt, atol=at, what=nm + ' [fp32 stencil]')
 
 
+@pytest.mark.parametrize('case', [(3, 100, 65), (2, 16, 65), (1, 1, 65), (2, 37, 130), (5, 400, 65)])
+def test_conv2d_mfma_wave_specialised_form_is_bit_identical(ops, case):
+    """The default dilation-1 fp32 forward kernel (c2m::fwd_ws_kernel: eight waves, four stage, four multiply) against the
+    four-wave form it replaced (c2m::fwd_kernel, forced by bit 16 of ptts_conv2d_mfma_debug): same tiles, passes and arithmetic,
+    so forward (LeakyReLU and BatchNorm-affine inputs), masked forward and backward data (with the output mask) are equal bit for bit."""
+    B, T, F = case
+    g = gen(77)
+    x = torch.randn(B, T, F, 4, generator=g).cuda()
+    w = (torch.randn(5, 5, 4, 4, generator=g) * 0.3).cuda()
+    b = torch.randn(4, generator=g).cuda()
+    sc = (torch.rand(4, generator=g) + 0.5).cuda()
+    sh = (torch.randn(4, generator=g) * 0.3).cuda()
+    dy = torch.randn(B, T, F, 4, generator=g).cuda()
+    msk = torch.randn(B, T, F, 4, generator=g).cuda()
+    lib = ops._hip.lib()
+
+    def run():
+        y = ops._conv2d_fwd_raw(x, w, b, None, None, None, ops.IN_LRELU, 0.3, 1, ops.PAD_SAME)
+        ya = ops._conv2d_fwd_raw(x, w, b, sc, sh, None, ops.IN_LRELU, 0.3, 1, ops.PAD_SAME)
+        ym = ops._conv2d_fwd_raw(x, w, None, None, None, msk, ops.IN_MASKMUL, 0.3, 1, ops.PAD_SAME)
+        dx, _, _, _, _ = ops._conv2d_bwd_raw(dy, x, w, None, None, None, ops.IN_LRELU, 0.3, 1, ops.PAD_SAME, True, False, False, False)
+        torch.cuda.synchronize()
+        return y, ya, ym, dx
+    res_ws = run()
+    lib.ptts_conv2d_mfma_debug(1 << 16, None)
+    try:
+        res_4 = run()
+    finally:
+        lib.ptts_conv2d_mfma_debug(0, None)
+    for nm, a, c in zip(('y', 'y (affine)', 'y (maskmul)', 'dx'), res_ws, res_4):
+        assert torch.equal(a, c), nm
+
+
 @pytest.mark.parametrize('in16,out16', [(False, True), (True, True), (True, False)])
 def test_conv2d_bf16_storage_layer(ops, in16, out16):
     """One 4 -> 4 channel 5x5 layer of the bf16-storage path (ops.conv2d(..., bf16=...), csrc/conv2d_mfma.hip with one
