@@ -1017,7 +1017,7 @@ extern "C" int ptts_conv2d_mfma_fwd(const void* x, const void* table, const floa
 #define C2M_WS(MODE, OM, NPL) do { if (fwd_ws_waves() == 8) C2M_WSN(MODE, OM, NPL, 8); else C2M_WSN(MODE, OM, NPL, 4); } while (0)
 #define C2M_L(DIL, MODE, OM, NPL)                                                                                        \
     do {                                                                                                                 \
-        if (DIL == 1 && NPL == 3 && !(g_dbg & DBG_FOUR_WAVES) && (fwd_wave_specialised() == 1 || (fwd_wave_specialised() == 2 && !in_scale))) C2M_WS(MODE, OM, NPL);                                       \
+        if (DIL == 1 && NPL == 3 && !(g_dbg & DBG_FOUR_WAVES) && (fwd_wave_specialised() == 1 || (fwd_wave_specialised() == 2 && !in_scale))) C2M_WS(MODE, OM, 3);                                         \
         else if (DIL == 1 && fwd_double_buffered()) { if (fwd_table_in_registers()) C2M_LB(1, MODE, OM, NPL, 2, true); else C2M_LB(1, MODE, OM, NPL, 2, false); } \
         else C2M_LB(DIL, MODE, OM, NPL, 1, false);                                                                       \
     } while (0)
