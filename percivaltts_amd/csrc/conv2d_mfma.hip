@@ -60,6 +60,9 @@ constexpr int DT_IN = 1, DT_OUT = 2, DT_DY = 4;
 // kt + 1 AFTER the MFMAs of row kt instead of before them.)
 constexpr int DBG_NOSTAGE = 1, DBG_NOMFMA = 2, DBG_NOSTORE = 4, DBG_STAMPS = 8, DBG_NOBAR = 64;
 constexpr int DBG_FOUR_WAVES = 1 << 16;      // host side only: launch the four-wave form although the wave-specialised one is the default (A/B in tests)
+#ifndef C2M_WS_FLAGS
+#define C2M_WS_FLAGS 1
+#endif
 static int g_dbg = 0;
 static unsigned long long* g_dbg_buf = nullptr;
 __device__ __forceinline__ void stamp(unsigned long long* buf, int dbg, int slot) {
@@ -633,6 +636,23 @@ __global__ __launch_bounds__((NMW + 4) * 64, 1) void fwd_ws_kernel(
             }
         if (bias) bv = *reinterpret_cast<const f32x4*>(bias);
     }
+    // Hand-off of the plane buffers by COUNTERS in the LDS instead of a workgroup barrier per piece (C2M_WS_FLAGS): piece p lives in
+    // buffer p & 1, use u = p >> 1.  ready[b] counts the staging waves' commits into buffer b, done[b] the multiplying waves that have
+    // finished reading it: a multiplying wave starts piece p when ready[p & 1] == 4 (u + 1), a staging wave commits piece p when
+    // done[p & 1] == NMW u.  The multiplying waves then drift against each other by up to a piece -- 17 bin groups over four waves is
+    // 5 + 4 + 4 + 4 with the fifth rotating, and a barrier per piece makes every piece last as long as five.  Every poll is bounded
+    // (a count that never arrives ends the wait after ~1 ms and the results are wrong, not the GPU hung).
+    int* const flags = reinterpret_cast<int*>(lds + 2 * NPL * ST::PS);       // ready[2] | done[2]  (the operand table's unused LDS slot)
+    if (C2M_WS_FLAGS && tid == 0) { flags[0] = 4; flags[1] = 0; flags[2] = 0; flags[3] = 0; }
+    auto wait_for = [&](int idx, int target) {
+        for (int r = 0; r < (1 << 14); ++r) {
+            if (__hip_atomic_load(flags + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+    };
+    auto signal = [&](int idx) {
+        if (lane == 0) __hip_atomic_fetch_add(flags + idx, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
     stamp(dbg_buf, dbg, 1);
     __syncthreads();
     stamp(dbg_buf, dbg, 2);
@@ -647,17 +667,23 @@ __global__ __launch_bounds__((NMW + 4) * 64, 1) void fwd_ws_kernel(
             if (have2) p2 = work_pos(s, w2);
         }
         if (stager) {
-            u16* pnxt = planes + ((it + 1) & 1) * NPL * ST::PS;       // every multiplying wave left it at the last barrier
-            if (havenxt && stage)
-                pref_commit<ST, MODE, NPL>(pf, sl, pnxt, nxt.t0 - s.pad_t, 4 * nxt.g_base - 2, s.T, s.F, in_scale, in_shift, alpha, 0, 0, nullptr);
+            u16* pnxt = planes + ((it + 1) & 1) * NPL * ST::PS;       // every multiplying wave left it at the last barrier / its done count
+            if (havenxt) {
+                if (C2M_WS_FLAGS) wait_for(2 + ((it + 1) & 1), NMW * ((it + 1) >> 1));
+                if (stage)
+                    pref_commit<ST, MODE, NPL>(pf, sl, pnxt, nxt.t0 - s.pad_t, 4 * nxt.g_base - 2, s.T, s.F, in_scale, in_shift, alpha, 0, 0, nullptr);
+                if (C2M_WS_FLAGS) signal((it + 1) & 1);
+            }
             if (have2 && stage)
                 pref_load<ST, MASK>(pf, sl, x, mask_src, in_bf16, p2.img, p2.t0 - s.pad_t, 4 * p2.g_base - 2, s.T, s.F, s.F, 4 * p2.ng + 4);
         } else {
             const u16* pcur = planes + (it & 1) * NPL * ST::PS;
+            if (C2M_WS_FLAGS) wait_for(it & 1, 4 * ((it >> 1) + 1));
             fwd_piece<ST, DIL, OUTMASK, MASK, NPL, true, NMW, (NMW == 8 ? 2 : 0)>(pcur, nullptr, wf, cur, s, wave, lane, it, bv, out_mask, y, out_bf16, alpha, store, nomfma);
+            if (C2M_WS_FLAGS) signal(2 + (it & 1));
         }
         if (it == 0) stamp(dbg_buf, dbg, 3);
-        __syncthreads();
+        if (!C2M_WS_FLAGS) __syncthreads();
         cur = nxt; havecur = havenxt; nxt = p2; havenxt = have2;
         ++it;
     }
