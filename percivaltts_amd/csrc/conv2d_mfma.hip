@@ -60,6 +60,9 @@ constexpr int DT_IN = 1, DT_OUT = 2, DT_DY = 4;
 // kt + 1 AFTER the MFMAs of row kt instead of before them.)
 constexpr int DBG_NOSTAGE = 1, DBG_NOMFMA = 2, DBG_NOSTORE = 4, DBG_STAMPS = 8, DBG_NOBAR = 64;
 constexpr int DBG_FOUR_WAVES = 1 << 16;      // host side only: launch the four-wave form although the wave-specialised one is the default (A/B in tests)
+#ifndef C2M_WS_NMAX
+#define C2M_WS_NMAX 0      // groups per pass of the wave-specialised kernel's multiplying waves: 0 = 5 (4 with mask values)
+#endif
 #ifndef C2M_WS_FLAGS
 #define C2M_WS_FLAGS 1
 #endif
@@ -679,7 +682,7 @@ __global__ __launch_bounds__((NMW + 4) * 64, 1) void fwd_ws_kernel(
         } else {
             const u16* pcur = planes + (it & 1) * NPL * ST::PS;
             if (C2M_WS_FLAGS) wait_for(it & 1, 4 * ((it >> 1) + 1));
-            fwd_piece<ST, DIL, OUTMASK, MASK, NPL, true, NMW, (NMW == 8 ? 2 : 0)>(pcur, nullptr, wf, cur, s, wave, lane, it, bv, out_mask, y, out_bf16, alpha, store, nomfma);
+            fwd_piece<ST, DIL, OUTMASK, MASK, NPL, true, NMW, (NMW == 8 ? 2 : C2M_WS_NMAX)>(pcur, nullptr, wf, cur, s, wave, lane, it, bv, out_mask, y, out_bf16, alpha, store, nomfma);
             if (C2M_WS_FLAGS) signal(2 + (it & 1));
         }
         if (it == 0) stamp(dbg_buf, dbg, 3);
