@@ -38,6 +38,7 @@ extern "C" {
 #define PTTS_EINVAL       -1   /* bad argument / unsupported shape */
 #define PTTS_ELAUNCH      -2   /* hipLaunch failed */
 #define PTTS_EWORKSPACE   -3   /* workspace too small */
+#define PTTS_EDEVICE      -4   /* a kernel reported a failed hand-off (sticky device status word, see ptts_device_status) */
 
 /* input transforms (applied on load; x is what lies in HBM) */
 #define PTTS_IN_NONE     0   /* a = x                                   */
@@ -57,6 +58,19 @@ extern "C" {
 const char* ptts_version(void);
 const char* ptts_device_arch(void);     /* "gfx950" : the only code object in the library */
 const char* ptts_last_error(void);      /* thread-local message of the last failure */
+/* Device status.  Kernels whose waves wait for each other with bounded polls (the wave-specialised Conv2D forward's LDS-counter
+ * hand-off, the persistent LSTM's granule hand-off) do not hang when a count never arrives -- and do not stay silent either: the
+ * wave that gave up stores a code into a block of pinned, device-mapped host memory.  The word is STICKY: ptts_device_status()
+ * returns PTTS_EDEVICE (message in ptts_last_error(), bit mask in *word_out: 1 = Conv2D hand-off, 2 = LSTM hand-off) from then on,
+ * and so does every later ptts_conv2d_mfma_fwd / ptts_lstm_fwd call, until ptts_device_status_clear().  Reading it is a host
+ * memory load (no synchronisation): call it at step boundaries.  The reference has no counterpart (TF raises from Session.run,
+ * optimizertts.py:254 turns a NaN cost into a ValueError); this is how a corrupted launch becomes an error instead of a bad step.
+ * ptts_device_status_word() returns the HOST address of the first word (tests poke it to exercise the host logic without a GPU);
+ * ptts_device_status_message() decodes a mask. */
+int ptts_device_status(unsigned* word_out);
+int ptts_device_status_clear(void);
+unsigned* ptts_device_status_word(void);
+int ptts_device_status_message(unsigned word, char* buf, size_t n);
 /* Deterministic mode: reductions over workgroups in a fixed order only (no fp32 atomics: stream-K GEMM tiles, the
  * thin weight-gradient kernel and the loss scalars take their single-pass forms).  Returns the previous setting. */
 int ptts_set_deterministic(int on);

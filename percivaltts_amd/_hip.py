@@ -44,6 +44,10 @@ SIGNATURES = {
     'ptts_version': (ctypes.c_char_p, []),
     'ptts_device_arch': (ctypes.c_char_p, []),
     'ptts_last_error': (ctypes.c_char_p, []),
+    'ptts_device_status': (c_i, [c_p]),
+    'ptts_device_status_clear': (c_i, []),
+    'ptts_device_status_word': (c_p, []),
+    'ptts_device_status_message': (c_i, [ctypes.c_uint, ctypes.c_char_p, c_sz]),
     'ptts_set_deterministic': (c_i, [c_i]),
     'ptts_get_deterministic': (c_i, []),
     'ptts_set_bf16_products': (c_i, [c_i]),
@@ -191,6 +195,18 @@ def call(name, *args, **kw):
         timer.records.append((name, kw.get('tag'), s, e))
     if rc != 0:
         raise HipLibraryError('{} failed (rc={}): {}'.format(name, rc, last_error()))
+
+
+def check_status():
+    """Raise HipLibraryError if a kernel has reported a failed hand-off since the last clear_status() (the sticky device status
+    word of include/percival_hip.h).  A host memory load, no synchronisation: the optimiser calls it at every step boundary."""
+    rc = lib().ptts_device_status(None)
+    if rc != 0:
+        raise HipLibraryError('device status (rc={}): {}'.format(rc, last_error()))
+
+
+def clear_status():
+    lib().ptts_device_status_clear()
 
 
 def stream_id():

@@ -18,6 +18,20 @@ bool bf16_products();
 int zero_f32(float* p, size_t n, hipStream_t st);
 int zero_f32_2d(float* p, size_t ld, size_t cols, size_t rows, hipStream_t st);
 
+// Device status words (core.hip).  Two kernels let waves wait for each other with BOUNDED polls (the LDS-counter hand-off of
+// c2m::fwd_ws_kernel, the granule hand-off of lstm_fwd_persistent_kernel): a poll that runs out means the results of that launch are
+// wrong.  The kernel then stores its code into its slot of a small block of pinned, device-mapped host memory (a plain system-scope
+// store: sticky, because nothing on the device ever clears it), and every later C-ABI call of the same family -- and
+// ptts_device_status(), which the Python layer calls at each step boundary -- returns PTTS_EDEVICE until ptts_device_status_clear().
+// Reading the words costs the host a memory load, no synchronisation.
+constexpr int STATUS_SLOT_C2M = 0, STATUS_SLOT_LSTM = 1, STATUS_SLOTS = 2;
+constexpr unsigned STATUS_C2M_HANDOFF = 0x1u, STATUS_LSTM_HANDOFF = 0x2u;
+unsigned* status_words();                 // device-visible pointer to STATUS_SLOTS words; never null
+int check_status(const char* what);       // PTTS_OK, or PTTS_EDEVICE with the message set
+__device__ __forceinline__ void raise_status(unsigned* words, int slot, unsigned code) {
+    __hip_atomic_store(words + slot, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

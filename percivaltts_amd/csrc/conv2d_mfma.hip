@@ -59,6 +59,9 @@ constexpr int DT_IN = 1, DT_OUT = 2, DT_DY = 4;
 // loop, and the compiler executed its 61 constant moves per 24 MFMAs on the normal path too and issued the LDS reads of row
 // kt + 1 AFTER the MFMAs of row kt instead of before them.)
 constexpr int DBG_NOSTAGE = 1, DBG_NOMFMA = 2, DBG_NOSTORE = 4, DBG_STAMPS = 8, DBG_NOBAR = 64;
+// bit 7 (tests/test_ops_gpu.py): the multiplying waves of the wave-specialised forward wait for a count that never comes, with a
+// short bound -- the hand-off's time-out path on demand (wrong results by construction, and the device status word set)
+constexpr int DBG_FORCE_TIMEOUT = 128;
 constexpr int DBG_FOUR_WAVES = 1 << 16;      // host side only: launch the four-wave form although the wave-specialised one is the default (A/B in tests)
 #ifndef C2M_WS_NMAX
 #define C2M_WS_NMAX 0      // groups per pass of the wave-specialised kernel's multiplying waves: 0 = 5 (4 with mask values)
@@ -590,7 +593,8 @@ template <int MODE, bool OUTMASK, int NPL, int NMW>
 __global__ __launch_bounds__((NMW + 4) * 64, 1) void fwd_ws_kernel(
     const void* __restrict__ x, const u16* __restrict__ tab, const float* __restrict__ bias,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, const void* __restrict__ mask_src,
-    const void* __restrict__ out_mask, void* __restrict__ y, int dt, Shape s, Sched sc, float alpha, int dbg, unsigned long long* dbg_buf) {
+    const void* __restrict__ out_mask, void* __restrict__ y, int dt, Shape s, Sched sc, float alpha, int dbg, unsigned long long* dbg_buf,
+    unsigned* status) {
     constexpr int DIL = 1;
     typedef Stage<4 * GPB + 4, 16 + (KT - 1) * DIL> ST;
     extern __shared__ __attribute__((aligned(16))) u16 lds[];
@@ -643,15 +647,23 @@ __global__ __launch_bounds__((NMW + 4) * 64, 1) void fwd_ws_kernel(
     // buffer p & 1, use u = p >> 1.  ready[b] counts the staging waves' commits into buffer b, done[b] the multiplying waves that have
     // finished reading it: a multiplying wave starts piece p when ready[p & 1] == 4 (u + 1), a staging wave commits piece p when
     // done[p & 1] == NMW u.  The multiplying waves then drift against each other by up to a piece -- 17 bin groups over four waves is
-    // 5 + 4 + 4 + 4 with the fifth rotating, and a barrier per piece makes every piece last as long as five.  Every poll is bounded
-    // (a count that never arrives ends the wait after ~1 ms and the results are wrong, not the GPU hung).
+    // 5 + 4 + 4 + 4 with the fifth rotating, and a barrier per piece makes every piece last as long as five.  Every poll is bounded:
+    // all eight waves of the workgroup are co-resident and every count is produced by a wave that waits for nothing but an earlier
+    // count, so the bound (~1 ms) is never reached by the protocol itself -- only by a stall from outside (preemption, a debugger,
+    // counter serialisation).  A wave whose poll does run out goes on (the GPU does not hang) but the launch's results are wrong, so it
+    // stores STATUS_C2M_HANDOFF into the device status word: the C ABI returns PTTS_EDEVICE from the next call on (common.h).
     int* const flags = reinterpret_cast<int*>(lds + 2 * NPL * ST::PS);       // ready[2] | done[2]  (the operand table's unused LDS slot)
     if (C2M_WS_FLAGS && tid == 0) { flags[0] = 4; flags[1] = 0; flags[2] = 0; flags[3] = 0; }
+    const bool force_timeout = (dbg & DBG_FORCE_TIMEOUT) != 0;
     auto wait_for = [&](int idx, int target) {
-        for (int r = 0; r < (1 << 14); ++r) {
+        const int bound = force_timeout ? 8 : (1 << 14);
+        if (force_timeout && !stager) target += 1 << 20;
+        int r = 0;
+        for (; r < bound; ++r) {
             if (__hip_atomic_load(flags + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) break;
             __builtin_amdgcn_s_sleep(2);
         }
+        if (r == bound && lane == 0) raise_status(status, STATUS_SLOT_C2M, STATUS_C2M_HANDOFF);
     };
     auto signal = [&](int idx) {
         if (lane == 0) __hip_atomic_fetch_add(flags + idx, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1007,6 +1019,7 @@ extern "C" int ptts_conv2d_mfma_fwd(const void* x, const void* table, const floa
                                     const float* in_shift, const void* mask_src, const void* out_mask, void* y,
                                     int B, int T, int F, int KT_, int dil_t, int pad_t, int in_mode, float alpha,
                                     int planes, int in_bf16, int out_bf16, void* stream) {
+    if (int rc = check_status("conv2d_mfma_fwd")) return rc;      // an earlier launch reported a failed hand-off: sticky
     PTTS_REQUIRE(x && table && y, "conv2d_mfma_fwd: null tensor");
     PTTS_REQUIRE(B > 0 && T > 0 && F > 0 && KT_ == 5, "conv2d_mfma_fwd: bad dims B=%d T=%d F=%d KT=%d", B, T, F, KT_);
     PTTS_REQUIRE(dil_t == 1 || dil_t == 2 || dil_t == 4 || dil_t == 8, "conv2d_mfma_fwd: time dilation %d has no kernel (1, 2, 4, 8)", dil_t);
@@ -1041,7 +1054,7 @@ extern "C" int ptts_conv2d_mfma_fwd(const void* x, const void* table, const floa
         if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_ws_kernel<MODE, OM, NPL, NMW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX); attr = true; } \
         const Sched sc = sched_for(s.ntiles, lds, 1, 1);                                                                 \
         hipLaunchKernelGGL((fwd_ws_kernel<MODE, OM, NPL, NMW>), dim3(sc.G), dim3((NMW + 4) * 64), lds, st, x, (const u16*)table, bias, \
-                           in_scale, in_shift, mask_src, out_mask, y, dt, s, sc, alpha, g_dbg, g_dbg_buf);               \
+                           in_scale, in_shift, mask_src, out_mask, y, dt, s, sc, alpha, g_dbg, g_dbg_buf, status_words()); \
     } while (0)
 #define C2M_WS(MODE, OM, NPL) do { if (fwd_ws_waves() == 8) C2M_WSN(MODE, OM, NPL, 8); else C2M_WSN(MODE, OM, NPL, 4); } while (0)
 #define C2M_L(DIL, MODE, OM, NPL)                                                                                        \

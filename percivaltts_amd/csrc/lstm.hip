@@ -480,11 +480,13 @@ static inline bool lstm_pk_ok(int H) { return H % 64 == 0 && ((H / 16) <= 16 ? t
 // member of its group, never two (it needs that member's h first).  Group = blockIdx % groups, so with groups = 8 (B = 64,
 // both directions) the 32 members of a group sit on one XCD (workgroups go to XCDs round-robin); any other placement is
 // slower, not wrong.  A poll that does not match within ~2^21 rounds (seconds: a workgroup of the group never became
-// resident) gives up for good and lets NaNs through, which the training loop reports as a NaN cost -- no hang.
+// resident) gives up for good: no hang, NaNs in the outputs from that step on AND STATUS_LSTM_HANDOFF in the device status word
+// (common.h), so that ptts_lstm_fwd / ptts_device_status return PTTS_EDEVICE from the next call on instead of a silent bad step.
 // ------------------------------------------------------------------------------------------------
 struct LstmPersistArgs {
     const float* xproj; const float* Upk; float* h_out; float* gates; float* c_out; unsigned long long* xbuf;
     int B, T, ndir, reverse, groups;
+    unsigned* status;
 };
 
 __global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(LstmPersistArgs a) {
@@ -542,7 +544,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(LstmPersistArg
                 for (int i = 0; i < KS; ++i) ok = ok && (unsigned)(gr[i] >> 32) == (unsigned)s;
                 if (__all(ok || !feeds) || gave_up) break;
                 __builtin_amdgcn_s_sleep(1);
-                if (++rounds > (1 << 21)) { gave_up = true; give_up = 1; }
+                if (++rounds > (1 << 21)) {
+                    gave_up = true; give_up = 1;
+                    if (lane == 0) raise_status(a.status, STATUS_SLOT_LSTM, STATUS_LSTM_HANDOFF);
+                }
             }
             f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -723,11 +728,13 @@ extern "C" int ptts_lstm_fwd(const float* xproj, const float* U, float* h_out, f
     if (lstm_pk_ok(H) && workspace && workspace_bytes >= ptts_lstm_fwd_workspace_bytes(B, T, H, ndir)) {
         float* Upk = (float*)workspace;
         if (lstm_persistent_ok(B, T, H, ndir)) {
+            if (int rc0 = check_status("lstm_fwd")) return rc0;       // an earlier persistent launch gave up: sticky
             hipLaunchKernelGGL(lstm_pack_u_fwd_kernel, dim3(1024), dim3(256), 0, st, U, Upk, H, ndir);
             LstmPersistArgs pa;
             pa.xproj = xproj; pa.Upk = Upk; pa.h_out = h_out; pa.gates = gates; pa.c_out = c_out;
             pa.xbuf = reinterpret_cast<unsigned long long*>(Upk + (size_t)ndir * 4 * H * H);
             pa.B = B; pa.T = T; pa.ndir = ndir; pa.reverse = reverse; pa.groups = ((B + 15) / 16) * ndir;
+            pa.status = status_words();
             int rc = zero_f32(reinterpret_cast<float*>(pa.xbuf), (size_t)2 * pa.groups * 16 * H * 2, st);      // tags 0
             if (rc) return rc;
             hipLaunchKernelGGL(lstm_fwd_persistent_kernel, dim3(pa.groups * 32), dim3(256), 0, st, pa);

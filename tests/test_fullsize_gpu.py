@@ -1,5 +1,7 @@
 """Parity at BASELINE.json's full size (configs[1]: B=64, T=400, ctx=601, 86 outputs, H=256, 8 x Conv2D(4, 5x5)),
-where the CPU oracle needs minutes per step: size-independent properties of the domain plus oracle checks on crops.
+size-independent properties of the domain plus oracle checks on crops at B = 64, and (round 4, at the end of the file) the fp64
+oracle against the whole networks at full width: predict, a critic step at B = 16 with every gradient, its loss parts at B = 64,
+a generator step at B = 12.
 
  * the kernels at the real layer shapes against the fp64 oracle on crops (conv2d with its halo) / row samples (GEMM);
  * linearity of the convolution and of the GEMM at full size;
@@ -637,3 +639,232 @@ def test_gated_dilated_causal_generator_at_T2000():
     assert torch.isfinite(lc) and torch.isfinite(lg), (float(lc), float(lg))
     assert torch.isfinite(opt.critic_opti.flat.grad).all() and torch.isfinite(opt.gen_opti.flat.grad).all()
     assert float(opt.gen_opti.flat.grad.abs().max()) > 0 and float(opt.critic_opti.flat.grad.abs().max()) > 0
+
+
+# ---- round 4: the fp64 oracle against the BASELINE ARCHITECTURE end to end (H = 256, ctx = 601, L = 8, C = 4, spec 65, nm 20) ----
+# The CPU oracle does a B = 16, T = 400 critic step with all gradients in seconds (fp64, host cores), so the whole networks at
+# full width meet it: predict (modeltts.py:68-69), the critic loss parts and every weight gradient (optimizertts_wgan.py:115-154),
+# the generator loss, gradients and BatchNorm moving statistics (:157-213).  Weights and the interpolation weights alpha are
+# injected (the reference draws both from TF's RNG).
+@pytest.fixture(scope='module')
+def full_arch():
+    import bench
+    import percivaltts_amd
+    from percivaltts_amd import vocoders, modeltts_common, networks_critic, optimizertts_wgan
+
+    class A: batch = 16; frames = T; ctx = CTX
+    cfg = bench.make_cfg(A)
+    cfg.train_wgan_critic_LSWGANtransidx = 30.0
+    voc = vocoders.VocoderPML(16000, 0.005, SPEC, NM)
+    a = O.Arch(CTX, SPEC, NM, 256, 1, 21, 8, 4, 5, 5)
+    # IDENTICAL inputs on both sides: weights (and, below, inputs and alpha) are fp32-representable values held in fp64 by the
+    # oracle -- what is compared is the arithmetic, not the rounding of the operands on their way to the device
+    gw = [w.float().double() for w in O.random_weights(O.generator_weight_shapes(a), seed=11)]
+    cw = [w.float().double() for w in O.random_weights(O.critic_weight_shapes(a), seed=12)]
+    with contextlib.redirect_stdout(io.StringIO()):
+        mod = modeltts_common.DCNNF0SpecNoiseFeatures(CTX, voc, cfg)
+        crit = networks_critic.Critic(voc, CTX, cfg)
+        assert mod.count_params() == O.count_params(O.generator_weight_shapes(a)) == 4707471
+        assert crit.model.count_params() == O.count_params(O.critic_weight_shapes(a)) == 3629941
+        mod.kerasmodel.set_weights([w.numpy() for w in gw])
+        crit.model.set_weights([w.numpy() for w in cw])
+        opt = optimizertts_wgan.OptimizerTTSWGAN(cfg, mod, errtype='WLSWGAN', critic=crit)
+        opt.prepare()
+    return cfg, mod, crit, opt, a, gw, cw
+
+
+def _full_inputs(Bq, seed):
+    g = torch.Generator().manual_seed(seed)
+    X = torch.rand(Bq, T, CTX, generator=g, dtype=torch.float64) * 2 - 1
+    Y = torch.randn(Bq, T, 1 + SPEC + NM, generator=g, dtype=torch.float64)
+    Y[:, :, 1 + SPEC:] = torch.rand(Bq, T, NM, generator=g, dtype=torch.float64)
+    al = torch.rand(Bq, generator=g, dtype=torch.float64)
+    return X.float().double(), Y.float().double(), al.float().double()
+
+
+def _reset_weights(mod, crit, opt, gw, cw):
+    """The tests below share one pair of networks: put the injected weights (and BatchNorm moving statistics) back."""
+    from percivaltts_amd import ops
+    opt.wait_updates()
+    mod.kerasmodel.set_weights([w.detach().numpy() for w in gw])
+    crit.model.set_weights([w.detach().numpy() for w in cw])
+    opt.gen_opti.flat.epoch += 1; opt.critic_opti.flat.epoch += 1
+    ops.clear_caches()
+
+
+def _f32(t):
+    return t.to(torch.float32).cuda().contiguous()
+
+
+def test_predict_at_baseline_architecture_against_oracle(full_arch):
+    """ModelTTS.predict (reference modeltts.py:68-69) on [2,400,601] at H = 256: all 86 output columns within the north
+    star's rtol 1e-3 of the fp64 oracle (BatchNorm on its moving statistics, BLSTM over 400 frames, the 8-layer conv stack)."""
+    import numpy as np
+    cfg, mod, crit, opt, a, gw, cw = full_arch
+    _reset_weights(mod, crit, opt, gw, cw)
+    X, _, _ = _full_inputs(2, 41)
+    want = O.generator_forward([w.detach() for w in gw], a, X, training=False)
+    got = torch.as_tensor(mod.predict(X.numpy().astype(np.float32)))
+    assert tuple(got.shape) == (2, T, 86)
+    scale = float(want.abs().mean())
+    close(got, want, 1e-3, 1e-3 * scale, 'predict, all 86 columns')
+    for name, lo, hi in (('f0', 0, 1), ('spec', 1, 1 + SPEC), ('noise', 1 + SPEC, 86)):
+        assert rel_l2(got[:, :, lo:hi], want[:, :, lo:hi]) < 1e-4, (name, rel_l2(got[:, :, lo:hi], want[:, :, lo:hi]))
+
+
+def _critic_step_device(opt, Xd, Yd, ald, part=None):
+    """The device side of a critic step up to (not including) the update, as OptimizerTTSWGAN._critic_grads runs it, keeping the
+    loss parts (part = 0 / 1 / 2: only that part is backpropagated); returns (total, parts, C-ABI call names)."""
+    from percivaltts_amd import ops, _hip
+    opt.critic_opti.zero_grad()
+    with _hip.KernelTimer() as kt:
+        with ops.deferred_weight_grads():
+            total, parts = opt.critic_loss(Xd, Yd, ald, training=True)
+            (total if part is None else parts[part]).backward()
+    torch.cuda.synchronize()
+    return total, parts, [r[0] for r in kt.records]
+
+
+def test_critic_step_at_baseline_architecture_against_oracle(full_arch):
+    """One critic step at B = 16, T = 400 (6 400 frames: the frequency-domain context Conv1D, the split Dense kernels, the two-stage
+    weight gradients and the matrix-core Conv2D kernels are what runs -- asserted) against fp64 `critic_step_loss`
+    (reference optimizertts_wgan.py:115-154) on identical fp32-representable weights, inputs and alpha: the three loss parts at 5e-4
+    and EVERY weight-gradient tensor by relative L2, with no per-tensor escape.
+
+    How the gradient bounds are set.  The critic loss is -mean D(y) + mean D(G(x)) + 10 gp, and for the CONTEXT branch (Conv1D +
+    two Dense layers: it sees the same context frames in both evaluations and the penalty does not reach it) the two Wasserstein
+    terms nearly cancel: |g_total| is 0.6 ... 1 % of |g_valid| + |g_fake| there (tools/fullarch_debug.py).  An error of 1e-5 of the
+    parts is then 1e-3 of the total -- for ANY fp32 evaluation: the oracle itself run in fp32 is off by 4.7e-3 / 3.2e-3 / 2.5e-3 on
+    those three kernels against fp64, the device by 4.8e-3 / 3.2e-3 / 2.5e-3.  So (1) each PART's gradient is checked against the
+    oracle's gradient of that part, relative to its own norm -- the stringent check, nothing cancels inside a part; (2) the total's
+    tensors are bounded relative to the sum of their parts' norms (the conditioning-aware form of "relative L2"), and over the whole
+    network relative to the total.  The Conv1D kernel's gradient keeps a wider bound than the other tensors inside a part: its
+    signal sum_t x[t+k] dz[t] is an incoherent sum over white-noise context frames, so ONE LeakyReLU mask that falls on the other side
+    of zero in fp32 (1 of 1.6 M pre-activations, |z| < 1e-6 rms) already moves it by 0.7 / sqrt(1.6 M) = 5.5e-4 of its norm; two
+    different weight-gradient kernels (frequency and time domain) fed the same dz agree to 8e-7."""
+    cfg, mod, crit, opt, a, gw, cw = full_arch
+    _reset_weights(mod, crit, opt, gw, cw)
+    X, Y, al = _full_inputs(16, 42)
+    cwr = [w.detach().clone().requires_grad_(True) for w in cw]
+    total, parts = O.critic_step_loss(cwr, [w.detach() for w in gw], a, X, Y, al, gp_lambda=10.0)
+    pg = [torch.autograd.grad(parts[k], cwr, retain_graph=True, allow_unused=True) for k in ('valid', 'fake', 'gp')]
+    grads = torch.autograd.grad(total, cwr)
+    Xd, Yd, ald = _f32(X), _f32(Y), _f32(al)
+    params = opt.critic_opti.flat.params
+    zero = lambda p: torch.zeros(tuple(p.shape), dtype=torch.float64)
+
+    # (1) the three parts, each against its own gradient
+    for ki, kname in enumerate(('valid', 'fake', 'gp')):
+        _critic_step_device(opt, Xd, Yd, ald, part=ki)
+        want = [g_ if g_ is not None else zero(p) for p, g_ in zip(params, pg[ki])]
+        gmax = max(float(w_.norm()) for w_ in want)
+        num = den = 0.0
+        for p, w_ in zip(params, want):
+            e = float((p.grad.detach().cpu().double() - w_).norm()); n = float(w_.norm())
+            num += e * e; den += n * n
+            bound = 3e-3 if tuple(w_.shape) == (21, CTX, 256) else 5e-4
+            assert e <= bound * max(n, 1e-4 * gmax), 'gradient of the {} part, tensor {}: relative L2 error {:.3e}'.format(
+                kname, tuple(w_.shape), e / max(n, 1e-300))
+        assert num <= (1e-3 ** 2) * den, 'gradient of the {} part: relative L2 error {:.3e} over all tensors'.format(kname, (num / den) ** 0.5)
+        print('critic step B=16, part {}: all-network gradient rel L2 {:.3e}'.format(kname, (num / den) ** 0.5))
+
+    # (2) the step itself: loss parts, which kernels ran, the total gradient
+    tot_d, (lv, lf, gp), names = _critic_step_device(opt, Xd, Yd, ald)
+    close(lv, parts['valid'], 5e-4, 1e-5, 'L valid')
+    close(lf, parts['fake'], 5e-4, 1e-5, 'L fake')
+    close(gp, parts['gp'], 5e-4, 1e-5, 'gradient penalty')
+    close(tot_d, total, 5e-4, 1e-5, 'critic loss')
+    # the kernels of the BASELINE-size step ran, not their small-shape fallbacks
+    for need in ('ptts_dense_bf16x6_batched', 'ptts_split3_frame_windows', 'ptts_conv1d_freq_wgrad_inverse',     # frequency-domain Conv1D
+                 'ptts_dense_bf16x6', 'ptts_dense_wgrad_bf16x6_partials', 'ptts_dense_wgrad_reduce_grouped',      # split Dense + two-stage dW
+                 'ptts_conv2d_mfma_fwd', 'ptts_conv2d_mfma_wgrad_partials', 'ptts_conv2d_reduce_grouped'):
+        assert need in names, '{} did not run in the B = 16 critic step: {}'.format(need, sorted(set(names)))
+    num = den = 0.0
+    worst = (0.0, None)
+    for i, (p, g_) in enumerate(zip(params, grads)):
+        e = float((p.grad.detach().cpu().double() - g_).norm()); n = float(g_.norm())
+        num += e * e; den += n * n
+        nparts = sum(float(pg[k][i].norm()) for k in range(3) if pg[k][i] is not None)
+        r = e / max(nparts, 1e-300) if nparts > 0 else 0.0
+        if r > worst[0]: worst = (r, tuple(g_.shape))
+        # (the output bias: exactly zero on both sides -- the Wasserstein terms cancel it, the penalty does not see it)
+        bound = 1e-3 if tuple(g_.shape) == (21, CTX, 256) else 3e-4       # (the Conv1D kernel: one flipped mask = 5.5e-4 of a part, see above)
+        assert e <= bound * nparts, 'critic gradient {}: error {:.3e} of the parts\' norms ({:.3e} of its own)'.format(tuple(g_.shape), r, e / max(n, 1e-300))
+    assert num <= (3e-3 ** 2) * den, 'critic gradients: relative L2 error {:.3e} over all tensors'.format((num / den) ** 0.5)
+    print('critic step B=16: all-network gradient rel L2 {:.3e}; worst tensor against its parts {} {:.3e}'.format((num / den) ** 0.5, worst[1], worst[0]))
+
+
+def test_critic_loss_parts_at_batch_64_against_oracle(full_arch):
+    """The same at BASELINE configs[1]'s own batch, B = 64, T = 400: the three loss parts against the fp64 oracle (its loss alone
+    is ~30 s of host time; the gradients are covered at B = 16 above and by the shard-mean property at B = 64)."""
+    cfg, mod, crit, opt, a, gw, cw = full_arch
+    _reset_weights(mod, crit, opt, gw, cw)
+    X, Y, al = _full_inputs(64, 43)
+    with torch.no_grad():
+        gwd = [w.detach() for w in gw]; cwd = [w.detach() for w in cw]
+        fake = O.generator_forward(gwd, a, X, training=True)
+        valid = O.critic_forward(cwd, a, Y, X)
+        fake_v = O.critic_forward(cwd, a, fake, X)
+    x_hat = O.random_weighted_average(Y, fake, al).detach().requires_grad_(True)
+    v_hat = O.critic_forward(cwd, a, x_hat, X)
+    g = torch.autograd.grad(v_hat.sum(), x_hat)[0]
+    gp_want = ((1 - torch.sqrt((g * g).sum(dim=(1, 2)))) ** 2).mean()
+    tot_d, (lv, lf, gp), names = _critic_step_device(opt, _f32(X), _f32(Y), _f32(al))
+    close(lv, -valid.mean(), 5e-4, 1e-5, 'L valid, B = 64')
+    close(lf, fake_v.mean(), 5e-4, 1e-5, 'L fake, B = 64')
+    close(gp, gp_want, 5e-4, 1e-5, 'gradient penalty, B = 64')
+    close(tot_d, -valid.mean() + fake_v.mean() + 10.0 * gp_want, 5e-4, 1e-5, 'critic loss, B = 64')
+    assert torch.isfinite(opt.critic_opti.flat.grad).all()
+
+
+def test_generator_step_at_baseline_architecture_against_oracle(full_arch):
+    """One generator step at B = 12, T = 400 (4 800 frames: above the 4 096 at which the frequency-domain Conv1D and the split
+    weight gradients take over) against fp64 `generator_step_loss` (reference optimizertts_wgan.py:157-213): both loss terms, every
+    trainable tensor's gradient by relative L2, and the BatchNorm moving statistics after the training forward."""
+    from percivaltts_amd import ops
+    cfg, mod, crit, opt, a, gw, cw = full_arch
+    _reset_weights(mod, crit, opt, gw, cw)
+    X, Y, _ = _full_inputs(12, 44)
+    shapes = O.generator_weight_shapes(a)
+    trainable, i = [], 0
+    while i < len(shapes):      # everything except the BatchNorm moving statistics (3rd / 4th of each run of four equal 1-D shapes)
+        if len(shapes[i]) == 1 and i + 3 < len(shapes) and all(shapes[i + k] == shapes[i] for k in range(4)):
+            trainable += [i, i + 1]; i += 4
+        else:
+            trainable.append(i); i += 1
+    gw_t = [w.detach().clone() for w in gw]
+    for i in trainable: gw_t[i].requires_grad_(True)
+    w_ls, ww = O.wls_weights(a.specsize, a.noisesize, 0, 0.25, 30.0)
+    ltot, lparts = O.generator_step_loss([w.detach() for w in cw], gw_t, a, X, Y, 'WLSWGAN', torch.tensor(w_ls), ww, update_moving=True)
+    ggrads = torch.autograd.grad(ltot, [gw_t[i] for i in trainable], allow_unused=True)
+    opt.gen_opti.zero_grad()
+    cps = opt.critic_opti.flat.params
+    for p in cps: p.requires_grad_(False)
+    try:
+        with ops.deferred_weight_grads():
+            ltot_d, (lw_d, lls_d) = opt.generator_loss(_f32(X), _f32(Y), training=True)
+            ltot_d.backward()
+    finally:
+        for p in cps: p.requires_grad_(True)
+    torch.cuda.synchronize()
+    close(lw_d, lparts['wgan'], 5e-4, 1e-5, 'generator wgan term')
+    close(lls_d, lparts['ls'], 5e-4, 1e-5, 'generator ls term')
+    close(ltot_d, ltot, 5e-4, 1e-5, 'generator loss')
+    num = den = 0.0
+    worst = (0.0, None)
+    gmax = max(float(g_.norm()) for g_ in ggrads if g_ is not None)
+    for p, g_ in zip(opt.gen_opti.flat.params, ggrads):
+        want = g_ if g_ is not None else torch.zeros(tuple(p.shape), dtype=torch.float64)
+        e = float((p.grad.detach().cpu().double() - want).norm()); n = float(want.norm())
+        num += e * e; den += n * n
+        # (a bias in front of a BatchNorm has an exactly-zero gradient: bounded against the largest tensor instead of itself)
+        r = e / max(n, 1e-6 * gmax)
+        if r > worst[0]: worst = (r, tuple(want.shape))
+        assert r <= 5e-3, 'generator gradient {}: relative L2 error {:.3e}'.format(tuple(want.shape), r)
+    assert num <= (2e-3 ** 2) * den, 'generator gradients: relative L2 error {:.3e} over all tensors (worst tensor {} {:.3e})'.format(
+        (num / den) ** 0.5, worst[1], worst[0])
+    print('generator step B=12: all-network gradient rel L2 {:.3e}, worst tensor {} {:.3e}'.format((num / den) ** 0.5, worst[1], worst[0]))
+    for (k, t), w in zip(mod.kerasmodel.weights(), gw_t):
+        if 'moving' in k:
+            close(t, w, 5e-4, 1e-5, k)
+    _reset_weights(mod, crit, opt, gw, cw)
