@@ -8,12 +8,17 @@ Workload at N=1 is BASELINE.json configs[1]: [64,400,601] -> [64,400,86] (f0 1 +
 64-sample shard (weak scaling, global batch 64*N) and the flat gradients are all-reduced over RCCL.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline       dominant kernel of the critic step, HIP-event timed here: since round 3 the 4 -> 4 Conv2D layer kernel (c2m::fwd_kernel, HBM
-                 roofline, per launch; --dtype bf16: the fused conv2d_chain kernels) -- the context Conv1D went to the frequency domain
+  roofline       SURVEY.md 8(d)'s quantity (round 4): the critic's whole 2D-conv stack, (149 C + 3) B T F s algorithmic bytes per critic
+                 step over the summed HIP-event time of every conv2d launch of the step, against the 8 TB/s HBM roofline; the stack's
+                 dominant kernel per launch is the sub-field `dominant_kernel` (the 4 -> 4 Conv2D layer kernel; --dtype bf16: the
+                 stack is its four fused conv2d_chain launches)
+  roofline_conv2d the same figures under their old name
   roofline_conv1d the context Conv1D's big product against the matrix-core peak (frequency domain: batched dense_bf16x6_kernel; time domain:
                  gemm_bf16x6_kernel / gemm_bf16x1_kernel)
-  roofline_conv2d the critic's 2D-conv stack against the HBM roofline, algorithmic bytes of SURVEY.md 8(d)
+  roofline_lstm  the BLSTM recurrence (2 x T step launches per generator step: by time in the loop the top kernel), fp32 MFMA peak
   cpu_baseline   the CPU oracle (PyTorch-CPU fp32 restatement of the reference path) on a bounded sample
+With more than one rank: `allreduce_ms` (both buckets, backend, the exposed -- not overlapped -- update time per critic step).
+--graph-critic / --graph-generator {on,off} pin the form of each step kind instead of the 'tune' timing comparison.
 """
 from __future__ import print_function
 
@@ -45,6 +50,8 @@ def parse():
     ap.add_argument('--no-hoist', action='store_true', help="do not launch the generator's forward before the critic step of a batch that trains both (cfg.train_wgan_hoist_generator)")
     ap.add_argument('--no-graph', action='store_true', help="never replay a step as a hipGraph (the default, cfg.train_wgan_hipgraph = 'tune', times eager launches against a replay per step kind on the first batch and keeps the faster)")
     ap.add_argument('--eager', action='store_true', help='(default) eager launches; kept for compatibility')
+    ap.add_argument('--graph-critic', choices=['on', 'off'], default=None, help="pin the critic step's form: hipGraph replay (on) or eager launches (off), instead of the 'tune' timing comparison on the first batch -- so that a profile and a bench run time ONE program")
+    ap.add_argument('--graph-generator', choices=['on', 'off'], default=None, help="pin the generator step's form likewise (on: its forward is then not hoisted in front of the critic step)")
     ap.add_argument('--no-prune', action='store_true', help="also run G's f0/noise branches in the critic step")
     ap.add_argument('--no-stack', action='store_true', help='evaluate critic(real) and critic(fake) separately instead of as one 2B pass')
     ap.add_argument('--no-ctx-reuse', action='store_true', help="recompute the generator's context Conv1D in the generator step instead of taking the critic step's product of the same batch")
@@ -249,22 +256,54 @@ def roofline_leg(opt, X, Y, args):
     # ---- `roofline`: the dominant kernel of the critic step.  fp32: the 4 -> 4 Conv2D layers on the matrix cores (c2m::fwd_kernel: forward,
     # masked forward, backward-data), per launch (2 or 3 maps of 16 bytes per time-frequency bin) against the HBM roofline; bf16: the
     # fused stack (the roofline_conv2d figures: four launches).  Before round 3's frequency-domain Conv1D the context Conv1D was.
+    # ---- `roofline` (round 4): SURVEY 8(d)'s quantity -- the critic's whole 2D-conv STACK, (149 C + 3) B T F s algorithmic bytes per
+    # critic step over the summed time of all its conv2d launches (forward, backward-data, weight gradients, the 1 -> 4 layer, the
+    # grouped reductions) -- with the stack's dominant kernel, per launch, as the sub-field `dominant_kernel` (fp32: the 4 -> 4 layer
+    # kernel, 2 or 3 maps of 16 bytes per time-frequency bin a launch; bf16: the stack IS its four chain launches).
     c2m = [(tag, d) for (nm, tag, d) in crit_recs[-1] if nm == 'ptts_conv2d_mfma_fwd']
-    if bf16_stack is True and 'roofline_conv2d' in out:
+    if 'roofline_conv2d' in out:
         out['roofline'] = dict(out['roofline_conv2d'])
-        out['roofline']['kernel'] = 'c2c::chain_fwd / chain_bwd / chain_second kernels (critic Conv2D stack, 8 layers per launch, bf16 maps): all launches of a critic step'
-    elif c2m:
-        by = 0.0
-        for tag, d in c2m:
-            Bq, Tq, Fq, _, _, mode, has_om, planes = tag
-            by += Bq * Tq * Fq * 4 * 4.0 * (2 + (1 if (mode == 2 or has_om) else 0))
-        tt = sum(sum(d for (nm, _, d) in r if nm == 'ptts_conv2d_mfma_fwd') for r in crit_recs) / reps * 1e-3
-        out['roofline'] = {'bound': 'hbm', 'kernel': 'c2m::fwd_ws_kernel (4 -> 4 Conv2D 5x5 layer on the matrix cores, wave-specialised: forward, masked forward, backward-data; fp32 maps, fp32 arithmetic as 6 bf16 products), '
-                           '{} launches per critic step'.format(len(c2m)),
-                           'achieved': by / tt / 1e9, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': by / tt / 1e9 / PEAK_HBM_GBPS, 'traffic': None,
-                           'algorithmic_bytes_per_launch': by / len(c2m), 'launch_ms': tt / len(c2m) * 1e3, 'launches_per_critic_step': len(c2m)}
+        out['roofline']['definition'] = 'SURVEY 8(d): algorithmic bytes of the critic 2D-conv stack per critic step / summed HIP-event time of every conv2d launch of the step'
+        if bf16_stack is True:
+            out['roofline']['kernel'] = 'c2c::chain_fwd / chain_bwd / chain_bwd_data / chain_second kernels (critic Conv2D stack, 8 layers per launch, bf16 maps): all launches of a critic step'
+        elif c2m:
+            by = 0.0
+            for tag, d in c2m:
+                Bq, Tq, Fq, _, _, mode, has_om, planes = tag
+                by += Bq * Tq * Fq * 4 * 4.0 * (2 + (1 if (mode == 2 or has_om) else 0))
+            tt = sum(sum(d for (nm, _, d) in r if nm == 'ptts_conv2d_mfma_fwd') for r in crit_recs) / reps * 1e-3
+            out['roofline']['dominant_kernel'] = {
+                'kernel': 'c2m::fwd_ws_kernel (4 -> 4 Conv2D 5x5 layer on the matrix cores, wave-specialised: forward, masked forward, backward-data; fp32 maps, '
+                          'fp32 arithmetic as 6 bf16 products), {} launches per critic step'.format(len(c2m)),
+                'achieved': by / tt / 1e9, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': by / tt / 1e9 / PEAK_HBM_GBPS, 'traffic': None,
+                'algorithmic_bytes_per_launch': by / len(c2m), 'launch_ms': tt / len(c2m) * 1e3, 'launches_per_critic_step': len(c2m)}
     elif 'roofline_conv1d' in out:
         out['roofline'] = dict(out['roofline_conv1d'])
+    # ---- `roofline_lstm`: by time in the LOOP the BLSTM's recurrence is the top kernel (2 x T step launches per generator step on the
+    # side stream): one step = h_{t-1} [B x H] . U [H x 4H] per direction on the fp32 matrix pipe -- latency-bound by construction
+    # (T sequential launches), priced against the fp32 MFMA peak so that the line says how far
+    H = int(opt.cfg.arch_hiddenwidth)
+    try:
+        for _ in range(2):
+            opt.generator_step(X, Y)
+        torch.cuda.synchronize()
+        lrecs = []
+        for _ in range(3):
+            with _hip.KernelTimer() as kt:
+                opt.generator_step(X, Y)
+            lrecs.append([(nm, d) for (nm, _, d) in kt.durations_ms() if nm in ('ptts_lstm_fwd', 'ptts_lstm_bwd')])
+        fw = [d for r in lrecs for (nm, d) in r if nm == 'ptts_lstm_fwd']; bw = [d for r in lrecs for (nm, d) in r if nm == 'ptts_lstm_bwd']
+        if fw and bw:
+            t_f, t_b = sum(fw) / len(fw) * 1e-3, sum(bw) / len(bw) * 1e-3
+            fl_step = 2.0 * B * H * 4 * H * 2            # both directions
+            out['roofline_lstm'] = {'bound': 'mfma', 'kernel': 'lstm_fwd_step_pk_kernel / lstm_bwd_step_pk_kernel: {} + {} launches per generator step (one per time step, both directions each)'.format(T, T),
+                                    'achieved': fl_step * T * 2 / (t_f + t_b) / 1e12, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                    'frac': fl_step * T * 2 / (t_f + t_b) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                                    'flop_per_launch': fl_step, 'fwd_us_per_step': t_f / T * 1e6, 'bwd_us_per_step': t_b / T * 1e6,
+                                    'fwd_chain_ms': t_f * 1e3, 'bwd_chain_ms': t_b * 1e3,
+                                    'note': 'latency-bound: T sequential launches; timed alone on one stream (inside the loop the chain shares the chip with the critic step)'}
+    except Exception as e:      # the leg must not take the headline down
+        out['roofline_lstm'] = {'error': repr(e)}
     # HBM(+Infinity-Cache) bytes per launch from the separate rocprofv3 PMC passes of the same kernels
     # (tools/profile_round.sh -> tools/summarize_profiles.py -> profiles/<round>_traffic.json; FETCH_SIZE x2 + WRITE_SIZE)
     try:
@@ -282,9 +321,16 @@ def roofline_leg(opt, X, Y, args):
             if 'roofline_conv2d' in out and ck and not bf16_stack:
                 out['roofline_conv2d']['traffic_fwd_4to4_per_launch'] = tr[ck]['hbm_bytes_per_launch']
                 out['roofline_conv2d']['traffic_kernel'] = ck
-                if 'roofline' in out and out['roofline'].get('bound') == 'hbm':
-                    out['roofline']['traffic'] = tr[ck]['hbm_bytes_per_launch']       # the forward variant of the kernel, [64,400,65,4] in and out
-                    out['roofline']['traffic_source'] = 'profiles/' + cands[-1] + ' (' + ck + ')'
+                dk = out.get('roofline', {}).get('dominant_kernel')
+                if dk is not None:
+                    # NOT measured by this run: the builder's separate rocprofv3 --pmc passes of the same kernel (a counter pass cannot run
+                    # inside a plain bench); the forward variant of the kernel, [64,400,65,4] in and out
+                    dk['traffic'] = tr[ck]['hbm_bytes_per_launch']
+                    dk['traffic_source'] = 'profiles/' + cands[-1] + ' (' + ck + "): builder's rocprofv3 PMC run, copied -- not a measurement of this run"
+                    stk = tr.get('critic_conv2d_stack_per_critic_step')
+                    if stk:
+                        out['roofline']['traffic'] = stk['hbm_bytes']
+                        out['roofline']['traffic_source'] = 'profiles/' + cands[-1] + " (sum over the stack's kernels x their launches per critic step): builder's rocprofv3 PMC run, copied -- not a measurement of this run"
     except (OSError, ValueError, KeyError):
         pass
     return out
@@ -300,7 +346,13 @@ def build_optimizer(args, ctx, spec, nm, batch, errtype, gated=False, bf16=None,
     cfg.train_wgan_bf16_products = bool(cfg.arch_critic_bf16)      # configs[2]: bf16 products in the GEMM-shaped layers as well
     if gated:       # BASELINE configs[4]: pGCNN2D spectral branch, time dilations 1,2,4,8,1,2,4,8, causal padding
         cfg.arch_gen_gated = True; cfg.arch_gen_dilations = [1, 2, 4, 8]; cfg.arch_gen_causal = True
-    cfg.train_wgan_hipgraph = ((True if args.graph else False if args.no_graph else 'tune') if graph is None else graph) if int(os.environ.get('WORLD_SIZE', '1')) <= 1 else False
+    # (more than one rank: 'tune' as well since round 4 -- the replayed form is then the split graph, forward + backward captured, the
+    # gradient all-reduce and Adam launched eagerly behind it; PTTS_DP_GRAPH=0 forces eager launches on every rank)
+    multi = int(os.environ.get('WORLD_SIZE', '1')) > 1
+    cfg.train_wgan_hipgraph = ((True if args.graph else False if args.no_graph else 'tune') if graph is None else graph) if (not multi or os.environ.get('PTTS_DP_GRAPH', '1') == '1') else False
+    if graph is None:
+        cfg.train_wgan_graph_critic = getattr(args, 'graph_critic', None)
+        cfg.train_wgan_graph_generator = getattr(args, 'graph_generator', None)
     cfg.train_wgan_prune_dead_branches = not args.no_prune
     cfg.train_wgan_graph_streams = os.environ.get('PTTS_GRAPH_STREAMS', '0') == '1'      # (experiment) fork / join inside the capture
     cfg.train_wgan_parallel_streams = (not args.no_streams) and (cfg.train_wgan_hipgraph is not True or cfg.train_wgan_graph_streams)
@@ -390,7 +442,8 @@ def main():
     # and before the warm-up (the training state is put back after the timing runs)
     hipgraph_choice = {'critic': bool(opt._use_graph(batches[0][0], 'critic', batches[0][1])),
                        'generator': bool(opt._use_graph(batches[0][0], 'generator', batches[0][1])),
-                       'mode': cfg.train_wgan_hipgraph,
+                       'mode': cfg.train_wgan_hipgraph, 'pinned': {'critic': cfg.train_wgan_graph_critic, 'generator': cfg.train_wgan_graph_generator},
+                       'form_with_more_than_one_rank': 'split graph (forward + backward captured; all-reduce + Adam eager behind it)' if world > 1 else None,
                        'tuning_ms': {k[0]: {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in opt._graph_tuning.items()}}
     dt, cyc = timed_loop(opt, batches, args.steps, args.warmup, dev)
     # (a batch that trains both networks may run as ONE graph: decided on the first such batch, inside the warm-up)
@@ -404,11 +457,15 @@ def main():
     # the same loop with the context Conv1D on the fp32 MFMA pipe (the variant kept selectable: --fp32-mfma)
     # (the variants change what a step launches: they run eagerly -- a captured graph would replay the headline's kernels)
     graph_mode = opt.cfg.train_wgan_hipgraph
+    pins = (opt.cfg.train_wgan_graph_critic, opt.cfg.train_wgan_graph_generator)
+    def unpinned_eager(on):
+        opt.cfg.train_wgan_hipgraph = False if on else graph_mode
+        opt.cfg.train_wgan_graph_critic, opt.cfg.train_wgan_graph_generator = (None, None) if on else pins
     if not args.fp32_mfma and not args.no_variants:
         opt.cfg.train_wgan_split_bf16 = False
-        opt.cfg.train_wgan_hipgraph = False
+        unpinned_eager(True)
         dtv, _ = timed_loop(opt, batches, short, 6, dev)
-        opt.cfg.train_wgan_hipgraph = graph_mode
+        unpinned_eager(False)
         opt.cfg.train_wgan_split_bf16 = True
         ops.conv1d_split(True)
         ops.dense_split(True)
@@ -421,9 +478,9 @@ def main():
         hoist_saved = opt.cfg.train_wgan_hoist_generator
         opt._gen_spec = None
         opt.cfg.train_wgan_stack_real_fake = opt.cfg.train_wgan_reuse_ctx_conv = opt.cfg.train_wgan_early_critic = opt.cfg.train_wgan_hoist_generator = False
-        opt.cfg.train_wgan_hipgraph = False
+        unpinned_eager(True)
         dtu, _ = timed_loop(opt, batches, short, 6, dev)
-        opt.cfg.train_wgan_hipgraph = graph_mode
+        unpinned_eager(False)
         opt._gen_spec, opt.cfg.train_wgan_stack_real_fake, opt.cfg.train_wgan_reuse_ctx_conv, opt.cfg.train_wgan_early_critic = saved
         opt.cfg.train_wgan_hoist_generator = hoist_saved
         extra['all_exact_work_reductions_off'] = {
@@ -463,6 +520,27 @@ def main():
         gc, gg = torch.zeros_like(opt.critic_opti.flat.grad), torch.zeros_like(opt.gen_opti.flat.grad)
         extra['allreduce_ms'] = {'critic_grads': ar_ms(gc), 'generator_grads': ar_ms(gg), 'critic_bytes': gc.numel() * 4, 'generator_bytes': gg.numel() * 4,
                                  'backend': dist.get_backend(), 'what': 'all-reduce(sum) of one flat fp32 gradient bucket per network, max over ranks'}
+        # what of the exchange + Adam is NOT hidden behind the next step: back-to-back steps with the update (on the communication
+        # stream, overlapped) against the same steps without it (gradients only)
+        def loop_ms(fn, n=10):
+            fn(); opt.wait_updates(); torch.cuda.synchronize(); parallel.barrier()
+            t = time.time()
+            for _ in range(n): fn()
+            opt.wait_updates(); torch.cuda.synchronize()
+            return parallel.max_over_ranks((time.time() - t) / n * 1e3, dev)
+        with_c = loop_ms((lambda: opt._graphed('critic', X, Y)) if graph_c else (lambda: opt.critic_step(X, Y)))
+        saved_update = opt._update
+        opt._update = lambda kind: None
+        try:
+            only_c = loop_ms((lambda: opt._graphed('critic', X, Y)) if graph_c else (lambda: opt._critic_grads(X, Y)))
+        finally:
+            opt._update = saved_update
+        extra['allreduce_ms']['critic_update_exposed_ms_per_step'] = with_c - only_c
+        extra['allreduce_ms']['critic_step_ms_with_update'] = with_c
+        extra['allreduce_ms']['critic_step_ms_gradients_only'] = only_c
+        extra['allreduce_ms']['update_form'] = 'asynchronous (communication stream: event -> all_reduce(async_op) -> work.wait() -> Adam)' if opt._async() else 'synchronous'
+        extra['allreduce_ms']['critic_step_form'] = 'split hipGraph replay + eager update' if graph_c else 'eager launches'
+
     if not args.no_roofline:
         extra.update(roofline_leg(opt, X, Y, args))
         opt.cfg.train_wgan_parallel_streams = par_streams

@@ -631,8 +631,9 @@ static bool lstm_persistent_ok(int B, int T, int H, int ndir) {
 struct LstmGraphKey {
     int kind, B, T, H, ndir, reverse;
     const void* p[6];
+    int device = -1;        // filled in by lstm_graph_run: an executable graph belongs to the device it was instantiated on
     bool operator==(const LstmGraphKey& o) const {
-        if (kind != o.kind || B != o.B || T != o.T || H != o.H || ndir != o.ndir || reverse != o.reverse) return false;
+        if (kind != o.kind || B != o.B || T != o.T || H != o.H || ndir != o.ndir || reverse != o.reverse || device != o.device) return false;
         for (int i = 0; i < 6; ++i) if (p[i] != o.p[i]) return false;
         return true;
     }
@@ -652,7 +653,9 @@ static bool lstm_graph_on() {
 extern "C" int ptts_set_lstm_graph(int on) { g_lstm_graph = on ? 1 : 0; return PTTS_OK; }
 
 template <class F>
-static int lstm_graph_run(const LstmGraphKey& key, hipStream_t st, const char* what, F&& launch_all) {
+static int lstm_graph_run(const LstmGraphKey& key_in, hipStream_t st, const char* what, F&& launch_all) {
+    LstmGraphKey key = key_in;
+    if (hipGetDevice(&key.device) != hipSuccess) { (void)hipGetLastError(); key.device = -1; }
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (!lstm_graph_on() || key.T < 8 || hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
         launch_all();
@@ -677,10 +680,19 @@ static int lstm_graph_run(const LstmGraphKey& key, hipStream_t st, const char* w
     hipGraphExec_t exec = nullptr;
     if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); launch_all(); return check_launch(what); }
     launch_all();
-    if (hipStreamEndCapture(st, &graph) != hipSuccess || !graph) { set_error("%s: stream capture failed", what); return PTTS_ELAUNCH; }
+    // The launches above went into the capture, not to the device: if the capture cannot be ended or instantiated the recurrence has
+    // NOT run yet -- clear the error, launch it directly, and stay on direct launches from now on (retried only now and then).
+    auto direct_after_failure = [&]() {
+        (void)hipGetLastError();
+        g_lg_consecutive_misses = 1 << 20;
+        ++g_lg_direct;
+        launch_all();
+        return check_launch(what);
+    };
+    if (hipStreamEndCapture(st, &graph) != hipSuccess || !graph) return direct_after_failure();
     const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
-    if (ie != hipSuccess || !exec) { set_error("%s: hipGraphInstantiate failed", what); return PTTS_ELAUNCH; }
+    if (ie != hipSuccess || !exec) return direct_after_failure();
     if (g_lg.size() >= LSTM_GRAPH_CACHE) {
         size_t lru = 0;
         for (size_t i = 1; i < g_lg.size(); ++i) if (g_lg[i].stamp < g_lg[lru].stamp) lru = i;

@@ -174,6 +174,56 @@ def addstop(X, value=1.0):
     return X
 
 
+def _kept_len(wk, thresh, cropmode, cropsize):
+    """Number of frames croplen_weight keeps of a weight track (same selection rules, no data moved)."""
+    keep = wk > thresh
+    if cropmode == 'begend':
+        on = np.where(keep)[0]
+        return int(on.max()) - int(on.min())
+    if cropmode == 'begendbigger':
+        on = np.where(keep)[0]
+        gaps = np.diff(on)
+        for gi in np.where(gaps > 1)[0]:
+            if gaps[gi] < int(cropsize):
+                keep[on[gi]:on[gi + 1]] = True
+        return int(keep.sum())
+    if cropmode == 'all':
+        return int(keep.sum())
+    raise ValueError('unknown cropmode ' + str(cropmode))
+
+
+def batch_window_length(indir, outdir, outwdir, fid_lst, length=None, lengthmax=None, maskpadtype='padright', cropmode='begend',
+                        thresh=0.5, cropsize=int(0.750 / 0.005)):
+    """The window length T load_inoutset would choose for the batch `fid_lst` (reference data.py:297-322 -> croplen,
+    croplen_weight, batching: with length=None it is the min ('randshift') or max ('padright') of the cropped sample lengths,
+    clipped by lengthmax), found WITHOUT reading the wide files: the frame counts of the inputs and outputs come from the file
+    sizes, only the one-column time-weight files are read.  Data parallelism needs it before sharding: a rank that loads only its
+    shard must window it to the GLOBAL batch's T -- the shard's own min / max can differ, and with it every random shift."""
+    if length is not None:
+        return int(min(length, lengthmax)) if lengthmax is not None else int(length)
+    lens = []
+    ipath, ishape = getpathandshape(indir)
+    opath, oshape = getpathandshape(outdir)
+    wpath, wshape = getpathandshape(outwdir)
+    def frames(path, shape, fid):
+        f = path.replace('*', fid)
+        if not os.path.isfile(f):
+            raise ValueError('{} does not exists'.format(f))
+        dim = 1
+        if shape is not None:
+            for d in shape[1:]: dim *= int(d)
+        return os.path.getsize(f) // (4 * dim)
+    for fid in fid_lst:
+        w = _read(wpath.replace('*', fid), wshape)
+        n = min(frames(ipath, ishape, fid), frames(opath, oshape, fid), w.shape[0])
+        wk = (w[:, 0] if w.ndim > 1 else w)[:n]
+        lens.append(_kept_len(wk, thresh, cropmode, cropsize))
+    T = max(lens) if maskpadtype == 'padright' else min(lens)
+    if lengthmax is not None and T > lengthmax:
+        T = lengthmax
+    return int(T)
+
+
 def load_inoutset(indir, outdir, outwdir, fid_lst, inouttimesync=True, length=None, lengthmax=None,
                   maskpadtype='padright', cropmode='begend', verbose=0, rand=None):
     """Load one batch of inputs, outputs and time weights, cropped and windowed: X [B,T,ctx], Y [B,T,out], W [B,T,1]

@@ -900,7 +900,10 @@ class Conv2dChainFn(torch.autograd.Function):
                      ptr(parts), parts.numel(), ctypes.byref(nblocks), ctypes.byref(npart), B, T, F, L, int(ws[0].shape[2]), alpha, stream(),
                      tag=(B, T, F, L))
                 want_b = any(ctx.has_b)
-                dws, dbs = _chain_reduce(parts, nblocks.value, npart.value, ws, ctx.gws, ctx.gbs, want_b)
+                # the targets were noted at FORWARD time; queue only if a deferred_weight_grads() context is open NOW (a backward run
+                # after the forward's context closed would append to a list nobody flushes, and the gradients would be lost)
+                live = _Deferred.active and not _Flags.deterministic
+                dws, dbs = _chain_reduce(parts, nblocks.value, npart.value, ws, ctx.gws if live else None, ctx.gbs if live else None, want_b)
                 if dws is not None:
                     for l in range(L):
                         grads[2 * l] = dws[l]
@@ -1289,7 +1292,11 @@ class _C1FFT(object):
     def eligible(a, w):
         B, T, Cin = a.shape
         KW, _, N = w.shape
-        return a.is_cuda and B * T >= 4096 and KW >= 3 and KW % 2 == 1 and T % 4 == 0 and N % 4 == 0 and Cin >= 64
+        if not (a.is_cuda and B * T >= 4096 and KW >= 3 and KW % 2 == 1 and T % 4 == 0 and N % 4 == 0 and Cin >= 64):
+            return False
+        # launch limits of the stages: ptts_split3_frame_windows and ptts_dense_bf16x6_batched put the B * NS segments on
+        # gridDim.y / z (<= 65535); larger batches take the time-domain kernels instead of failing in the middle of the forward
+        return B * (T // _C1FFT.segment(T, KW)) <= 65535
 
     @classmethod
     def segment(cls, T, KW):
@@ -1305,9 +1312,13 @@ class _C1FFT(object):
 
     @classmethod
     def _buf(cls, name, key, nfloats, dev):
-        k = (name, key, _hip.stream_id())
+        sid = _hip.stream_id()
+        k = (name, key, sid)
         t = cls.bufs.get(k)
         if t is None:
+            # one buffer per (name, stream): an entry of another shape (hundreds of MB) is dropped when the shape changes
+            for k2 in [k2 for k2 in cls.bufs if k2[0] == name and k2[2] == sid]:
+                del cls.bufs[k2]
             t = cls.bufs[k] = torch.zeros(nfloats, dtype=torch.float32, device=dev)
         return t
 

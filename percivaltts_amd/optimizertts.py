@@ -182,12 +182,19 @@ class OptimizerTTS:
             def make_batch(batchid, rndidxb=rndidxb, shift_rand=shift_rand):
                 ids = rndidxb[batchid]
                 rnd = None
+                length = self.cfg.train_batch_length
                 if world > 1:
+                    # the window length is a property of the GLOBAL batch (min / max of its cropped sample lengths when
+                    # train_batch_length is None, the default): fixed before sharding from the file sizes and the one-column
+                    # weight files, so that every rank windows its shard to the same T and draws the shifts one process would
+                    length = data.batch_window_length(indir, outdir, wdir, [fid_lst_tra[bidx] for bidx in ids], length=length,
+                                                      lengthmax=self.cfg.train_batch_lengthmax, maskpadtype=self.cfg.train_batch_padtype,
+                                                      cropmode=self.cfg.train_batch_cropmode)
                     lo, hi = parallel.shard_batch(len(ids), world, rank)
                     ids, rnd = ids[lo:hi], shift_rand[batchid][lo:hi]
                 fid_lst_trab = [fid_lst_tra[bidx] for bidx in ids]
                 X_trab, Y_trab, W_trab = data.load_inoutset(
-                    indir, outdir, wdir, fid_lst_trab, length=self.cfg.train_batch_length,
+                    indir, outdir, wdir, fid_lst_trab, length=length,
                     lengthmax=self.cfg.train_batch_lengthmax, maskpadtype=self.cfg.train_batch_padtype,
                     cropmode=self.cfg.train_batch_cropmode, rand=rnd)
                 return X_trab, Y_trab                        # already this rank's shard: only it was read and crosses PCIe

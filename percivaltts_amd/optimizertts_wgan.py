@@ -140,6 +140,8 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         cfg.train_wgan_hoist_side_backward = True    # ... and the BLSTM branch's BACKWARD too (its output is read by the least-squares term only: the branch is cut out of the tape, run on its own, its gradient injected at the cut).  Measured + 1 % (three A/B pairs, fp32 and bf16): both chains then run under the critic step
         cfg.train_wgan_batch_graph = False           # 'tune': a batch that trains both networks may be replayed as ONE hipGraph (BLSTM fork kept), if that times faster.  It does not: 29.6 ms against 14.0 for the separate steps (cross-stream edges of a graph replay at half speed on this runtime) -- off, so that the timing runs are not made either
         cfg.train_wgan_hoist_generator = True        # a batch that trains both: G's forward (it does not depend on the critic) is launched BEFORE the critic step -- its BLSTM chain runs under that step -- and the critic step takes its fake sample from it
+        cfg.train_wgan_graph_critic = None           # 'on' / 'off': pin the critic step's form (hipGraph replay / eager launches) whatever train_wgan_hipgraph would choose
+        cfg.train_wgan_graph_generator = None        # ... and the generator step's
         cfg.train_wgan_graph_split = False           # hipGraph of forward + backward only, update launched eagerly (what data parallelism uses; settable for tests)
         cfg.train_wgan_async_update = None           # all-reduce + Adam on a communication stream, overlapped with the next forward that does not need the weights (None: on when world > 1)
         cfg.train_sync_batchnorm = False             # data parallelism: BatchNorm statistics over all ranks (SyncBN) instead of per rank
@@ -398,7 +400,13 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         opti = self.critic_opti if kind == 'critic' else self.gen_opti
 
         def run():
-            opti.step(parallel.allreduce_sum_(opti.flat.grad))
+            # explicit ordering, the same for RCCL and gloo: the collective is started (RCCL: on its own stream, behind everything
+            # already queued on the current one), work.wait() makes the current stream (gloo: the host) wait for the sums, and only
+            # then is Adam queued -- nothing here depends on which stream a blocking all_reduce would have synchronised with
+            work, gscale = parallel.allreduce_sum_async(opti.flat.grad)
+            if work is not None:
+                work.wait()
+            opti.step(gscale)
             if kind == 'critic' and self.cfg.train_wgan_weight_clip:
                 c = float(self.cfg.train_wgan_weight_clip)
                 opti.clip_weights(-c, c)
@@ -409,8 +417,9 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         if self._comm is None:
             from . import layers
             self._comm = layers.side_streams(1, 'comm')[0]
-        cur = torch.cuda.current_stream()
-        self._comm.wait_stream(cur)
+        # the backward pass's last kernel -> event -> communication stream; the compute stream goes on at once
+        done = torch.cuda.current_stream().record_event()
+        self._comm.wait_event(done)
         with torch.cuda.stream(self._comm):
             run()
             self._pending[kind] = self._comm.record_event()
@@ -508,6 +517,8 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         for _ in range(2):                  # alternating: clocks and caches drift over the first seconds of a process
             t_eager.append(timed(eager)); t_graph.append(timed(graph))
         t_eager, t_graph = min(t_eager), min(t_graph)
+        if self.world > 1:
+            t_eager, t_graph = parallel.max_over_ranks(t_eager, self.device), parallel.max_over_ranks(t_graph, self.device)
         self._state_restore(snap)
         # a replay costs the host one launch: inside the training loop that time goes to the launches of whatever else is in flight (the
         # generator's forward hoisted in front of the critic step), so a step that replays within 8 % of its eager time is replayed --
@@ -594,11 +605,16 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         'auto' below the frame threshold, above it measured per step kind on the first batch (`_tune_graph`): a step whose kernels
         are short against the host's enqueue time (the bf16 critic step) replays faster than it launches, one that lives on
         overlapping streams (the generator step's BLSTM branch) does not."""
+        pin = getattr(self.cfg, 'train_wgan_graph_' + kind, None) if kind in ('critic', 'generator') else None
+        if pin is not None:             # 'on' / 'off' (bench.py --graph-critic / --graph-generator): the timed program is pinned,
+            return pin in (True, 'on')  # not left to the wall-clock comparison of 'tune' (two runs of one tree time ONE program)
         g = self.cfg.train_wgan_hipgraph
         if g in ('auto', 'tune'):
             if X.shape[0] * X.shape[1] <= int(getattr(self.cfg, 'train_wgan_hipgraph_maxframes', 8192)):
                 return True
-            if g == 'tune' and kind is not None and self.world == 1:
+            if g == 'tune' and kind is not None:
+                # (more than one rank: the graph holds forward + backward only, the collective and Adam follow eagerly --
+                # _graphed's split form; the timings are maxed over the ranks so that every rank makes the same choice)
                 return self._tune_graph(kind, X, Y)
             return False
         return bool(g)
@@ -608,6 +624,10 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         as device scalars."""
         critic_runs = 10 if (self.generator_updates < 25) or (self.generator_updates % 500 == 0) else 5   # (:225-228)
         gen_too = batchid % critic_runs == 0
+        # a kernel of an earlier step that gave up on a hand-off has left its code in the device status word: an error at the step
+        # boundary (a host memory load, no synchronisation; graph replays bypass the per-call checks of the C ABI), not a bad step
+        from . import _hip
+        _hip.check_status()
         # the generator step that follows on the same batch reuses the generator's context-Conv1D product of the critic
         # step's fake sample (same input, same not-yet-updated kernel): ops._C1Cache, valid inside this call only
         ops.bf16_products(bool(getattr(self.cfg, 'train_wgan_bf16_products', False)))

@@ -47,6 +47,17 @@ def allreduce_sum_(flat):
     return 1.0 / w
 
 
+def allreduce_sum_async(flat):
+    """Start the in-place sum of a flat buffer over all ranks on the CURRENT stream's behalf and return (work, factor): the
+    caller orders it explicitly -- `work.wait()` makes the current stream (RCCL) or the host (gloo) wait for the result, whatever
+    stream the backend ran the collective on -- instead of relying on what a blocking call does with the current stream.
+    work is None in a single process."""
+    w = world_size()
+    if w <= 1:
+        return None, 1.0
+    return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), 1.0 / w
+
+
 def broadcast_(flat, src=0):
     if world_size() > 1:
         dist.broadcast(flat, src=src)

@@ -36,6 +36,36 @@ def test_library_exports_every_declared_symbol():
     assert lib.ptts_device_arch() == b'gfx950'
 
 
+def test_device_status_word_is_sticky_and_decoded():
+    """The host side of the device status word (include/percival_hip.h: ptts_device_status*): a code a kernel would store -- written
+    here through the word's host address, no GPU involved -- makes ptts_device_status return PTTS_EDEVICE with a message naming the
+    kernel family, stays until ptts_device_status_clear(), and _hip.check_status() raises."""
+    from percivaltts_amd import _hip
+    if not os.path.exists(_hip.LIB_PATH):
+        pytest.skip('libpercival_hip.so not built (run __graft_entry__.build())')
+    lib = _hip.lib()
+    word = ctypes.cast(lib.ptts_device_status_word(), ctypes.POINTER(ctypes.c_uint))
+    _hip.clear_status()
+    out = ctypes.c_uint(99)
+    assert lib.ptts_device_status(ctypes.byref(out)) == 0 and out.value == 0
+    _hip.check_status()
+    for slot, code, text in ((0, 1, 'conv2d'), (1, 2, 'LSTM')):
+        word[slot] = code
+        assert lib.ptts_device_status(ctypes.byref(out)) == -4 and out.value == code        # PTTS_EDEVICE
+        assert text in _hip.last_error()
+        assert lib.ptts_device_status(None) == -4                                           # sticky
+        with pytest.raises(_hip.HipLibraryError, match='hand-off|hidden state'):
+            _hip.check_status()
+        _hip.clear_status()
+        assert lib.ptts_device_status(ctypes.byref(out)) == 0 and out.value == 0
+    word[0] = 1; word[1] = 2
+    assert lib.ptts_device_status(ctypes.byref(out)) == -4 and out.value == 3
+    buf = ctypes.create_string_buffer(400)
+    assert lib.ptts_device_status_message(3, buf, 400) == 0 and b'conv2d' in buf.value and b'LSTM' in buf.value
+    assert lib.ptts_device_status_message(0, buf, 400) == 0 and buf.value == b'ok'
+    _hip.clear_status()
+
+
 def test_missing_library_or_cpu_tensor_fails_loudly(monkeypatch):
     import torch
     from percivaltts_amd import _hip, ops

@@ -223,6 +223,27 @@ def test_loader_windows_are_the_files_frames_and_rank_shards_agree(tmp_path):
             Xr, Yr, Wr = data.load_inoutset(indir, outdir, wdir, fids[lo:hi], length=None, lengthmax=L, maskpadtype='randshift',
                                             cropmode='begend', rand=u[lo:hi])
             assert np.array_equal(Xr, Xa[lo:hi]) and np.array_equal(Yr, Ya[lo:hi]) and np.array_equal(Wr, Wa[lo:hi]), (world, rank)
+    # ---- a sample SHORTER than lengthmax in another rank's shard (train_batch_length None, the default): the window length is the
+    # global batch's, found before sharding (data.batch_window_length: file sizes + the one-column weight files only)
+    Lbig = 60                                                # kept lengths are 53, 65, 46, 76, 50, 53: min 46 < 60
+    kept_all = [expected_rows(fid, k, 0)[1] for k, fid in enumerate(fids)]
+    for padtype, want_T in (('randshift', min(kept_all)), ('padright', Lbig)):
+        Tg = data.batch_window_length(indir, outdir, wdir, fids, length=None, lengthmax=Lbig, maskpadtype=padtype, cropmode='begend')
+        assert Tg == want_T
+        Xg, Yg, Wg = data.load_inoutset(indir, outdir, wdir, fids, length=None, lengthmax=Lbig, maskpadtype=padtype, cropmode='begend', rand=u)
+        assert Xg.shape[1] == Tg
+        for world in (2, 3):
+            for rank in range(world):
+                lo, hi = parallel.shard_batch(6, world, rank)
+                Xr, Yr, Wr = data.load_inoutset(indir, outdir, wdir, fids[lo:hi], length=Tg, lengthmax=Lbig, maskpadtype=padtype,
+                                                cropmode='begend', rand=u[lo:hi])
+                assert np.array_equal(Xr, Xg[lo:hi]) and np.array_equal(Yr, Yg[lo:hi]) and np.array_equal(Wr, Wg[lo:hi]), (padtype, world, rank)
+        # (without the global length the shard of samples 3..5 would have windowed to its own minimum, 50, not 46)
+    assert min(kept_all[3:]) != min(kept_all)
+    assert data.batch_window_length(indir, outdir, wdir, fids, length=30, lengthmax=Lbig) == 30
+    for cm in ('all', 'begendbigger'):
+        Tc = data.batch_window_length(indir, outdir, wdir, fids, length=None, lengthmax=None, maskpadtype='randshift', cropmode=cm)
+        assert Tc == data.load_inoutset(indir, outdir, wdir, fids, length=None, lengthmax=None, maskpadtype='randshift', cropmode=cm, rand=u)[0].shape[1]
     # ---- cropmode 'all' drops the pause inside as well
     Xc, Yc, Wc = data.load_inoutset(indir, outdir, wdir, fids[:1], length=None, lengthmax=L, maskpadtype='randshift', cropmode='all', rand=np.zeros(1))
     w0 = files[('w', 'u0')][:lens[0], 0]

@@ -243,6 +243,37 @@ def test_conv2d_mfma_wave_specialised_form_is_bit_identical(ops, case):
         assert torch.equal(a, c), nm
 
 
+def test_conv2d_mfma_hand_off_timeout_is_reported_not_silent(ops):
+    """The wave-specialised forward hands its plane buffers over by LDS counters with BOUNDED polls (csrc/conv2d_mfma.hip).  A poll
+    that runs out must not pass silently: the wave stores its code into the sticky device status word, the C ABI returns PTTS_EDEVICE
+    from the next call on, and the word stays clear in normal operation.  The time-out is forced once through the debug hook
+    (bit 7 of ptts_conv2d_mfma_debug: the multiplying waves wait, briefly, for a count that never comes)."""
+    _hip = ops._hip
+    g = gen(78)
+    x = torch.randn(4, 100, 65, 4, generator=g).cuda()
+    w = (torch.randn(5, 5, 4, 4, generator=g) * 0.3).cuda()
+    lib = _hip.lib()
+    _hip.clear_status()
+    y0 = ops._conv2d_fwd_raw(x, w, None, None, None, None, ops.IN_LRELU, 0.3, 1, ops.PAD_SAME)
+    torch.cuda.synchronize()
+    _hip.check_status()                                   # a normal launch leaves the word clear
+    lib.ptts_conv2d_mfma_debug(128, None)
+    try:
+        ops._conv2d_fwd_raw(x, w, None, None, None, None, ops.IN_LRELU, 0.3, 1, ops.PAD_SAME)     # this launch times out on the device
+        torch.cuda.synchronize()
+    finally:
+        lib.ptts_conv2d_mfma_debug(0, None)
+    with pytest.raises(_hip.HipLibraryError, match='hand-off'):
+        _hip.check_status()
+    with pytest.raises(_hip.HipLibraryError, match='hand-off'):      # sticky: the next launch of the family is refused
+        ops._conv2d_fwd_raw(x, w, None, None, None, None, ops.IN_LRELU, 0.3, 1, ops.PAD_SAME)
+    _hip.clear_status()
+    y1 = ops._conv2d_fwd_raw(x, w, None, None, None, None, ops.IN_LRELU, 0.3, 1, ops.PAD_SAME)
+    torch.cuda.synchronize()
+    _hip.check_status()
+    assert torch.equal(y0, y1)
+
+
 @pytest.mark.parametrize('in16,out16', [(False, True), (True, True), (True, False)])
 def test_conv2d_bf16_storage_layer(ops, in16, out16):
     """One 4 -> 4 channel 5x5 layer of the bf16-storage path (ops.conv2d(..., bf16=...), csrc/conv2d_mfma.hip with one
