@@ -166,6 +166,21 @@ int ptts_conv2d_mfma_wgrad_partials(const void* dy, const void* x, const void* m
                                     size_t workspace_bytes, int* nblocks_out, int* npart_out, int B, int T, int F,
                                     int KT, int dil_t, int pad_t, int in_mode, float alpha,
                                     int planes, int x_bf16, int dy_bf16, void* stream);
+/* Fused backward launches (round 4; dilation 1, 'same' padding, fp32 maps): the two passes of a layer that read the same staged tile
+ * as ONE launch -- what TF runs as Conv2DBackpropInput + Conv2DBackpropFilter (+ BiasAddGrad) of one kl.Conv2D (networks_critic.py:67),
+ * and, for the gradient penalty (optimizertts_wgan.py:53-68), the forward + Conv2DBackpropFilter pair of the backward of
+ * Conv2DBackpropInput:
+ *   kind 1  p = dy, q = x (the layer's pre-activation input), table = table_bwd:  y = dx = conv^T(dy) . lrelu'(x), and the partial
+ *           rows of dw = corr(lrelu(x), dy), dbias = sum dy
+ *   kind 2  p = u with mask_src = x, q = dy, table = table_fwd:  y = conv(u . lrelu'(x)), and the partial rows of
+ *           dw = corr(u . lrelu'(x), dy) (bias sums zero)
+ * pad_t is the forward layer's (2).  y is bit-identical to ptts_conv2d_mfma_fwd's; the partial rows (one per workgroup, behind a
+ * 4096-byte head, *npart_out floats each) go to ptts_conv2d_reduce_grouped like ptts_conv2d_mfma_wgrad_partials'. */
+size_t ptts_conv2d_mfma_bwd_fused_workspace_bytes(int B, int T);
+int ptts_conv2d_mfma_bwd_fused_supported(int F, int dil_t, int planes);
+int ptts_conv2d_mfma_bwd_fused(const void* p, const void* q, const void* mask_src, const void* table, void* y,
+                               void* workspace, size_t workspace_bytes, int* nblocks_out, int* npart_out,
+                               int B, int T, int F, int KT, int pad_t, int kind, float alpha, void* stream);
 int ptts_conv2d_mfma_debug(int flags, void* stamp_buf);
 
 /* ---------------------------------------------------------------------------------------

@@ -74,6 +74,9 @@ SIGNATURES = {
     'ptts_conv2d_mfma_fwd': (c_i, [c_p] * 8 + [c_i] * 7 + [c_f] + [c_i] * 3 + [c_p]),
     'ptts_conv2d_mfma_wgrad_workspace_bytes': (c_sz, [c_i, c_i]),
     'ptts_conv2d_mfma_wgrad_partials': (c_i, [c_p] * 4 + [c_sz, c_p, c_p] + [c_i] * 7 + [c_f] + [c_i] * 3 + [c_p]),
+    'ptts_conv2d_mfma_bwd_fused_workspace_bytes': (c_sz, [c_i, c_i]),
+    'ptts_conv2d_mfma_bwd_fused_supported': (c_i, [c_i, c_i, c_i]),
+    'ptts_conv2d_mfma_bwd_fused': (c_i, [c_p] * 6 + [c_sz, c_p, c_p] + [c_i] * 6 + [c_f, c_p]),
     'ptts_conv2d_chain_supported': (c_i, [c_i] * 6),
     'ptts_conv2d_chain_debug': (c_i, [c_p]),
     'ptts_conv2d_chain_tables_bytes': (c_sz, []),

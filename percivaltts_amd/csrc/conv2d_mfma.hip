@@ -853,6 +853,205 @@ __global__ __launch_bounds__(THREADS, DIL <= 2 ? 2 : 1) void wgrad_kernel(
     stamp(dbg_buf, dbg, 4);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// FUSED backward launches (round 4, dilation 1, fp32 = three planes): the two passes of a layer that read the same staged tile run
+// as ONE wave-specialised launch -- one prologue, one staging (activation, three-way split, ds_write) of the shared operand, one read
+// of it from HBM -- instead of a backward-data / forward launch plus a weight-gradient launch:
+//   KIND 1, first-order backward of a layer (TF's Conv2DBackpropInput + Conv2DBackpropFilter + bias gradient):
+//       P = dy (20 rows with the time halo)      dx = conv(P, flipped / transposed table) . lrelu'(x)      [fwd_ws_kernel<NONE, OUTMASK>]
+//       Q = a = lrelu(x) (16 rows)               dW = corr(Q, P), dbias = sum P                            [wgrad_kernel<LRELU>]
+//   KIND 2, second-order sweep of the gradient penalty (backward of the backward-data pass):
+//       P = a = u . lrelu'(x) (20 rows)          cot_dy = conv(P, forward table)                           [fwd_ws_kernel<MASKMUL>]
+//       Q = dy (20 rows)                         dW = corr(P rows 2..17, Q)                                [wgrad_kernel<MASKMUL>]
+// Same tiles, passes and MFMA order as the separate kernels, so dx / cot_dy are bit-identical to theirs; the dW partial rows are one
+// per workgroup (256 instead of 512: sums grouped differently, same tolerance), reduced by ptts_conv2d_reduce_grouped as before.
+// Structure = fwd_ws_kernel: waves NMW.. stage piece i + 1 (both tiles) while waves 0..NMW-1 multiply piece i (the convolution over P,
+// then the wave's share of the weight-gradient pairs), buffers handed over by the LDS counters (bounded polls -> status word).
+// Rows are 76 staged bins wide (18 bin groups: the weight gradient's K step takes two adjacent groups).  The second group of a
+// piece's last pair may lie beyond the piece (odd number of groups): its half of the A fragment is zeroed by a wave-uniform select
+// (P carries the convolution's frequency halo there, which the weight gradient must not count).
+// ------------------------------------------------------------------------------------------------------------
+template <int KIND, int NPL>
+__global__ __launch_bounds__(8 * 64, 1) void bwd_ws_kernel(
+    const void* __restrict__ psrc, const void* __restrict__ qsrc, const void* __restrict__ mask_src, const u16* __restrict__ tab,
+    void* __restrict__ y, float* __restrict__ partials, Shape s, Sched sc, float alpha, int dbg, unsigned* status) {
+    constexpr int DIL = 1, NMW = 4;
+    typedef Stage<4 * (GPB + 1) + 4, 16 + (KT - 1) * DIL> SP;                              // the convolved tile, with its time halo
+    typedef Stage<4 * (GPB + 1) + 4, KIND == 1 ? 16 : 16 + (KT - 1) * DIL> SQ;             // the other operand of the weight gradient
+    static_assert(SP::RS == SQ::RS, "one row stride");
+    constexpr int MODE_P = KIND == 1 ? PTTS_IN_NONE : PTTS_IN_MASKMUL;
+    constexpr int MODE_Q = KIND == 1 ? PTTS_IN_LRELU : PTTS_IN_NONE;
+    constexpr bool OUTMASK = KIND == 1, PMASK = KIND == 2;
+    constexpr int BUF = NPL * (SP::PS + SQ::PS);                                           // elements of one buffer (P planes | Q planes)
+    extern __shared__ __attribute__((aligned(16))) u16 lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool stager = wave8 >= NMW;
+    const int wave = wave8 & (NMW - 1);
+    const int lo = (KT - 1) * DIL - s.pad_t;          // staged P row r <-> t = t0 - lo + r (pad_t = 2: symmetric halo of two rows)
+    const int wg = blockIdx.x, nitems = sched_items(sc, wg);
+
+    int* const flags = reinterpret_cast<int*>(lds + 2 * BUF);       // ready[2] | done[2]
+    if (tid == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0; }
+    const bool force_timeout = (dbg & DBG_FORCE_TIMEOUT) != 0;
+    auto wait_for = [&](int idx, int target) {
+        const int bound = force_timeout ? 8 : (1 << 14);
+        if (force_timeout && !stager) target += 1 << 20;
+        int r = 0;
+        for (; r < bound; ++r) {
+            if (__hip_atomic_load(flags + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (r == bound && lane == 0) raise_status(status, STATUS_SLOT_C2M, STATUS_C2M_HANDOFF);
+    };
+    auto signal = [&](int idx) {
+        if (lane == 0) __hip_atomic_fetch_add(flags + idx, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);          // the end-of-launch reduction scratch lies over the (then dead) planes
+    float* bs = red + 4 * KT * 2 * 4 * 64;
+
+    // The two roles are two separate programs (no variable of one is live in the other: the register allocation is the maximum of the
+    // two, not their sum); both end with the same pair of workgroup barriers.  ready[b] counts the staging waves' commits into buffer
+    // b (piece p lives in buffer p & 1, use u = p >> 1: a multiplying wave starts it at ready == 4 (u + 1)), done[b] the multiplying
+    // waves that have finished with it (a staging wave overwrites it at done == NMW u).
+    if (stager) {
+        Slots<SP> slp; slp.init(tid - NMW * 64);
+        Slots<SQ> slq; slq.init(tid - NMW * 64);
+        Pref<SP::NB, PMASK> pp;
+        Pref<SQ::NB, false> pq;
+        f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+        // the two tiles of a piece: P from t0 - lo (20 rows); Q from t0 (KIND 1: the layer input, 16 rows, zero beyond the piece's own
+        // bins) or from t0 - lo (KIND 2: the incoming gradient with its halo)
+        auto load_piece = [&](const TilePos& p) {
+            pref_load<SP, PMASK>(pp, slp, psrc, mask_src, false, p.img, p.t0 - lo, 4 * p.g_base - 2, s.T, s.F, s.F, 4 * p.ng + 4);
+            if (KIND == 1) pref_load<SQ, false>(pq, slq, qsrc, nullptr, false, p.img, p.t0, 4 * p.g_base - 2, s.T, s.F, min(s.F, 4 * (p.g_base + p.ng)), 4 * p.ng + 4);
+            else pref_load<SQ, false>(pq, slq, qsrc, nullptr, false, p.img, p.t0 - lo, 4 * p.g_base - 2, s.T, s.F, s.F, 4 * p.ng + 4);
+        };
+        auto commit_piece = [&](const TilePos& p, u16* buf) {
+            // the bias gradient rides on the staging of dy (KIND 1 only: the second-order sweep has none): its own 16 rows and bins
+            pref_commit<SP, MODE_P, NPL>(pp, slp, buf, p.t0 - lo, 4 * p.g_base - 2, s.T, s.F, nullptr, nullptr, alpha, lo, 2 + 4 * p.ng, KIND == 1 ? &bsum : nullptr);
+            pref_commit<SQ, MODE_Q, NPL>(pq, slq, buf + NPL * SP::PS, KIND == 1 ? p.t0 : p.t0 - lo, 4 * p.g_base - 2, s.T, s.F, nullptr, nullptr, alpha, 0, 0, nullptr);
+        };
+        int item = -1, it = 0;
+        Work w = next_work(s, sc, wg, item, nitems);
+        if (w.ng > 0) load_piece(work_pos(s, w));
+        while (w.ng > 0) {
+            const TilePos p = work_pos(s, w);
+            wait_for(2 + (it & 1), NMW * (it >> 1));
+            commit_piece(p, lds + (it & 1) * BUF);
+            signal(it & 1);
+            w = next_work(s, sc, wg, item, nitems);
+            if (w.ng > 0) load_piece(work_pos(s, w));
+            ++it;
+        }
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(bs + (tid - NMW * 64) * 4) = bsum;
+    } else {
+        const int li = lane & 15, lg = lane >> 4;
+        bf16x8 wf[KT][NPL];
+        {
+            const u16* wa = tab + (li & 3) * TROW + (2 * lg - (li >> 2) + 3) * C;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const u16* wp = wa + (kt * NPL + q) * TKP;
+                    wf[kt][q] = cat(*reinterpret_cast<const bf16x4*>(wp), *reinterpret_cast<const bf16x4*>(wp + 4));
+                }
+        }
+        f32x4 acc[KT][2];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) { acc[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        // transposed-read addresses of this lane inside a 4 rows x 16 columns block (wgrad_kernel): row li >> 2, bin li & 3
+        const int trow = 4 * lg + (li >> 2);
+        const int aoff = (KIND == 1 ? NPL * SP::PS : lo * SP::RS) + trow * SP::RS;          // a: Q (16 rows) / P's own rows
+        constexpr int APS = KIND == 1 ? SQ::PS : SP::PS;                                     // ... and its plane stride
+        const int doff = (KIND == 1 ? 0 : NPL * SP::PS) + trow * SP::RS;                     // dy with its halo: P / Q
+        const f32x4 bv0 = {0.f, 0.f, 0.f, 0.f};
+        int item = -1, it = 0;
+        Work w = next_work(s, sc, wg, item, nitems);
+        while (w.ng > 0) {
+            const TilePos cur = work_pos(s, w);
+            const u16* pcur = lds + (it & 1) * BUF;
+            wait_for(it & 1, 4 * ((it >> 1) + 1));
+            // ---- the convolution over P: dx (KIND 1, masked by the layer input) / cot_dy (KIND 2)
+            fwd_piece<SP, DIL, OUTMASK, PMASK, NPL, true, NMW, 0>(pcur, nullptr, wf, cur, s, wave, lane, it, bv0, qsrc, y, false, alpha, true, false);
+            // ---- the weight gradient: K step = 16 rows x 2 adjacent bin groups, both operands read transposed
+            const u16* abase0 = pcur + aoff + bin_off(2 + (li & 3));
+            const u16* abase1 = pcur + aoff + bin_off(6 + (li & 3));
+            const u16* dbase0 = pcur + doff + bin_off(0 + (li & 3));
+            const u16* dbase1 = pcur + doff + bin_off(4 + (li & 3));
+            const u16* dbase2 = pcur + doff + bin_off(8 + (li & 3));
+            const int ng2 = (cur.ng + 1) >> 1;
+            for (int gp = (wave + it) & 3; gp < ng2; gp += 4) {
+                const bool second = 2 * gp + 1 < cur.ng;         // wave-uniform
+                bf16x8 af[NPL];
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) {
+                    bf16x4 h0 = tr_read(abase0 + 32 * gp + p * APS), h1 = tr_read(abase1 + 32 * gp + p * APS);
+                    if (!second) h1 = __builtin_bit_cast(bf16x4, (u32x2){0u, 0u});
+                    af[p] = cat(h0, h1);
+                }
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    bf16x4 d0[NPL], d1[NPL], d2[NPL];
+#pragma unroll
+                    for (int p = 0; p < NPL; ++p) {
+                        const int off = 32 * gp + p * SP::PS + (KT - 1 - kt) * DIL * SP::RS;
+                        d0[p] = tr_read(dbase0 + off);
+                        d1[p] = tr_read(dbase1 + off);
+                        d2[p] = tr_read(dbase2 + off);
+                    }
+#define C2M_MM(PA_, PW_)                                                                                                 \
+                    { constexpr int PA = PA_ < NPL ? PA_ : 0, PW = PW_ < NPL ? PW_ : 0;                                  \
+                    acc[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA], cat(d0[PW], d1[PW]), acc[kt][0], 0, 0, 0);   \
+                    acc[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA], cat(d1[PW], d2[PW]), acc[kt][1], 0, 0, 0); }
+                    C2M_PRODUCTS_NPL(NPL, C2M_MM);
+#undef C2M_MM
+                }
+            }
+            signal(2 + (it & 1));
+            w = next_work(s, sc, wg, item, nitems);
+            ++it;
+        }
+        __syncthreads();
+        // ---- one reduction per workgroup, fixed order (wgrad_kernel's): red[wave][kt][hb][r][lane]
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[(((wave * KT + kt) * 2 + hb) * 4 + r) * 64 + lane] = acc[kt][hb][r];
+    }
+    __syncthreads();
+    float* out = partials + (size_t)blockIdx.x * NPART;
+    for (int i = tid; i < KT * KF * 16; i += 8 * 64) {
+        const int co = i & 3, ci = (i >> 2) & 3, kf = (i >> 4) % KF, kt = (i >> 4) / KF;
+        float sum = 0.f;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) {
+                const int fo = fi + 4 - 4 * hb - kf;
+                if (fo >= 0 && fo < 4) {
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) sum += red[(((w * KT + kt) * 2 + hb) * 4 + ci) * 64 + 16 * fi + 4 * fo + co];
+                }
+            }
+        out[i] = sum;
+    }
+    if (tid < 64) {
+        const int ch = tid & 3, j0 = tid >> 2;
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v += bs[(j0 * 16 + j) * 4 + ch];
+        v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+        if (tid < 4) out[KT * KF * 16 + tid] = v;
+    }
+}
+
 }  // namespace c2m
 }  // namespace ptts
 
@@ -1131,4 +1330,58 @@ extern "C" int ptts_conv2d_mfma_wgrad_partials(const void* dy, const void* x, co
     *nblocks_out = grid;
     *npart_out = NPART;
     return check_launch("conv2d_mfma_wgrad");
+}
+
+extern "C" size_t ptts_conv2d_mfma_bwd_fused_workspace_bytes(int B, int T) {
+    (void)B; (void)T;
+    return 4096 + (size_t)NCU * NPART * sizeof(float);
+}
+
+// 1 when the fused backward launch exists for the shape: 5x5, 4 -> 4 channels, time dilation 1, fp32 maps (three planes)
+extern "C" int ptts_conv2d_mfma_bwd_fused_supported(int F, int dil_t, int planes) {
+    return (F >= 1 && dil_t == 1 && planes == 3) ? 1 : 0;
+}
+
+// Two passes of a 4 -> 4 5x5 layer that share a staged tile, as ONE launch (c2m::bwd_ws_kernel):
+//   kind 1 (first-order backward):  p = dy, q = x (the layer's pre-activation input; a = lrelu(x)), table = the transposed table:
+//           y = dx = conv^T(dy) . lrelu'(x);  partial rows of dW = corr(lrelu(x), dy) and dbias = sum dy
+//   kind 2 (second-order sweep):    p = u with mask_src = x (a = u . lrelu'(x)), q = dy, table = the forward table:
+//           y = cot_dy = conv(a);             partial rows of dW = corr(a, dy) (no bias gradient: the row's bias sums are zero)
+// pad_t is the FORWARD layer's ('same': 2).  Partial rows as ptts_conv2d_mfma_wgrad_partials writes them (4096-byte head).
+extern "C" int ptts_conv2d_mfma_bwd_fused(const void* p, const void* q, const void* mask_src, const void* table, void* y,
+                                          void* workspace, size_t workspace_bytes, int* nblocks_out, int* npart_out,
+                                          int B, int T, int F, int KT_, int pad_t, int kind, float alpha, void* stream) {
+    if (int rc = check_status("conv2d_mfma_bwd_fused")) return rc;
+    PTTS_REQUIRE(p && q && table && y && workspace && nblocks_out && npart_out, "conv2d_mfma_bwd_fused: null pointer");
+    PTTS_REQUIRE(B > 0 && T > 0 && F > 0 && KT_ == 5, "conv2d_mfma_bwd_fused: bad dims B=%d T=%d F=%d KT=%d", B, T, F, KT_);
+    PTTS_REQUIRE(kind == 1 || kind == 2, "conv2d_mfma_bwd_fused: kind %d (1 = first-order backward, 2 = second-order sweep)", kind);
+    PTTS_REQUIRE(kind == 1 || mask_src, "conv2d_mfma_bwd_fused: the second-order sweep needs mask_src");
+    PTTS_REQUIRE(pad_t == 2, "conv2d_mfma_bwd_fused: built for 'same' padding at dilation 1 (pad_t 2, got %d)", pad_t);
+    PTTS_REQUIRE(alpha >= 0.f && alpha <= 1.f, "conv2d_mfma_bwd_fused: LeakyReLU slope %g outside [0, 1]", alpha);
+    PTTS_REQUIRE((long long)(T + 64) * F * C < (1LL << 31), "conv2d_mfma_bwd_fused: utterance too large for 32-bit tile offsets");
+    const Shape s = make_shape(B, T, F, pad_t);
+    PTTS_REQUIRE(shape_ok(s), "conv2d_mfma_bwd_fused: too many tiles");
+    const size_t need = ptts_conv2d_mfma_bwd_fused_workspace_bytes(B, T);
+    if (workspace_bytes < need) { set_error("conv2d_mfma_bwd_fused: workspace %zu < %zu", workspace_bytes, need); return PTTS_EWORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    float* parts = reinterpret_cast<float*>((char*)workspace + 4096);
+    typedef Stage<4 * (GPB + 1) + 4, 16 + (KT - 1)> SP;
+    int grid = 0;
+#define C2M_BF(KIND)                                                                                                     \
+    do {                                                                                                                 \
+        typedef Stage<4 * (GPB + 1) + 4, KIND == 1 ? 16 : 16 + (KT - 1)> SQ;                                             \
+        constexpr size_t lds = (size_t)2 * NP * (SP::PS + SQ::PS) * sizeof(u16) + 64;                                    \
+        static_assert(lds <= LDS_MAX, "tile does not fit the LDS");                                                      \
+        static_assert((size_t)(4 * KT * 2 * 4 * 64 + 256 * 4) * sizeof(float) <= lds, "reduction scratch");             \
+        static bool attr = false;                                                                                        \
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_ws_kernel<KIND, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX); attr = true; } \
+        const Sched sc = sched_for(s.ntiles, lds, 1, 2);                                                                 \
+        grid = sc.G;                                                                                                     \
+        hipLaunchKernelGGL((bwd_ws_kernel<KIND, NP>), dim3(grid), dim3(8 * 64), lds, st, p, q, mask_src, (const u16*)table, y, parts, s, sc, alpha, g_dbg, status_words()); \
+    } while (0)
+    if (kind == 1) C2M_BF(1); else C2M_BF(2);
+#undef C2M_BF
+    *nblocks_out = grid;
+    *npart_out = NPART;
+    return check_launch("conv2d_mfma_bwd_fused");
 }

@@ -401,6 +401,37 @@ def _conv2d_mfma_wgrad(dy, x, mask_src, mode, alpha, dil_t, pad_t, planes=3):
     return buf, nblocks.value, npart.value
 
 
+class _C2MFused(object):
+    """The fused backward launches of csrc/conv2d_mfma.hip (c2m::bwd_ws_kernel; dilation 1, fp32 maps): dx + dW of a layer, and the
+    second-order sweep's masked forward + dW, as ONE launch each -- one staging of the shared operand.  PTTS_C2M_FUSED=0 /
+    conv2d_fused(False) select the separate launches (A/B, tests)."""
+    default = os.environ.get('PTTS_C2M_FUSED', '1') == '1'
+    enabled = default
+
+    @staticmethod
+    def ok(x, dil_t, pad_mode, planes):
+        return _C2MFused.enabled and planes == 3 and dil_t == 1 and pad_mode == PAD_SAME and not _is16(x)
+
+
+def conv2d_fused(on):
+    _C2MFused.enabled = _C2MFused.default if on is None else bool(on)
+
+
+def _conv2d_mfma_bwd_fused(kind, p, q, mask_src, w, alpha):
+    """kind 1: (dy, x) -> dx, partial rows of dW / dbias; kind 2: (u, dy, mask_src = x) -> cot_dy, partial rows of dW.
+    Returns (y, buffer, nblocks, npart); the rows start 4096 bytes into the buffer."""
+    B, T, F, _ = p.shape
+    f32c(p, 'conv2d_bwd_fused.p'); f32c(q, 'conv2d_bwd_fused.q'); f32c(mask_src)
+    assert q.shape == p.shape and (mask_src is None or mask_src.shape == p.shape)
+    y = torch.empty_like(p)
+    nws = _hip.lib().ptts_conv2d_mfma_bwd_fused_workspace_bytes(B, T)
+    buf = torch.empty(int(nws), dtype=torch.uint8, device=p.device)
+    nblocks, npart = ctypes.c_int(0), ctypes.c_int(0)
+    call('ptts_conv2d_mfma_bwd_fused', ptr(p), ptr(q), ptr(mask_src), ptr(_C2M.table(w, kind == 1)), ptr(y), ptr(buf), buf.numel(),
+         ctypes.byref(nblocks), ctypes.byref(npart), B, T, F, 5, 2, kind, alpha, stream(), tag=(B, T, F, kind))
+    return y, buf, nblocks.value, npart.value
+
+
 def _st(t, name='tensor'):
     """Validate a conv2d map of the bf16-storage path: contiguous device tensor, fp32 or bf16."""
     if t is None:
@@ -453,12 +484,16 @@ def _conv2d_bwd_raw(dy, x, w, scale, shift, mask_src, mode, alpha, dil_t, pad_mo
         # stored like the map (bf16 storage: dx has x's type)
         pad_t = _C2M.pad_t(dil_t, pad_mode)
         dx = dw = db = None
-        if want_dx:
+        fused = want_dx and (want_dw or want_db) and mode == IN_LRELU and _C2MFused.ok(x, dil_t, pad_mode, planes)
+        if fused:
+            dx, buf, nblocks, npart = _conv2d_mfma_bwd_fused(1, dy, x, None, w, alpha)
+        elif want_dx:
             assert mode != IN_MASKMUL, 'conv2d_bwd: dx is not defined for MASKMUL (weight-only sweep)'
             dx = _conv2d_mfma_fwd(dy, w, _C2M.table(w, True, planes), None, None, None, None, x if mode == IN_LRELU else None,
                                   IN_NONE, alpha, dil_t, 4 * dil_t - pad_t, planes, _is16(x))
         if want_dw or want_db:
-            buf, nblocks, npart = _conv2d_mfma_wgrad(dy, x, mask_src, mode, alpha, dil_t, pad_t, planes)
+            if not fused:
+                buf, nblocks, npart = _conv2d_mfma_wgrad(dy, x, mask_src, mode, alpha, dil_t, pad_t, planes)
             dw = torch.zeros_like(w) if want_dw else None
             db = torch.zeros(Cout, dtype=torch.float32, device=dev) if want_db else None
             desc = (_hip.Conv2dReduceDesc * 1)()
@@ -491,10 +526,13 @@ def _conv2d_bwd_deferred(dy, x, w, mask_src, mode, alpha, dil_t, pad_mode, want_
     if (planes == 1 or _C2M.enabled) and _C2M.eligible(x, w, dil_t) and 0.0 <= alpha <= 1.0:
         pad_t = _C2M.pad_t(dil_t, pad_mode)
         dx = None
-        if want_dx:
-            dx = _conv2d_mfma_fwd(dy, w, _C2M.table(w, True, planes), None, None, None, None, x if mode == IN_LRELU else None,
-                                  IN_NONE, alpha, dil_t, 4 * dil_t - pad_t, planes, _is16(x))
-        buf, nblocks, npart = _conv2d_mfma_wgrad(dy, x, mask_src, mode, alpha, dil_t, pad_t, planes)
+        if want_dx and mode == IN_LRELU and _C2MFused.ok(x, dil_t, pad_mode, planes):
+            dx, buf, nblocks, npart = _conv2d_mfma_bwd_fused(1, dy, x, None, w, alpha)      # dx + dW + dbias: one launch
+        else:
+            if want_dx:
+                dx = _conv2d_mfma_fwd(dy, w, _C2M.table(w, True, planes), None, None, None, None, x if mode == IN_LRELU else None,
+                                      IN_NONE, alpha, dil_t, 4 * dil_t - pad_t, planes, _is16(x))
+            buf, nblocks, npart = _conv2d_mfma_wgrad(dy, x, mask_src, mode, alpha, dil_t, pad_t, planes)
         cur = torch.cuda.current_stream()
         if all(cur.cuda_stream != st.cuda_stream for st in _Deferred.streams):
             _Deferred.streams.append(cur)
@@ -750,6 +788,25 @@ class Conv2dBwdDataFn(torch.autograd.Function):
         u = u.contiguous()
         m2, msk = (IN_MASKMUL, x) if mode == IN_LRELU else (IN_NONE, None)
         cot_dy = cot_w = None
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[2] and m2 == IN_MASKMUL and _C2M.enabled and _C2M.eligible(u, w, dil_t) and \
+                0.0 <= alpha <= 1.0 and _C2MFused.ok(u, dil_t, pad_mode, planes):
+            # the masked forward and the weight gradient of the sweep read the same staged tile u . lrelu'(x): one launch
+            defer = _Deferred.active and not _Flags.deterministic and ctx.gw is not None
+            cot_dy, buf, nblocks, npart = _conv2d_mfma_bwd_fused(2, u, dy, msk, w, alpha)
+            if defer:
+                cur = torch.cuda.current_stream()
+                if all(cur.cuda_stream != st.cuda_stream for st in _Deferred.streams):
+                    _Deferred.streams.append(cur)
+                _Deferred.conv_items.append((buf, 4096, nblocks, npart, w.numel(), w.shape[3], ctx.gw, None))
+                return cot_dy, None, None, None, None, None, None, None, None
+            cot_w = torch.zeros_like(w)
+            desc = (_hip.Conv2dReduceDesc * 1)()
+            desc[0].partials = buf.data_ptr() + 4096
+            desc[0].nblocks, desc[0].npart, desc[0].nw, desc[0].cout = nblocks, npart, w.numel(), w.shape[3]
+            desc[0].dw = cot_w.data_ptr()
+            desc[0].dbias = None
+            call('ptts_conv2d_reduce_grouped', ctypes.cast(desc, ctypes.c_void_p), 1, stream(), tag=(1,))
+            return cot_dy, None, cot_w, None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             cot_dy = _conv2d_fwd_raw(u, w, None, None, None, msk, m2, alpha, dil_t, pad_mode, planes, _is16(dy))
         if ctx.needs_input_grad[2]:

@@ -777,7 +777,7 @@ def test_critic_step_at_baseline_architecture_against_oracle(full_arch):
     # the kernels of the BASELINE-size step ran, not their small-shape fallbacks
     for need in ('ptts_dense_bf16x6_batched', 'ptts_split3_frame_windows', 'ptts_conv1d_freq_wgrad_inverse',     # frequency-domain Conv1D
                  'ptts_dense_bf16x6', 'ptts_dense_wgrad_bf16x6_partials', 'ptts_dense_wgrad_reduce_grouped',      # split Dense + two-stage dW
-                 'ptts_conv2d_mfma_fwd', 'ptts_conv2d_mfma_wgrad_partials', 'ptts_conv2d_reduce_grouped'):
+                 'ptts_conv2d_mfma_fwd', 'ptts_conv2d_mfma_bwd_fused', 'ptts_conv2d_reduce_grouped'):                            # matrix-core Conv2D, fused backward
         assert need in names, '{} did not run in the B = 16 critic step: {}'.format(need, sorted(set(names)))
     num = den = 0.0
     worst = (0.0, None)

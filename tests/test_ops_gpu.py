@@ -201,7 +201,12 @@ def test_conv2d_mfma_against_the_oracle_and_the_fp32_stencil(ops, case):
 
     res_m, names_m = run(True)
     res_s, names_s = run(False)
-    assert names_m.count('ptts_conv2d_mfma_fwd') == 4 and names_m.count('ptts_conv2d_mfma_wgrad_partials') == 2, names_m
+    if dil == 1 and not causal:
+        # dx + dW + dbias of the layer are ONE launch (c2m::bwd_ws_kernel, kind 1)
+        assert names_m.count('ptts_conv2d_mfma_fwd') == 3 and names_m.count('ptts_conv2d_mfma_wgrad_partials') == 1 and \
+            names_m.count('ptts_conv2d_mfma_bwd_fused') == 1, names_m
+    else:
+        assert names_m.count('ptts_conv2d_mfma_fwd') == 4 and names_m.count('ptts_conv2d_mfma_wgrad_partials') == 2, names_m
     assert 'ptts_conv2d_fwd' not in names_m and not any(n.startswith('ptts_conv2d_mfma') for n in names_s)
     wants = (yr, xr.grad, wr.grad, br.grad, ya, ym, wm.grad)
     tols = ((RT, AT), (RT, AT), (2e-4, 1e-4), (2e-4, 1e-4), (RT, AT), (RT, AT), (2e-4, 1e-4))
@@ -241,6 +246,59 @@ def test_conv2d_mfma_wave_specialised_form_is_bit_identical(ops, case):
         lib.ptts_conv2d_mfma_debug(0, None)
     for nm, a, c in zip(('y', 'y (affine)', 'y (maskmul)', 'dx'), res_ws, res_4):
         assert torch.equal(a, c), nm
+
+
+@pytest.mark.parametrize('case', [(3, 100, 65), (2, 16, 65), (1, 1, 65), (2, 37, 130), (5, 400, 65), (1, 50, 129), (4, 7, 33), (300, 17, 3), (2, 33, 71), (64, 400, 65)])
+def test_conv2d_mfma_fused_backward_launches(ops, case):
+    """The fused backward launches (c2m::bwd_ws_kernel, round 4): dx + dW + dbias of a layer (kind 1) and the second-order sweep's
+    masked forward + dW (kind 2), each ONE launch sharing the staging of dy / u, against the separate launches they replace
+    (ops.conv2d_fused(False)): dx and cot_dy bit for bit (same tiles, passes and MFMA order), the weight and bias gradients --
+    partial sums grouped per 256 instead of 512 workgroups -- to fp32 summation accuracy, and against an fp64 oracle.  Shapes:
+    ragged T and F, F > 68 (two bin blocks), F = 3 (one group: the zeroed half of an odd piece's last pair), many small
+    utterances, and BASELINE's [64,400,65]."""
+    B, T, F = case
+    g = gen(79)
+    x = torch.randn(B, T, F, 4, generator=g).cuda()
+    u = torch.randn(B, T, F, 4, generator=g).cuda()
+    dy = torch.randn(B, T, F, 4, generator=g).cuda()
+    w = (torch.randn(5, 5, 4, 4, generator=g) * 0.3).cuda()
+
+    def run(fused):
+        ops.conv2d_fused(fused)
+        try:
+            with ops._hip.KernelTimer() as kt:
+                dx, dw, db, _, _ = ops._conv2d_bwd_raw(dy, x, w, None, None, None, ops.IN_LRELU, 0.3, 1, ops.PAD_SAME, True, True, True, False)
+                # second order through the autograd Function that runs it in the optimiser: backward of the backward-data pass
+                dyr, wr = dy.clone().requires_grad_(True), w.clone().requires_grad_(True)
+                gx = ops.Conv2dBwdDataFn.apply(dyr, x, wr, ops.IN_LRELU, 0.3, 1, ops.PAD_SAME, None, 3)
+                gx.backward(u)
+            torch.cuda.synchronize()
+            return (dx, dw, db, dyr.grad, wr.grad), [r[0] for r in kt.records]
+        finally:
+            ops.conv2d_fused(None)
+    (dx1, dw1, db1, c1, cw1), n1 = run(True)
+    (dx0, dw0, db0, c0, cw0), n0 = run(False)
+    assert n1.count('ptts_conv2d_mfma_bwd_fused') == 2 and 'ptts_conv2d_mfma_wgrad_partials' not in n1, n1
+    assert 'ptts_conv2d_mfma_bwd_fused' not in n0 and n0.count('ptts_conv2d_mfma_wgrad_partials') == 2, n0
+    assert torch.equal(dx1, dx0) and torch.equal(c1, c0)
+    for nm, a, b in (('dw', dw1, dw0), ('db', db1, db0), ('cot_w', cw1, cw0)):
+        assert float((a - b).norm()) <= 3e-6 * float(b.norm()) + 1e-6, (nm, float((a - b).norm() / b.norm()))
+    # fp64 oracle (chunked over the batch)
+    dw64 = torch.zeros(5, 5, 4, 4, dtype=torch.float64); db64 = torch.zeros(4, dtype=torch.float64); cw64 = torch.zeros(5, 5, 4, 4, dtype=torch.float64)
+    step = max(1, min(B, (1 << 19) // (T * F)))
+    for b0 in range(0, B, step):
+        sl = slice(b0, b0 + step)
+        xq = x[sl].double().cpu().requires_grad_(True); wq = w.double().cpu().requires_grad_(True); bq = torch.zeros(4, dtype=torch.float64, requires_grad=True)
+        O.conv2d_nhwc(O.lrelu(xq), wq, bq).backward(dy[sl].double().cpu())
+        dw64 += wq.grad; db64 += bq.grad
+        close(dx1[sl], xq.grad, rtol=RT, atol=AT, what='dx (fused)')
+        m = torch.where(x[sl].double().cpu() > 0, 1.0, 0.3)
+        wq2 = w.double().cpu().requires_grad_(True)
+        O.conv2d_nhwc(u[sl].double().cpu() * m, wq2, None).backward(dy[sl].double().cpu())
+        cw64 += wq2.grad
+        close(c1[sl], O.conv2d_nhwc(u[sl].double().cpu() * m, w.double().cpu(), None), rtol=RT, atol=AT, what='cot_dy (fused)')
+    for nm, a, b in (('dw', dw1, dw64), ('db', db1, db64), ('cot_w', cw1, cw64)):
+        assert float((a.double().cpu() - b).abs().max()) <= 2e-5 * float(b.abs().mean()) + 1e-5, (nm, float((a.double().cpu() - b).abs().max() / b.abs().mean()))
 
 
 def test_conv2d_mfma_hand_off_timeout_is_reported_not_silent(ops):
