@@ -314,6 +314,13 @@ int ptts_dense_wgrad_bf16x6(const float* A, const float* dY, const float* mask_s
 int ptts_dense_bf16x6(const float* A, const void* planes, const float* bias, float* C, int M, int N, int K,
                       long long lda, long long ldc, int in_mode, const float* in_scale, const float* in_shift,
                       const float* mask_src, float alpha, int accumulate, const float* out_mask, void* stream);
+/* ... + res[m % res_rows][n] (row stride ldr floats) added in the store, res_rows <= M <= 8 res_rows: the product of a concatenation part
+ * shared by k stacked evaluations (the critic's context branch, networks_critic.py:78-86, computed once at B rows) joins each of the k
+ * row blocks without an add pass.  res == C with res_rows >= M is ptts_dense_bf16x6's accumulate. */
+int ptts_dense_bf16x6_res(const float* A, const void* planes, const float* bias, float* C, int M, int N, int K,
+                          long long lda, long long ldc, int in_mode, const float* in_scale, const float* in_shift,
+                          const float* mask_src, float alpha, const float* res, int res_rows, long long ldr,
+                          const float* out_mask, void* stream);
 /* Frequency-domain context Conv1D, helper: Ap [NB][2][B][2*Kh] floats with [Xr | .] in part 0 and [Xi | .] in part 1 (columns < Cin)
  * -> columns Kh .. Kh+Cin-1 get -Xi (part 0) and Xr (part 1): the rows [Xr | -Xi], [Xi | Xr] of the real form of a complex product. */
 int ptts_dft_mirror(float* Ap, int NB, int B, int Cin, int Kh, void* stream);

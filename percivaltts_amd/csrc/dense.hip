@@ -221,6 +221,7 @@ struct DenseArgs {
     long long lda, ldc;
     float alpha, out_alpha;
     int accumulate, has_affine, vec_out;
+    const float* res; int res_rows; long long ldr;      // residual added in the store: C[m][n] += res[m % res_rows][n] (NULL: none).  accumulate = res == C
     long long bsA, bsP, bsC;          // batched launch (gridDim.z products of one shape): strides of A and C in floats, of the planes in u16
 };
 
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(THREADS) void dense_bf16x6_kernel(DenseArgs g) {
                     const long long off = (long long)m * g.ldc + n;
                     float v = acc[i][j][e] + (g.bias ? g.bias[n] : 0.f);
                     if (g.out_mask) v *= g.out_mask[off] > 0.f ? 1.f : g.out_alpha;
-                    if (g.accumulate) v += g.C[off];
+                    if (g.res) { int mr = m; while (mr >= g.res_rows) mr -= g.res_rows; v += g.res[(long long)mr * g.ldr + n]; }
                     g.C[off] = v;
                 }
             }
@@ -393,15 +394,17 @@ __global__ __launch_bounds__(THREADS) void dense_bf16x6_kernel(DenseArgs g) {
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if (g.bias) bv = *reinterpret_cast<const f32x4*>(g.bias + n);
         const long long off0 = (long long)(m0 + li) * g.ldc + n;
+        // row of the residual: m modulo res_rows (a product shared by k stacked evaluations is added to each of its k row blocks)
+        auto res_at = [&](int m) { int mr = m; while (mr >= g.res_rows) mr -= g.res_rows; return g.res + (long long)mr * g.ldr + n; };
         if (interior) {
             f32x4 mk[MT], old[MT];
             if (g.out_mask) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) mk[i] = *reinterpret_cast<const f32x4*>(g.out_mask + off0 + (long long)16 * i * g.ldc);
             }
-            if (g.accumulate) {
+            if (g.res) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i) old[i] = *reinterpret_cast<const f32x4*>(g.C + off0 + (long long)16 * i * g.ldc);
+                for (int i = 0; i < MT; ++i) old[i] = *reinterpret_cast<const f32x4*>(res_at(m0 + 16 * i + li));
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(THREADS) void dense_bf16x6_kernel(DenseArgs g) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] * (mk[i][e] > 0.f ? 1.f : g.out_alpha);
                 }
-                if (g.accumulate) v += old[i];
+                if (g.res) v += old[i];
                 *reinterpret_cast<f32x4*>(g.C + off0 + (long long)16 * i * g.ldc) = v;
             }
         } else {
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(THREADS) void dense_bf16x6_kernel(DenseArgs g) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] * (mk[e] > 0.f ? 1.f : g.out_alpha);
                 }
-                if (g.accumulate) v += *reinterpret_cast<const f32x4*>(g.C + off);
+                if (g.res) v += *reinterpret_cast<const f32x4*>(res_at(m));
                 *reinterpret_cast<f32x4*>(g.C + off) = v;
             }
         }
@@ -780,9 +783,26 @@ extern "C" int ptts_dense_bf16x6_supported(int M, int N, int K, long long lda, l
 
 // C[M,N] (+)= T(A)[M,K] . B (+ bias), then C *= (out_mask > 0 ? 1 : alpha) -- the contract of ptts_gemm with transA = 0 and
 // B given as the planes of ptts_split3_dense_weight.  in_mode / in_scale / in_shift / mask_src / alpha as in ptts_gemm.
+extern "C" int ptts_dense_bf16x6_res(const float* A, const void* planes, const float* bias, float* C, int M, int N, int K,
+                                     long long lda, long long ldc, int in_mode, const float* in_scale, const float* in_shift,
+                                     const float* mask_src, float alpha, const float* res, int res_rows, long long ldr,
+                                     const float* out_mask, void* stream);
 extern "C" int ptts_dense_bf16x6(const float* A, const void* planes, const float* bias, float* C, int M, int N, int K,
                                  long long lda, long long ldc, int in_mode, const float* in_scale, const float* in_shift,
                                  const float* mask_src, float alpha, int accumulate, const float* out_mask, void* stream) {
+    return ptts_dense_bf16x6_res(A, planes, bias, C, M, N, K, lda, ldc, in_mode, in_scale, in_shift, mask_src, alpha,
+                                 accumulate ? C : nullptr, M, ldc, out_mask, stream);
+}
+
+// ... + res[m % res_rows][n] (row stride ldr) in the store: the product of a concat part that several stacked evaluations share (the
+// critic's context branch, computed once at B rows) joins each of the k B-row blocks of the stacked product without an add pass of its
+// own.  res == C, res_rows >= M is the plain accumulate of ptts_dense_bf16x6.
+extern "C" int ptts_dense_bf16x6_res(const float* A, const void* planes, const float* bias, float* C, int M, int N, int K,
+                                     long long lda, long long ldc, int in_mode, const float* in_scale, const float* in_shift,
+                                     const float* mask_src, float alpha, const float* res, int res_rows, long long ldr,
+                                     const float* out_mask, void* stream) {
+    const int accumulate = res != nullptr;
+    PTTS_REQUIRE(!res || (res_rows > 0 && ldr >= N && M <= 8LL * res_rows), "dense_bf16x6: bad residual (rows %d, ldr %lld)", res_rows, ldr);
     PTTS_REQUIRE(A && planes && C, "dense_bf16x6: null matrix");
     PTTS_REQUIRE(ptts_dense_bf16x6_supported(M, N, K, lda, ldc), "dense_bf16x6: unsupported shape M=%d N=%d K=%d lda=%lld ldc=%lld (K and lda must be multiples of 4)", M, N, K, lda, ldc);
     PTTS_REQUIRE(lda >= K && ldc >= N, "dense_bf16x6: bad leading dims");
@@ -793,7 +813,7 @@ extern "C" int ptts_dense_bf16x6(const float* A, const void* planes, const float
     PTTS_REQUIRE(!(out_mask && bias), "dense_bf16x6: out_mask with bias is not defined");
     PTTS_REQUIRE(alpha >= 0.f && alpha <= 1.f, "dense_bf16x6: LeakyReLU slope %g outside [0, 1]", alpha);
     const bool vec_out = N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0) &&
-                         (!out_mask || ((uintptr_t)out_mask & 15) == 0);
+                         (!out_mask || ((uintptr_t)out_mask & 15) == 0) && (!res || (((uintptr_t)res & 15) == 0 && ldr % 4 == 0));
     PTTS_REQUIRE(((uintptr_t)A & 15) == 0 && (!mask_src || ((uintptr_t)mask_src & 15) == 0) &&
                  (!in_scale || (((uintptr_t)in_scale | (uintptr_t)in_shift) & 15) == 0), "dense_bf16x6: A, its mask and scale/shift must be 16-byte aligned");
     DenseArgs g;
@@ -801,6 +821,7 @@ extern "C" int ptts_dense_bf16x6(const float* A, const void* planes, const float
     g.out_mask = out_mask; g.C = C; g.M = M; g.N = N; g.K = K;
     g.NT = (N + NBLK - 1) / NBLK * (NBLK / 16); g.KS = (K + BK - 1) / BK;
     g.lda = lda; g.ldc = ldc; g.alpha = alpha; g.out_alpha = alpha; g.accumulate = accumulate; g.has_affine = in_scale != nullptr; g.vec_out = vec_out;
+    g.res = res; g.res_rows = res ? res_rows : 1; g.ldr = ldr;
     g.bsA = g.bsP = g.bsC = 0;
     const int cb = (N + NBLK - 1) / NBLK;
     const int mt = pick_mt(M, cb);
@@ -868,6 +889,7 @@ extern "C" int ptts_dense_bf16x6_batched(const float* A, long long strideA, cons
     g.out_mask = nullptr; g.C = C; g.M = M; g.N = N; g.K = K;
     g.NT = (N + NBLK - 1) / NBLK * (NBLK / 16); g.KS = (K + BK - 1) / BK;
     g.lda = lda; g.ldc = ldc; g.alpha = 0.f; g.out_alpha = 0.f; g.accumulate = 0; g.has_affine = 0; g.vec_out = vec_out;
+    g.res = nullptr; g.res_rows = 1; g.ldr = 0;
     g.bsA = strideA; g.bsP = stride_planes_bytes / 2; g.bsC = strideC;
     const int cb = (N + NBLK - 1) / NBLK;
     // rows per workgroup: every workgroup of a product reads that product's planes, so fewer row tiles = fewer reads of the right

@@ -155,6 +155,17 @@ class Dense(Layer):
 
     def compute(self, vals, training, memo):
         v = vals[0]
+        if isinstance(v, LazyConcat) and memo is not None and len(v.parts) == 2 and \
+                ('dense_part', id(self), 1, id(v.parts[1].z)) in memo and torch.is_tensor(v.parts[0].z) and v.parts[0].z.is_cuda:
+            # two parts, the second one's product already made (shared by the stacked evaluations of forward_multi: the critic's
+            # context branch): it joins the first part's product inside that product's store -- no add pass, no broadcast copy
+            y = memo[('dense_part', id(self), 1, id(v.parts[1].z))]
+            k0 = v.parts[0].shape[-1]
+            lead = 1
+            for d_ in v.parts[0].shape[:-1]: lead *= d_
+            if lead % (y.numel() // y.shape[-1]) == 0:
+                z = ops.dense(v.parts[0], self.kernel[:k0], self.bias, res=y)
+                return _apply_activation(z, self.activation)
         if isinstance(v, LazyConcat):
             z, off = None, 0
             for i, part in enumerate(v.parts):
@@ -702,6 +713,65 @@ class Model(nn.Module):
         for vi, x in enumerate(variants):
             values = dict(shared)
             values[id(vin)] = x
+            if streams is not None and vi > 0:
+                st = streams[vi - 1]
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    values = self._run({}, training, memo, values)
+                    outs = [to_tensor(values[id(o)]) for o in self.outputs]
+            else:
+                values = self._run({}, training, memo, values)
+                outs = [to_tensor(values[id(o)]) for o in self.outputs]
+            results.append(outs[0] if self.single_output else outs)
+        if streams is not None:
+            for vi in range(1, len(variants)):
+                cur.wait_stream(streams[vi - 1])
+                for o in (results[vi] if isinstance(results[vi], list) else [results[vi]]):
+                    o.record_stream(cur)
+        return results
+
+    def forward_multi_at(self, node, variants, feed, training=False, memo=None, parallel_streams=False):
+        """forward_multi with the varying value at an INTERNAL node (`variants` are values of `node`, e.g. the critic's spectral slice:
+        the stacked real / fake spectra and the interpolated sample, built by the optimiser without materialising the 86-column
+        inputs they would be sliced from).  `feed` = {input node: tensor} for the inputs the rest of the graph needs; nodes that only
+        `node` depends on (its own inputs) are not evaluated.  Everything that does not depend on `node` is computed once and shared."""
+        memo = {} if memo is None else memo
+        desc = set([id(node)])
+        for n in self.order:
+            if any(id(p) in desc for p in n.parents):
+                desc.add(id(n))
+        anc = set()
+        def up(n):
+            for p in n.parents:
+                if id(p) not in anc:
+                    anc.add(id(p)); up(p)
+        up(node)
+        feed = {id(k): v for k, v in feed.items()}
+        shared = {}
+        for n in self.order:
+            if id(n) in desc:
+                continue
+            if not n.parents:
+                if id(n) in feed:
+                    shared[id(n)] = feed[id(n)]
+                else:
+                    assert id(n) in anc, 'forward_multi_at: input {} is needed but was not fed'.format(n.name)
+                    shared[id(n)] = None
+            elif id(n) in anc and any(shared.get(id(p)) is None for p in n.parents):
+                shared[id(n)] = None                  # feeds only `node`: its value is given
+            else:
+                shared[id(n)] = n.layer.compute([shared[id(p)] for p in n.parents], training, memo)
+        for n in self.order:
+            if isinstance(n.layer, Dense) and id(n) in desc and isinstance(n.parents[0].layer, Concatenate):
+                for i, pn in enumerate(n.parents[0].parents):
+                    if i > 0 and id(pn) in shared and shared[id(pn)] is not None:
+                        n.layer.prime_part(i, [pp.shape[-1] for pp in n.parents[0].parents], shared[id(pn)], memo)
+        results = []
+        streams = self._variant_streams(len(variants)) if parallel_streams else None
+        cur = torch.cuda.current_stream() if parallel_streams else None
+        for vi, x in enumerate(variants):
+            values = dict(shared)
+            values[id(node)] = x
             if streams is not None and vi > 0:
                 st = streams[vi - 1]
                 st.wait_stream(cur)

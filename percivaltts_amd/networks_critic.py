@@ -29,6 +29,9 @@ class Critic:
         self.input_features = kl.Input(shape=(None, vocoder.featuressize()), name='input_features')
 
         l_spec = kl.SliceLast(1, 1 + vocoder.specsize())(self.input_features)
+        # the optimiser feeds the critic at this node (kl.Model.forward_multi_at): the real / fake / interpolated SPECTRA, so that the
+        # 86-column samples the slice would cut them out of are never built (the critic reads nothing else: :57-59)
+        self.node_spec_in = l_spec
 
         if cfgarch.arch_gen_nbcnnlayers > 0:
             # build extension (BASELINE configs[2]; the reference is fp32): cfgarch.arch_critic_bf16

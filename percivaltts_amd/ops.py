@@ -627,8 +627,25 @@ def _ptr_off(t, off):
 
 def gemm_raw(A, Bm, C, M, N, K, transA=0, lda=None, rows_per_seg=None, seg_stride=0, transB=0, ldb=None, ldc=None,
              bias=None, mode=IN_NONE, scale=None, shift=None, mask_src=None, alpha=0.3, accumulate=0, out_mask=None,
-             colsum_b=None):
-    """C[M,N] (+)= opA(A).opB(B) (+bias).  Pointers may be views with offsets; dims are the caller's contract."""
+             colsum_b=None, res=None):
+    """C[M,N] (+)= opA(A).opB(B) (+bias).  Pointers may be views with offsets; dims are the caller's contract.
+    res [R, N] contiguous, M a multiple of R: C[m] += res[m % R] (the split Dense kernel adds it in its store; elsewhere an add pass)."""
+    if res is not None:
+        R = res.numel() // N
+        assert not accumulate and out_mask is None and M % R == 0 and res.is_contiguous()
+        N1 = N if (N <= 256 or N % 256 == 0 or N % 256 > 32) else N - N % 256
+        if transA == 0 and seg_stride == 0 and (rows_per_seg is None or rows_per_seg == M) and colsum_b is None and N1 == N and \
+                _DenseSplit.eligible(A, C, M, N, K, K if lda is None else lda, N if ldc is None else ldc, (scale, shift, mask_src)):
+            planes = _DenseSplit.get(Bm, K, N, (N if transB == 0 else K) if ldb is None else ldb, transB)
+            if planes is not None:
+                call('ptts_dense_bf16x6_res', ptr(A), ptr(planes), ptr(bias), ptr(C), M, N, K, K if lda is None else lda, N if ldc is None else ldc,
+                     mode, ptr(scale), ptr(shift), ptr(mask_src), alpha, ptr(res), R, N, None, stream(), tag=(M, N, K, transB, 'res'))
+                return C
+        gemm_raw(A, Bm, C, M, N, K, transA, lda, rows_per_seg, seg_stride, transB, ldb, ldc, bias, mode, scale, shift, mask_src, alpha)
+        Cv = C.view(M // R, R, N) if (ldc is None or ldc == N) else None
+        assert Cv is not None, 'gemm_raw: a residual needs a dense C'
+        Cv.add_(res.view(1, R, N))
+        return C
     for t in (A, Bm, C, bias, scale, shift, mask_src):
         if t is not None:
             assert t.is_cuda and t.dtype == torch.float32
@@ -1042,14 +1059,17 @@ def _dense_bwd_data(dy2, x2, w, mode, scale, shift, alpha, want_affine):
 
 
 class DenseFn(torch.autograd.Function):
+    """res (optional, [R..., N] with x's leading size a multiple of R): added to every R-row block of the product in the kernel's store
+    -- the product of a concatenation part that k stacked evaluations share (layers.Dense over a LazyConcat)."""
     @staticmethod
-    def forward(ctx, x, w, b, scale, shift, mode, alpha):
+    def forward(ctx, x, w, b, scale, shift, mode, alpha, res=None):
         f32c(x, 'dense.x'); f32c(w, 'dense.w')
         K, N = w.shape
         assert x.shape[-1] == K, 'dense: input width {} != kernel rows {}'.format(x.shape[-1], K)
         M = x.numel() // K
         y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
-        gemm_raw(x, w, y, M, N, K, bias=b, mode=mode, scale=scale, shift=shift, alpha=alpha)
+        gemm_raw(x, w, y, M, N, K, bias=b, mode=mode, scale=scale, shift=shift, alpha=alpha, res=None if res is None else f32c(res, 'dense.res'))
+        ctx.res_shape = None if res is None else tuple(res.shape)
         ctx.save_for_backward(x, w, scale, shift)
         ctx.has_b = b is not None
         ctx.cfg = (mode, alpha)
@@ -1062,11 +1082,18 @@ class DenseFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         if dy is None:               # see Conv2dFn.backward
-            return (None,) * 7
+            return (None,) * 8
         x, w, scale, shift = ctx.saved_tensors
         mode, alpha = ctx.cfg
         K, N = w.shape
         M = x.numel() // K
+        dres = None
+        if ctx.res_shape is not None and ctx.needs_input_grad[7]:
+            # gradient of the shared part: the sum of dy over the k row blocks it was added to (differentiable: plain torch ops)
+            R = 1
+            for d_ in ctx.res_shape: R *= d_
+            k = dy.numel() // R
+            dres = dy.reshape(ctx.res_shape) if k == 1 else dy.reshape((k,) + ctx.res_shape).sum(0)
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_b and ctx.needs_input_grad[2]
         need_aff = scale is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
         if _Flags.skip_param_grads:
@@ -1100,7 +1127,7 @@ class DenseFn(torch.autograd.Function):
                          mode=mode, scale=scale, shift=shift, alpha=alpha, colsum_b=db if fuse_b else None)
             if need_b and db is None:
                 db = _colsum_f32(dy2)
-        return dx, dw, db, dscale, dshift, None, None
+        return dx, dw, db, dscale, dshift, None, None, dres
 
 
 class DenseBwdDataFn(torch.autograd.Function):
@@ -1141,10 +1168,12 @@ class DenseBwdDataFn(torch.autograd.Function):
         return cot_dy, None, cot_w, None, None, None
 
 
-def dense(v, w, b=None):
-    """z_out = act(v).W + b over the last axis."""
+def dense(v, w, b=None, res=None):
+    """z_out = act(v).W + b over the last axis (+ res, broadcast over row blocks: see DenseFn)."""
     z, mode, scale, shift, alpha = _prep(v)
-    return DenseFn.apply(z, w, b, scale, shift, mode, alpha)
+    if res is None:
+        return DenseFn.apply(z, w, b, scale, shift, mode, alpha)
+    return DenseFn.apply(z, w, b, scale, shift, mode, alpha, res.contiguous())
 
 
 # ----------------------------------------------------------------------------------------------
@@ -2071,6 +2100,38 @@ class MeanScaledFn(torch.autograd.Function):
         for s in ctx.shape:
             n *= s
         return (up * (ctx.sign / n)).expand(ctx.shape).contiguous(), None
+
+
+class WassersteinPairFn(torch.autograd.Function):
+    """(-mean(v[:B]), +mean(v[B:])) of the stacked critic output v [2B, T, 1]: the two Wasserstein terms of the critic loss
+    (optimizertts_wgan.py:152-153) off ONE tensor -- sliced with torch, the backward of the two slices is two zero-filled
+    [2B,T,1] tensors, two copies and an add; here it is the two halves of one gradient tensor, written once."""
+    @staticmethod
+    def forward(ctx, v, B):
+        f32c(v, 'wasserstein.v')
+        n = v.numel()
+        h = n // v.shape[0] * B
+        out = torch.empty(2, dtype=torch.float32, device=v.device)
+        call('ptts_mean_scaled', ptr(v), h, -1.0, ptr(out), stream())
+        call('ptts_mean_scaled', ptr(_ptr_off(v, h)), n - h, 1.0, ptr(_ptr_off(out, 1)), stream())
+        ctx.cfg = (tuple(v.shape), B, h, n)
+        return out[0], out[1]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, up_v, up_f):
+        shape, B, h, n = ctx.cfg
+        dv = torch.empty(shape, dtype=torch.float32, device=(up_v if up_v is not None else up_f).device)
+        flat = dv.view(-1)
+        if up_v is None: flat[:h].zero_()
+        else: flat[:h].copy_((up_v * (-1.0 / h)).expand(h))
+        if up_f is None: flat[h:].zero_()
+        else: flat[h:].copy_((up_f * (1.0 / (n - h))).expand(n - h))
+        return dv, None
+
+
+def wasserstein_pair(v, B):
+    return WassersteinPairFn.apply(v.contiguous(), int(B))
 
 
 def wasserstein(v, sign):

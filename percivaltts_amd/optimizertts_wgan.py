@@ -135,6 +135,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         cfg.train_wgan_parallel_streams = False      # the critic evaluations on separate HIP streams
         cfg.train_wgan_side_backward_first = False   # generator step: the BLSTM's autograd node created last (its launches go out first), so that its backward chain is enqueued first.  Measured: the chain then ends 1 ms earlier, the step does not (the main stream's backward becomes the tail): off
         cfg.train_wgan_stack_real_fake = True        # critic(real) and critic(fake) as one stacked 2B pass (exact: no BatchNorm)
+        cfg.train_wgan_feed_spectra = True           # the critic is fed at its spectral slice (real / fake / interpolated spectra built directly; False: whole 86-column samples through the slice, as the reference's graph does)
         cfg.train_wgan_reuse_ctx_conv = True         # generator step reuses the critic step's G-context-Conv1D product (same batch)
         cfg.train_wgan_early_critic = True           # generator step: critic starts on the spectral branch, BLSTM joins for the LS term
         cfg.train_wgan_hoist_side_backward = True    # ... and the BLSTM branch's BACKWARD too (its output is read by the least-squares term only: the branch is cut out of the tape, run on its own, its gradient injected at the cut).  Measured + 1 % (three A/B pairs, fp32 and bf16): both chains then run under the critic step
@@ -233,29 +234,64 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
     # ---- device-side losses ----------------------------------------------------------------------------------
     def _fake_sample(self, X, training):
         """G(x) with the generator frozen: batch statistics in training mode but NO moving-average update
-        (hard parts)."""
+        (hard parts).  With the dead branches pruned: the spectral branch alone, [B,T,spec] -- the only columns
+        of G(x) the critic reads (networks_critic.py:57-59); critic_loss takes either form."""
         memo = {'freeze_bn_stats': True}
         self._wait_update('generator')
         with torch.no_grad():
             if self._gen_spec is not None:
-                spec = self._gen_spec(X, training=training, memo=memo)
-                voc = self._model.vocoder
-                fake = torch.zeros(X.shape[0], X.shape[1], voc.featuressize(), dtype=torch.float32, device=X.device)
-                fake[:, :, 1:1 + voc.specsize()] = spec
-                return fake
+                return self._gen_spec(X, training=training, memo=memo)
             return self._model.kerasmodel(X, training=training, memo=memo)
 
+    def _spec_of(self, t):
+        """The spectral columns of a sample [B,T,out] (a view), or the tensor itself if it already is the spectral slice [B,T,spec]."""
+        voc = self._model.vocoder
+        F = voc.specsize()
+        if t.shape[-1] == F and voc.featuressize() != F:
+            return t.reshape(t.shape[0], t.shape[1], F)
+        return t[:, :, 1:1 + F]
+
     def critic_loss(self, X, Y, alpha=None, training=True, fake=None):
-        """Total critic loss and its three parts on device tensors X [B,T,ctx], Y [B,T,out]."""
+        """Total critic loss and its three parts on device tensors X [B,T,ctx], Y [B,T,out]; `fake`: G(x) as [B,T,out] or just its
+        spectral columns [B,T,spec]."""
         if fake is None:
             fake = self._fake_sample(X, training)
         self._wait_update('critic')
-        x_hat = RandomWeightedAverage(X.shape[0])([Y, fake], alpha).requires_grad_(True)
         streams = bool(getattr(self.cfg, 'train_wgan_parallel_streams', False))
+        node = getattr(self.critic, 'node_spec_in', None)
+        B = Y.shape[0]
+        if node is not None and getattr(self.cfg, 'train_wgan_feed_spectra', True):
+            # The critic reads the spectral columns only (networks_critic.py:57-59).  It is fed AT its slice: real and fake spectra are
+            # copied once into the two halves of one [2B,T,spec] tensor (no 86-column fake sample, no concatenation, no slice copies),
+            # and x^ is interpolated between those halves.  d D(x^) / d x^ is zero in the columns the critic does not read, so the
+            # penalty's norm over [T,spec] IS the reference's norm over [T,out] (optimizertts_wgan.py:53-68).
+            F = self._model.vocoder.specsize()
+            spec2 = torch.empty((2 * B, Y.shape[1], F), dtype=torch.float32, device=Y.device)
+            spec2[:B].copy_(self._spec_of(Y))
+            spec2[B:].copy_(self._spec_of(fake))
+            if alpha is None:
+                alpha = torch.rand(B, device=Y.device, dtype=torch.float32)
+            x_hat = ops.gp_interpolate(spec2[:B], spec2[B:], alpha.reshape(-1).contiguous()).requires_grad_(True)
+            feed = {self.critic.input_ctx: X}
+            if getattr(self.cfg, 'train_wgan_stack_real_fake', True) and self._critic_is_per_sample():
+                # no BatchNorm in the critic: critic(real) and critic(fake) are one pass over the stacked 2B batch (half the launches,
+                # one weight-gradient product per layer instead of two; the context branch stays shared, at B)
+                both, v_hat = self.critic_net.forward_multi_at(node, [spec2, x_hat], feed, training=training, parallel_streams=streams)
+                l_valid, l_fake = ops.wasserstein_pair(both, B)
+            else:
+                valid, fake_v, v_hat = self.critic_net.forward_multi_at(node, [spec2[:B], spec2[B:], x_hat], feed, training=training,
+                                                                        parallel_streams=streams)
+                l_valid = wasserstein_loss(-1.0, valid)
+                l_fake = wasserstein_loss(+1.0, fake_v)
+            gp = gradient_penalty_loss(None, v_hat, x_hat)
+            total = l_valid + l_fake + float(self.cfg.train_wgan_pg_lambda) * gp
+            return total, (l_valid, l_fake, gp)
+        if fake.shape[-1] != Y.shape[-1]:          # a custom critic fed whole samples: the spectral branch embedded in zeros
+            full = torch.zeros_like(Y)
+            full[:, :, 1:1 + fake.shape[-1]] = fake
+            fake = full
+        x_hat = RandomWeightedAverage(X.shape[0])([Y, fake], alpha).requires_grad_(True)
         if getattr(self.cfg, 'train_wgan_stack_real_fake', True) and self._critic_is_per_sample():
-            # the critic has no BatchNorm, so critic(real) and critic(fake) are one pass over the stacked 2B batch: half the
-            # launches and one weight-gradient product per layer instead of two (the context branch stays shared, at B)
-            B = Y.shape[0]
             both, v_hat = self.critic_net.forward_multi(0, [torch.cat([Y, fake], 0), x_hat], [X], training=training,
                                                         parallel_streams=streams)
             valid, fake_v = both[:B], both[B:]
@@ -328,13 +364,10 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         return feed, values
 
     def fake_from_early(self, X, pre):
-        """The critic step's fake sample from the hoisted forward (the spectral branch, detached; the other columns are not read)."""
+        """The critic step's fake sample from the hoisted forward: the spectral branch [B,T,spec], detached (the other columns are not read)."""
         _, values = pre
         spec = kl.to_tensor(values[id(self._model.node_spec)]).detach()
-        voc = self._model.vocoder
-        fake = torch.zeros(X.shape[0], X.shape[1], voc.featuressize(), dtype=torch.float32, device=X.device)
-        fake[:, :, 1:1 + voc.specsize()] = spec
-        return fake
+        return spec.reshape(spec.shape[0], spec.shape[1], -1)
 
     def generator_loss(self, X, Y, training=True, pre=None):
         m = self._model.kerasmodel
@@ -358,10 +391,17 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             if ops.lstm_trace is not None and spec.requires_grad:
                 spec.register_hook(lambda g: ops._lstm_mark('critic_bwd_end'))
             voc = self._model.vocoder
-            feat = torch.zeros(X.shape[0], X.shape[1], voc.featuressize(), dtype=torch.float32, device=X.device)
-            feat[:, :, 1:1 + voc.specsize()] = spec
             self._wait_update('critic')          # the critic's update of this batch may still be in flight: G's forward above did not need it
-            valid = self.critic_net(feat, X, training=training)
+            cnode = getattr(self.critic, 'node_spec_in', None)
+            if cnode is not None and getattr(self.cfg, 'train_wgan_feed_spectra', True):
+                # the critic fed at its spectral slice (see critic_loss): no zero-padded 86-column sample, no slice copy, and the
+                # gradient comes back as [B,T,spec] straight into the generator's last convolution
+                valid = self.critic_net.forward_multi_at(cnode, [spec.reshape(spec.shape[0], spec.shape[1], voc.specsize())],
+                                                         {self.critic.input_ctx: X}, training=training)[0]
+            else:
+                feat = torch.zeros(X.shape[0], X.shape[1], voc.featuressize(), dtype=torch.float32, device=X.device)
+                feat[:, :, 1:1 + voc.specsize()] = spec
+                valid = self.critic_net(feat, X, training=training)
             l_w = wasserstein_loss(-1.0, valid)
             ops._lstm_mark('critic_fwd_end')
             values = m._run(feed, training, None, values=values)

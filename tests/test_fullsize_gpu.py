@@ -265,6 +265,30 @@ def test_stacked_real_fake_equals_separate_passes(setup):
     assert rel_l2(g1, g2) < 2e-5
 
 
+def test_critic_fed_at_its_spectral_slice_equals_whole_samples(setup):
+    """cfg.train_wgan_feed_spectra (default on, round 4): the critic is fed at its slice node -- real / fake spectra in the two halves of
+    one [2B,T,spec] tensor, x^ interpolated between them, the two Wasserstein terms off the one stacked output, the shared context
+    product added inside the first post-concat product's store -- against the reference's own data flow (86-column samples through
+    the slice, networks_critic.py:57-59; concatenation, slice copies and the broadcast add as torch ops): same losses, same gradients
+    (the penalty's norm over [T,spec] is the norm over [T,out]: the critic's gradient is zero in the columns it does not read)."""
+    cfg, opt, crit, X, Y = setup
+    g = torch.Generator().manual_seed(13)
+    alpha = torch.rand(B, generator=g).cuda()
+    with torch.no_grad():
+        fake = opt._fake_sample(X, True).detach()
+    assert fake.shape[-1] == SPEC
+    res = []
+    for feed in (True, False):
+        opt.cfg.train_wgan_feed_spectra = feed
+        res.append(_critic_grads(opt, X, Y, alpha, fake))
+    opt.cfg.train_wgan_feed_spectra = True
+    (t1, p1, g1), (t2, p2, g2) = res
+    for a, b, nm in zip(p1, p2, ('valid', 'fake', 'gp')):
+        close(a, b, 1e-5, 1e-6, 'fed at the slice vs whole samples: ' + nm)
+    close(t1, t2, 1e-5, 1e-6, 'total')
+    assert rel_l2(g1, g2) < 2e-5
+
+
 def test_batch_gradient_is_the_mean_of_the_shard_gradients(setup):
     """What data parallelism relies on: with per-sample interpolation weights fixed, the critic loss is a mean over the
     samples (no BatchNorm in the critic), so grad(batch) = (grad(first half) + grad(second half)) / 2."""
