@@ -220,8 +220,8 @@ class BatchNormalization(Layer):
     def compute(self, vals, training, memo):
         z = to_tensor(vals[0])
         update = bool(training) and not (memo is not None and memo.get('freeze_bn_stats', False))
-        scale, shift = ops.batchnorm_affine(z, self.gamma, self.beta, self.moving_mean, self.moving_variance,
-                                            bool(training), update, self.fused4d)
+        z, scale, shift = ops.batchnorm_affine(z, self.gamma, self.beta, self.moving_mean, self.moving_variance,
+                                               bool(training), update, self.fused4d)
         return Lazy(z, scale, shift, lrelu=False)
 
 

@@ -1726,7 +1726,10 @@ def _allreduce_small(t):
 
 
 class BatchNormTrainFn(torch.autograd.Function):
-    """(scale, shift) from the batch statistics of z [.., C]; updates the moving statistics in place."""
+    """(z, scale, shift) from the batch statistics of z [.., C]; updates the moving statistics in place.  z is handed THROUGH the
+    node (the consumer applies scale / shift to this output, not to the node's input): the consumer's gradient w.r.t. z then
+    arrives here and the statistics' share c2 z + c0 is added to it in the same pass (ptts_axpby_cols) -- as two separate
+    contributions autograd added them with one more pass over the map per BatchNorm layer."""
     @staticmethod
     def forward(ctx, z, gamma, beta, moving_mean, moving_var, update_moving, unbiased_moving):
         f32c(z, 'bn.z')
@@ -1745,7 +1748,7 @@ class BatchNormTrainFn(torch.autograd.Function):
                  1 if update_moving else 0, 1 if unbiased_moving else 0, ptr(scale), ptr(shift), ptr(mean), ptr(rstd),
                  ptr(ws), ws.numel(), ptr(_stream_counter(dev)), stream(), tag=(rows, C))
             ctx.save_for_backward(z, gamma, mean, rstd)
-            return scale, shift
+            return z.view_as(z), scale, shift
         sums = colsums(z.view(rows, C))
         if ctx.sync > 1:          # the statistics of the global batch: one tiny all-reduce (2C doubles)
             _allreduce_small(sums)
@@ -1754,11 +1757,11 @@ class BatchNormTrainFn(torch.autograd.Function):
              BN_EPS, BN_MOMENTUM, 1, 1 if update_moving else 0, 1 if unbiased_moving else 0, C,
              ptr(scale), ptr(shift), ptr(mean), ptr(rstd), stream())
         ctx.save_for_backward(z, gamma, mean, rstd)
-        return scale, shift
+        return z.view_as(z), scale, shift
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dscale, dshift):
+    def backward(ctx, dz_through, dscale, dshift):
         z, gamma, mean, rstd = ctx.saved_tensors
         C = z.shape[-1]
         rows = z.numel() // C
@@ -1782,12 +1785,14 @@ class BatchNormTrainFn(torch.autograd.Function):
         dz = None
         if ctx.needs_input_grad[0]:
             dz = torch.empty_like(z)
-            call('ptts_axpby_cols', None, None, ptr(z), ptr(c2), ptr(c0), ptr(dz), rows, C, stream())
+            if dz_through is not None:
+                dz_through = f32c(dz_through.contiguous(), 'bn.dz')
+            call('ptts_axpby_cols', ptr(dz_through), None, ptr(z), ptr(c2), ptr(c0), ptr(dz), rows, C, stream())
         return dz, dgamma, dbeta, None, None, None, None
 
 
 def batchnorm_affine(z, gamma, beta, moving_mean, moving_var, training, update_moving=True, unbiased_moving=False):
-    """Returns (scale, shift) such that BN(z) = scale*z + shift."""
+    """Returns (z', scale, shift) such that BN(z) = scale*z' + shift; z' is z handed through the autograd node (training) or z itself."""
     if training:
         return BatchNormTrainFn.apply(z, gamma, beta, moving_mean, moving_var, update_moving, unbiased_moving)
     C = z.shape[-1]
@@ -1795,7 +1800,7 @@ def batchnorm_affine(z, gamma, beta, moving_mean, moving_var, training, update_m
     shift = torch.empty(C, dtype=torch.float32, device=z.device)
     call('ptts_bn_finalize', None, 1, ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var), BN_EPS, BN_MOMENTUM,
          0, 0, 0, C, ptr(scale), ptr(shift), None, None, stream())
-    return scale, shift
+    return z, scale, shift
 
 
 # ----------------------------------------------------------------------------------------------

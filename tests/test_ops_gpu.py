@@ -847,8 +847,9 @@ def test_batchnorm_train_and_infer(ops, shape):
     yr.backward(dy)
     zd, gd, bd = dev(z, True), dev(gamma, True), dev(beta, True)
     mmd, mvd = dev(torch.zeros(C)), dev(torch.ones(C))
-    sc, sh = ops.batchnorm_affine(zd, gd, bd, mmd, mvd, True, True, fused4d)
-    yd = ops.Lazy(zd, sc, sh, lrelu=True).tensor()
+    # (z is handed through the node: the consumer's gradient and the statistics' share of dz are added in one pass)
+    zt, sc, sh = ops.batchnorm_affine(zd, gd, bd, mmd, mvd, True, True, fused4d)
+    yd = ops.Lazy(zt, sc, sh, lrelu=True).tensor()
     close(yd, yr, what='y')
     yd.backward(dev(dy))
     close(zd.grad, zr.grad, rtol=3e-4, atol=3e-5, what='dz')
@@ -857,7 +858,7 @@ def test_batchnorm_train_and_infer(ops, shape):
     close(mmd, mm, what='moving_mean')
     close(mvd, mv, what='moving_var')
     # inference mode uses the moving statistics
-    sc2, sh2 = ops.batchnorm_affine(zd.detach(), gd.detach(), bd.detach(), mmd, mvd, False)
+    _, sc2, sh2 = ops.batchnorm_affine(zd.detach(), gd.detach(), bd.detach(), mmd, mvd, False)
     yi = ops.Lazy(zd.detach(), sc2, sh2, lrelu=True).tensor()
     close(yi, O.lrelu(O.BN(ref(gamma), ref(beta), mm, mv)(ref(z), False)), what='infer')
 
