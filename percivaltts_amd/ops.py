@@ -1967,6 +1967,9 @@ def lstm_launch(x, W, U, b, reverse=False):
     return h, c, gates
 
 
+lstm_dx_ready = None      # (data_ptr of the last LSTM backward's dx, event recorded right behind its product)
+
+
 class LSTMFn(torch.autograd.Function):
     """x [B,T,In]; W [In, ndir*4H]; U [ndir,H,4H]; b [ndir*4H] -> h [B,T,ndir*H] (Keras gate order i,f,c,o)."""
     @staticmethod
@@ -2008,6 +2011,11 @@ class LSTMFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             gemm_raw(dgates, W, dx, M, In, ndir * G4, transB=1, ldb=ndir * G4)
+            # dx is what the rest of the backward pass waits for; the weight-gradient products below (0.5 ms at [64,400], H = 256) are
+            # not.  The point on this stream where dx is complete is published: a caller that runs this node on a side stream
+            # (optimizertts_wgan.generator_forward_early) lets the main stream wait for THIS event instead of for the whole node.
+            global lstm_dx_ready
+            lstm_dx_ready = (dx.data_ptr(), torch.cuda.current_stream().record_event())
         if ctx.needs_input_grad[1]:
             dW = torch.empty_like(W)
             gemm_raw(x, dgates, dW, In, ndir * G4, M, transA=1, lda=In, rows_per_seg=M)

@@ -352,14 +352,21 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
                             cols.append(torch.zeros(X.shape[0], X.shape[1], int(p.shape[-1]), dtype=torch.float32, device=X.device))
                     pred_tmp = torch.cat(cols, dim=-1)
                     l_tmp = specweighted_lse_loss(Y, pred_tmp, self._w_ls)
+                    ops.lstm_dx_ready = None
                     l_tmp.backward()
                     for p in sp:                               # the branch is done with: the join sees constants
                         values[id(p)] = kl.to_tensor(values[id(p)]).detach()
                     ev = side.record_event()
+                    # The main stream needs the branch's dx only: the recurrence's weight-gradient products behind it (0.5 ms) may
+                    # still run on the side stream while the trunk's backward goes on.  The LSTM's backward publishes the event right
+                    # behind its dx product; it is the leaf's gradient if autograd handed that very tensor over (no copy behind it).
+                    dxr = ops.lstm_dx_ready
                     for t, leaf, holder in values['__cuts__']:
                         if leaf.grad is not None:
-                            holder['grad'], holder['event'] = leaf.grad, ev
+                            early = dxr is not None and len(values['__cuts__']) == 1 and leaf.grad.data_ptr() == dxr[0]
+                            holder['grad'], holder['event'] = leaf.grad, (dxr[1] if early else ev)
                             self._gen_cuts.append(t)
+                    self._side_tail_event = ev                 # (the weight-gradient products: joined before the optimiser reads the buffer)
         values.pop('__cuts__', None)
         return feed, values
 
