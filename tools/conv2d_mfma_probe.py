@@ -33,6 +33,13 @@ if os.environ.get('C2M_ONLY'):
         call('ptts_conv2d_mfma_fwd', ptr(dy), ptr(tb), None, None, None, None, ptr(x), ptr(y), B, T, F, 5, dil, 4 * dil - pad, ops.IN_NONE, 0.3, 3, 0, 0, stream())
         call('ptts_conv2d_mfma_wgrad_partials', ptr(dy), ptr(x), None, ptr(ws), ws.numel(), ctypes.byref(nblocks), ctypes.byref(npart),
              B, T, F, 5, dil, pad, ops.IN_LRELU, 0.3, 3, 0, 0, stream())
+        if dil == 1:
+            # round 4: the fused backward launches (c2m::bwd_ws_kernel<1 / 2, 3>) and the masked forward they replace half of
+            call('ptts_conv2d_mfma_bwd_fused', ptr(dy), ptr(x), None, ptr(tb), ptr(y), ptr(ws), ws.numel(), ctypes.byref(nblocks), ctypes.byref(npart),
+                 B, T, F, 5, 2, 1, 0.3, stream())
+            call('ptts_conv2d_mfma_bwd_fused', ptr(msk), ptr(dy), ptr(x), ptr(tf), ptr(y), ptr(ws), ws.numel(), ctypes.byref(nblocks), ctypes.byref(npart),
+                 B, T, F, 5, 2, 2, 0.3, stream())
+            call('ptts_conv2d_mfma_fwd', ptr(msk), ptr(tf), None, None, None, ptr(x), None, ptr(y), B, T, F, 5, dil, pad, ops.IN_MASKMUL, 0.3, 3, 0, 0, stream())
     torch.cuda.synchronize()
     sys.exit(0)
 

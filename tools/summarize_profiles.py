@@ -85,6 +85,24 @@ for fdir, wdir in (('pmc_fetch', 'pmc_write'), ('pmc_fetch_conv', 'pmc_write_con
         w_kib = sum(wr.get(k, [0.0])) / max(1, len(wr.get(k, [0.0])))
         traffic[k] = {'fetch_bytes_raw': f_kib * 1024, 'fetch_bytes_corrected_x2': 2 * f_kib * 1024, 'write_bytes': w_kib * 1024,
                       'hbm_bytes_per_launch': (2 * f_kib + w_kib) * 1024, 'launches_averaged': len(fe[k])}
+# round 4: HBM bytes of the critic's whole Conv2D stack per critic step (bench.py's `roofline.traffic`): the per-launch bytes of the
+# stack's kernels at [64,400,65,4] (tools/conv2d_mfma_probe.py) x their launches per critic step, a launch over the stacked 2B batch
+# counted twice; the two 1 -> 4 / 4 -> 1 stencil layers at their algorithmic bytes (no counter pass of their own)
+def _k(prefix):
+    return next((traffic[k]['hbm_bytes_per_launch'] for k in traffic if k.startswith(prefix)), None)
+parts = {'forward 4->4 (7 layers: real + fake stacked 2B, x^ at B)': (_k('c2m::fwd_ws_kernel<1, false'), 7 * (2 + 1)),
+         'backward-data of the gradient penalty (7 layers at B)': (_k('c2m::fwd_ws_kernel<0, true'), 7),
+         'fused dx + dW + dbias (7 layers at 2B)': (_k('c2m::bwd_ws_kernel<1'), 7 * 2),
+         'fused masked forward + dW of the second-order sweep (7 layers at B)': (_k('c2m::bwd_ws_kernel<2'), 7)}
+if all(v[0] is not None for v in parts.values()):
+    A1 = 64 * 400 * 65 * 4.0
+    stencil = (A1 + 4 * A1) * 3 + (2 * 4 * A1 + A1) * 2 + (4 * A1 + A1) + (2 * 4 * A1 + A1)      # 1 -> 4 layer: forward x 3B, dW (+ dx for x^) ...
+    tot = sum(v[0] * v[1] for v in parts.values()) + stencil
+    traffic['critic_conv2d_stack_per_critic_step'] = {
+        'hbm_bytes': tot, 'algorithmic_bytes': (149.0 * 4 + 3) * 64 * 400 * 65 * 4,
+        'parts': {k: {'hbm_bytes_per_launch_at_B64': v[0], 'units_of_B_per_critic_step': v[1]} for k, v in parts.items()},
+        'first_layer_1to4_and_its_backward_algorithmic': stencil,
+        'note': 'sum over the stack\'s kernels of (FETCH_SIZE x 2 + WRITE_SIZE per launch at B = 64) x (launches per critic step, a 2B launch counted twice)'}
 json.dump(traffic, open(outdir + '/%s_traffic.json' % tag, 'w'), indent=1, sort_keys=True)
 # the frequency-domain Conv1D's kernels (tools/conv1d_fft_probe.py), in a file of their own: the batched products share their template
 # names with the Dense layers' launches of other shapes.  Raw and x2-corrected fetch bytes both given (see the chain counters' note).
