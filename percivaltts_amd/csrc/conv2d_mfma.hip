@@ -964,8 +964,12 @@ __global__ __launch_bounds__(8 * 64, 1) void bwd_ws_kernel(
         f32x4 acc[KT][2];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) { acc[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        // transposed-read addresses of this lane inside a 4 rows x 16 columns block (wgrad_kernel): row li >> 2, bin li & 3
-        const int trow = 4 * lg + (li >> 2);
+        // transposed-read addresses of this lane inside a 4 rows x 16 columns block: bin li & 3 of the block's row li >> 2.  WHICH four
+        // time rows make up the block of lane group lg is free (the reduction index of both operands is permuted alike): the 32 lanes
+        // the LDS serves per cycle (lg = 0, 1, then 2, 3) take the EVEN rows 0, 2, .. 14, then the odd ones -- rows two apart are
+        // 312 dwords = 56 mod 64 banks apart, so their eight 8-bank windows tile the 64 banks; with consecutive rows (156 dwords = 28
+        // mod 64) the windows of rows r and r + 7 overlap by half: SQ_LDS_BANK_CONFLICT 30 % of the LDS cycles (profiles/r04_*)
+        const int trow = 2 * (4 * (lg & 1) + (li >> 2)) + (lg >> 1);
         const int aoff = (KIND == 1 ? NPL * SP::PS : lo * SP::RS) + trow * SP::RS;          // a: Q (16 rows) / P's own rows
         constexpr int APS = KIND == 1 ? SQ::PS : SP::PS;                                     // ... and its plane stride
         const int doff = (KIND == 1 ? 0 : NPL * SP::PS) + trow * SP::RS;                     // dy with its halo: P / Q

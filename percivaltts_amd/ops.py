@@ -1367,6 +1367,12 @@ class _C1FFT(object):
     enabled = default
     KWS = (3, 5, 7, 9, 11, 21)      # instantiations of conv1d_wdft_planes_kernel<KW> / conv1d_freq_wgrad_inverse_kernel<KW>
     wgrad_enabled = os.environ.get('PTTS_CONV1D_FFT_WGRAD', '1') == '1'
+    # BASELINE configs[2] (ops.bf16_products): the frequency-domain path with its BIG products -- the per-frequency product of the forward
+    # and the per-frequency correlation of the weight gradient, 80 % of its flops -- as ONE bf16 product of the operands' roundings
+    # (X^ and H^ / DY^ rounded once, fp32 accumulation), the small transforms (DFT, inverse DFT) still six products: the same single
+    # operand rounding per product as the time-domain one-product kernels it replaces, a sixth of the matrix work.  PTTS_CONV1D_FFT_BF16=0
+    # keeps the time-domain kernels in that mode.
+    bf16_one_product = os.environ.get('PTTS_CONV1D_FFT_BF16', '1') == '1'
     seg_target = int(os.environ.get('PTTS_CONV1D_FFT_SEG', '100'))      # preferred segment length (0: one segment per utterance)
     consts = {}         # (T, KW, device, stream) -> dict of the geometry and the twiddle operands
     x_src = None; x_key = None; x_hat = None
@@ -1521,7 +1527,7 @@ class _C1FFT(object):
         npw = lib.ptts_dense_planes_bytes(N, 2 * Kh)
         Yh = cls._scratch('Yh', NB * 2 * Z * N * 4, a.device)                                        # [NB][2][Z][N] fp32
         call('ptts_dense_bf16x6_batched', ptr(Ap), 2 * Z * 2 * Kh, ptr(wpl), npw, None, ptr(Yh), 2 * Z * N, NB, 2 * Z, N, 2 * Kh,
-             2 * Kh, N, 3, stream(), tag=('freq', NB, 2 * Z, N, 2 * Kh))
+             2 * Kh, N, 1 if _Flags.bf16_products else 3, stream(), tag=('freq', NB, 2 * Z, N, 2 * Kh))
         npy = lib.ptts_dense_planes_bytes(N, c['R'])
         ypl = cls._scratch('ypl', Z * npy, a.device)
         call('ptts_split3_dense_weight_strided', ptr(Yh), N, ptr(ypl), npy, Z, Z * N, c['R'], N, 0, stream(), tag=('y', Z))
@@ -1561,7 +1567,7 @@ class _C1FFT(object):
         call('ptts_transpose_batched', ptr(DYh), ptr(DYt), NB, 2 * Z, N, stream())
         Gt = cls._scratch('Gt', NB * N * 2 * Kh * 4, dev)                                          # [NB][N][2 Kh] fp32 = (Gr | -Gi)^T
         call('ptts_dense_bf16x6_batched', ptr(DYt), N * 2 * Z, ptr(cls.xw_planes), npx, None, ptr(Gt), N * 2 * Kh, NB, N, 2 * Kh, 2 * Z,
-             2 * Z, 2 * Kh, 3, stream(), tag=('corr', NB, N, 2 * Kh, 2 * Z))
+             2 * Z, 2 * Kh, 1 if _Flags.bf16_products else 3, stream(), tag=('corr', NB, N, 2 * Kh, 2 * Z))
         dw = torch.empty((KW, Cin, N), dtype=torch.float32, device=dev)
         if KW in cls.KWS:
             ws = _workspace(lib.ptts_conv1d_freq_wgrad_inverse_workspace_bytes(KW, Cin, N), dev)
@@ -1608,7 +1614,7 @@ class Conv1dFn(torch.autograd.Function):
             saved, padded, y = pre
         else:
             y = torch.empty((B, T, N), dtype=torch.float32, device=a.device)
-            if _C1FFT.enabled and _C1Split.enabled and not _Flags.bf16_products and _C1FFT.eligible(a, w):
+            if _C1FFT.enabled and _C1Split.enabled and (not _Flags.bf16_products or _C1FFT.bf16_one_product) and _C1FFT.eligible(a, w):
                 _C1FFT.forward(a, w, b, y)
                 saved, padded = a, False
             elif _C1Split.enabled and not _Flags.deterministic and _C1Split.eligible(a, w):
@@ -1642,7 +1648,7 @@ class Conv1dFn(torch.autograd.Function):
         def padded_frames():
             return saved if ctx.padded else _pad_time(saved, pl, KW - 1 - pl)
 
-        if want_w and _C1FFT.enabled and _C1FFT.wgrad_enabled and _C1Split.enabled and not _Flags.bf16_products and dy.is_cuda and \
+        if want_w and _C1FFT.enabled and _C1FFT.wgrad_enabled and _C1Split.enabled and (not _Flags.bf16_products or _C1FFT.bf16_one_product) and dy.is_cuda and \
                 _C1FFT.has_x(ctx.x_src, KW) and not ctx.padded and (B * (T // _C1FFT.segment(T, KW))) % 2 == 0:      # (2 B NS is a reduction length: a multiple of 4)
             # in the frequency domain, from the transform of the input the forward left behind (ops._C1FFT.wgrad)
             dw = _C1FFT.wgrad(ctx.x_src, dy, KW)

@@ -772,6 +772,52 @@ def test_conv1d_bf16_products(ops, case):
     close(bd.grad, dy.double().sum((0, 1)), rtol=2e-4, atol=3e-4, what='db')
 
 
+def test_conv1d_frequency_domain_bf16_products(ops):
+    """BASELINE configs[2] with the context Conv1D in the frequency domain (round 4): ops.bf16_products(True) and >= 4096 frames select
+    ops._C1FFT with its two big products -- the per-frequency product X^_f H^_f of the forward, the per-frequency correlation of the
+    weight gradient -- as ONE bf16 product of the operands' roundings (fp32 accumulation); DFT and inverse DFT stay six-product.
+    Bound: the bf16 budget of one rounding per operand of a product (2^-8 relative each): relative L2 <= 1e-2 and no entry off by more
+    than 2^-5 of the mean magnitude against the exact fp64 convolution -- what the time-domain one-product kernels are held to -- and
+    the asserted kernels ran with planes_count = 1."""
+    g = gen(35)
+    B, T, Cin, N, KW = 12, 400, 601, 256, 21
+    x = (torch.rand(B, T, Cin, generator=g) * 2 - 1).float()
+    w = (torch.randn(KW, Cin, N, generator=g) * (1.0 / (KW * Cin) ** 0.5)).float()
+    b = torch.randn(N, generator=g).float()
+    dy = torch.randn(B, T, N, generator=g).float()
+    wr = w.double().requires_grad_(True)
+    yr = O.conv1d_ntc(x.double(), wr, b.double())
+    yr.backward(dy.double())
+    ops.bf16_products(True)
+    try:
+        wd, bd = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+        with ops._hip.KernelTimer() as kt:
+            y = ops.conv1d(x.cuda(), wd, bd)
+            y.backward(dy.cuda())
+        torch.cuda.synchronize()
+        # the same layer through the time-domain one-product kernels: the error budget must be of the same class
+        fft_saved = ops._C1FFT.bf16_one_product
+        ops._C1FFT.bf16_one_product = False
+        ops.clear_caches()
+        wt = w.cuda().requires_grad_(True)
+        yt = ops.conv1d(x.cuda(), wt, b.cuda())
+        yt.backward(dy.cuda())
+        torch.cuda.synchronize()
+        ops._C1FFT.bf16_one_product = fft_saved
+    finally:
+        ops.bf16_products(False)
+    tags = [(r[0], r[1]) for r in kt.records]
+    assert any(n == 'ptts_dense_bf16x6_batched' and t and t[0] == 'freq' for n, t in tags) and any(n == 'ptts_dense_bf16x6_batched' and t and t[0] == 'corr' for n, t in tags), tags
+    assert not any(n in ('ptts_conv1d_bf16x6', 'ptts_conv1d_wgrad_bf16x6') for n, _ in tags)
+    def rl2(a, ref): return float((a.detach().double().cpu() - ref).norm() / ref.norm())
+    e_f, e_t = rl2(y, yr.detach()), rl2(yt, yr.detach())
+    g_f, g_t = rl2(wd.grad, wr.grad), rl2(wt.grad, wr.grad)
+    assert e_f <= 1e-2 and g_f <= 1e-2, (e_f, g_f)
+    assert e_f <= 2.0 * e_t + 1e-4 and g_f <= 2.0 * g_t + 1e-4, 'frequency-domain one-product error {:.2e} / {:.2e} against the time-domain kernels\' {:.2e} / {:.2e}'.format(e_f, g_f, e_t, g_t)
+    assert float((y.detach().double().cpu() - yr.detach()).abs().max()) < 2.0 ** -5 * float(yr.abs().mean())
+    close(bd.grad, dy.double().sum((0, 1)), rtol=2e-4, atol=3e-4, what='db')
+
+
 def test_dense_bf16_products(ops):
     """ops.bf16_products(True): Dense forward (pending LeakyReLU applied, then ONE rounding to bf16), backward-data with the
     output mask, and the two-stage weight gradient as single products of bf16 roundings (csrc/dense.hip with one plane) against
