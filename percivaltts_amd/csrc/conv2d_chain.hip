@@ -275,6 +275,9 @@ __device__ __forceinline__ int pair_of(int j, int c, int wave, int ng2, int rot)
     else if (wave >= KT) gp = (wave - KT) + j * (NW - KT);
     else {
         if (j) return -1;
+        // (round 4: shifting work from the convolution-only waves to these -- five pairs on waves KT.., four going round here, as the
+        // per-wave stamps of tools/chain_probe.py suggested -- made the step LONGER, 329 -> 339 us backward, 336 -> 371 second order at
+        // 2B: the waves are not independent, the step is bound by what the CU issues in all, not by its longest wave)
         const int k = (c + rot + wave) % KT;
         gp = k < 3 ? 2 * (NW - KT) + k : -1;
     }
@@ -428,7 +431,10 @@ __device__ __forceinline__ void dw_step(f32x4& c0, f32x4& c1, const u16* at, con
 // the step loop itself need not be unrolled (unrolled eight-fold it drove the kernel past its register budget)
 __device__ __forceinline__ void acc_add(f32x4 (&acc)[LMAX][2], int s, f32x4 c0, f32x4 c1) {
     switch (s) {
-#define C2C_CASE(S) case S: acc[S][0] += c0; acc[S][1] += c1; break;
+// (the empty asm pins the two registers inside their own case: without it the optimiser sinks the eight identical additions out of
+// the switch into ONE addition through a run-time index -- half of the accumulators then live in scratch memory, one 16-byte scratch
+// load + store per step and lane: 144 bytes of scratch per lane, 88-141 MB of scratch write-backs per launch, profiles/r03_*)
+#define C2C_CASE(S) case S: acc[S][0] += c0; acc[S][1] += c1; asm volatile("" : "+v"(acc[S][0]), "+v"(acc[S][1])); break;
         C2C_CASE(0) C2C_CASE(1) C2C_CASE(2) C2C_CASE(3) C2C_CASE(4) C2C_CASE(5) C2C_CASE(6) C2C_CASE(7)
 #undef C2C_CASE
         default: break;
