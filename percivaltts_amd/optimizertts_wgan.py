@@ -559,7 +559,21 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         eager = (lambda: self.critic_step(X, Y)) if kind == 'critic' else (lambda: self.generator_step(X, Y))
         graph = lambda: self._graphed(kind, X, Y)
         for _ in range(2): eager()          # both forms warm (allocator, weight-keyed caches, the capture itself) before either is timed
-        graph()
+        ok = 1.0
+        try:
+            graph()
+        except Exception as e:              # a capture this runtime / collective backend refuses: the step stays eager, and the line says why
+            ok = 0.0
+            self._graph_tuning[key] = {'graph': False, 'capture_error': repr(e)[:300]}
+            torch.cuda.synchronize()
+        if self.world > 1:                  # every rank must take the same branch below (the timed runs contain collectives)
+            ok = 1.0 if parallel.max_over_ranks(1.0 - ok, self.device) == 0.0 else 0.0
+        if ok == 0.0:
+            self._graphs = {k: v for k, v in self._graphs.items() if k[0] != kind}
+            self._state_restore(snap)
+            self._graph_choice[key] = False
+            self._graph_tuning.setdefault(key, {'graph': False, 'capture_error': 'on another rank'})
+            return False
         t_eager, t_graph = [], []
         for _ in range(2):                  # alternating: clocks and caches drift over the first seconds of a process
             t_eager.append(timed(eager)); t_graph.append(timed(graph))
@@ -621,10 +635,12 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
             ops.clear_caches()         # every derived operand (bf16 planes, Toeplitz tables) must be rebuilt inside the graph
-            with torch.cuda.graph(g, stream=side):      # the stream of the warm-up: stream-keyed operand caches (weight planes) keep their entries and are refreshed grouped
-                out = fn()
-            ops.clear_caches()         # ... and the graph's private copies are not for eager code
-            self.cfg.train_wgan_parallel_streams, self._model.kerasmodel.parallel_branches = saved_streams
+            try:
+                with torch.cuda.graph(g, stream=side):      # the stream of the warm-up: stream-keyed operand caches (weight planes) keep their entries and are refreshed grouped
+                    out = fn()
+            finally:
+                ops.clear_caches()         # ... and the graph's private copies are not for eager code
+                self.cfg.train_wgan_parallel_streams, self._model.kerasmodel.parallel_branches = saved_streams
             ent = (g, sX, sY, sA, out, sF)
             self._graphs[key] = ent
             self._state_restore(snap)
