@@ -174,7 +174,9 @@ def roofline_leg(opt, X, Y, args):
         recs.append(kt.durations_ms())
     # average per call position
     n = len(recs[0])
-    avg = [(recs[0][i][0], recs[0][i][1], sum(r[i][2] for r in recs) / reps) for i in range(n)]
+    # (median over the repetitions: the first launch of a kernel variant pays its code object's load -- tens of milliseconds, once)
+    med = lambda xs: sorted(xs)[len(xs) // 2]
+    avg = [(recs[0][i][0], recs[0][i][1], med([r[i][2] for r in recs])) for i in range(n)]
     M, N, K = B * T, opt.cfg.arch_hiddenwidth, opt.cfg.arch_ctx_winlen * X.shape[2]
     conv1d_fwd = [d for (nm, tag, d) in avg if nm == 'ptts_gemm' and tag == (M, N, K, 0, 0, 1)]
     conv1d_bww = [d for (nm, tag, d) in avg if (nm == 'ptts_gemm' and tag == (K, N, M, 1, 0, 1)) or nm in ('ptts_conv1d_wgrad_t', 'ptts_conv1d_wgrad_bf16x6')]
@@ -239,7 +241,7 @@ def roofline_leg(opt, X, Y, args):
                 total.backward()
         crit_recs.append(kt.durations_ms())
     # (summed per repetition: the call list of the first one may hold a refresh of cached operands the others do not)
-    t_conv2d = sum(sum(d for (nm, _, d) in r if nm.startswith('ptts_conv2d')) for r in crit_recs) / reps * 1e-3
+    t_conv2d = med([sum(d for (nm, _, d) in r if nm.startswith('ptts_conv2d')) for r in crit_recs]) * 1e-3
     n_conv2d = sum(1 for (nm, _, _) in crit_recs[-1] if nm.startswith('ptts_conv2d'))
     bf16_stack = getattr(opt.cfg, 'arch_critic_bf16', False)
     # (149 C + 3) B T F s bytes per critic step, s = 4 (configs[1], fp32) or 2 (configs[2], every map bf16)
@@ -271,7 +273,7 @@ def roofline_leg(opt, X, Y, args):
             for tag, d in c2m:
                 Bq, Tq, Fq, _, _, mode, has_om, planes = tag
                 by += Bq * Tq * Fq * 4 * 4.0 * (2 + (1 if (mode == 2 or has_om) else 0))
-            tt = sum(sum(d for (nm, _, d) in r if nm == 'ptts_conv2d_mfma_fwd') for r in crit_recs) / reps * 1e-3
+            tt = med([sum(d for (nm, _, d) in r if nm == 'ptts_conv2d_mfma_fwd') for r in crit_recs]) * 1e-3
             out['roofline']['dominant_kernel'] = {
                 'kernel': 'c2m::fwd_ws_kernel (4 -> 4 Conv2D 5x5 layer on the matrix cores, wave-specialised: forward, masked forward, backward-data; fp32 maps, '
                           'fp32 arithmetic as 6 bf16 products), {} launches per critic step'.format(len(c2m)),
