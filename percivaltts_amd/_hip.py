@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libpercival_hip.so')
+LIB_PATH = os.environ.get('PTTS_LIB_PATH') or os.path.join(_HERE, 'lib', 'libpercival_hip.so')      # (PTTS_LIB_PATH: an A/B build of the library, tools/ab_define.sh)
 
 c_f = ctypes.c_float
 c_i = ctypes.c_int

@@ -69,6 +69,13 @@ constexpr int DBG_FOUR_WAVES = 1 << 16;      // host side only: launch the four-
 #ifndef C2M_WS_FLAGS
 #define C2M_WS_FLAGS 1
 #endif
+#ifndef C2M_PIN_WF
+// 1: the wave-specialised kernels' table fragments pinned in registers by an empty asm.  The table is `const __restrict__`, and the
+// compiler RE-LOADS the lane's fifteen fragments from global memory (L2) in every pass instead of keeping 60 registers -- which is the
+// faster program: pinned, the same box measured forward 22.6 -> 25.0 us, backward data 23.6 -> 29.8, fused backward 42.5 -> 45.1
+// (tools/ab_c2m.sh C2M_PIN_WF=0 against the pinned build, three alternating pairs).  Default 0.
+#define C2M_PIN_WF 0
+#endif
 static int g_dbg = 0;
 static unsigned long long* g_dbg_buf = nullptr;
 __device__ __forceinline__ void stamp(unsigned long long* buf, int dbg, int slot) {
@@ -640,6 +647,7 @@ __global__ __launch_bounds__((NMW + 4) * 64, 1) void fwd_ws_kernel(
             for (int q = 0; q < NPL; ++q) {
                 const u16* wp = wa + (kt * NPL + q) * TKP;
                 wf[kt][q] = cat(*reinterpret_cast<const bf16x4*>(wp), *reinterpret_cast<const bf16x4*>(wp + 4));
+                if (C2M_PIN_WF) asm volatile("" : "+v"(wf[kt][q]));      // (C2M_PIN_WF, off: see its definition)
             }
         if (bias) bv = *reinterpret_cast<const f32x4*>(bias);
     }
@@ -665,8 +673,14 @@ __global__ __launch_bounds__((NMW + 4) * 64, 1) void fwd_ws_kernel(
         }
         if (r == bound && lane == 0) raise_status(status, STATUS_SLOT_C2M, STATUS_C2M_HANDOFF);
     };
+    // The counters order LDS traffic only: a staging wave's commit (ds_write) before `ready`, a multiplying wave's fragment reads before
+    // `done`.  The LDS executes a wave's operations in order and lgkmcnt(0) says they have completed, so the count goes up with a
+    // RELAXED add behind an explicit s_waitcnt lgkmcnt(0).  (A release add made the multiplying waves drain their GLOBAL stores as
+    // well -- vmcnt(0), a write acknowledged by the L2, about a microsecond under load -- once per piece: 13.6 of the 63 us of the fused
+    // backward kernel at 2B, tools/c2m_fused_probe2.py "no stores".)
     auto signal = [&](int idx) {
-        if (lane == 0) __hip_atomic_fetch_add(flags + idx, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(flags + idx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     stamp(dbg_buf, dbg, 1);
     __syncthreads();
@@ -905,8 +919,14 @@ __global__ __launch_bounds__(8 * 64, 1) void bwd_ws_kernel(
         }
         if (r == bound && lane == 0) raise_status(status, STATUS_SLOT_C2M, STATUS_C2M_HANDOFF);
     };
+    // The counters order LDS traffic only: a staging wave's commit (ds_write) before `ready`, a multiplying wave's fragment reads before
+    // `done`.  The LDS executes a wave's operations in order and lgkmcnt(0) says they have completed, so the count goes up with a
+    // RELAXED add behind an explicit s_waitcnt lgkmcnt(0).  (A release add made the multiplying waves drain their GLOBAL stores as
+    // well -- vmcnt(0), a write acknowledged by the L2, about a microsecond under load -- once per piece: 13.6 of the 63 us of the fused
+    // backward kernel at 2B, tools/c2m_fused_probe2.py "no stores".)
     auto signal = [&](int idx) {
-        if (lane == 0) __hip_atomic_fetch_add(flags + idx, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(flags + idx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     __syncthreads();
     float* red = reinterpret_cast<float*>(lds);          // the end-of-launch reduction scratch lies over the (then dead) planes
@@ -934,16 +954,17 @@ __global__ __launch_bounds__(8 * 64, 1) void bwd_ws_kernel(
             pref_commit<SP, MODE_P, NPL>(pp, slp, buf, p.t0 - lo, 4 * p.g_base - 2, s.T, s.F, nullptr, nullptr, alpha, lo, 2 + 4 * p.ng, KIND == 1 ? &bsum : nullptr);
             pref_commit<SQ, MODE_Q, NPL>(pq, slq, buf + NPL * SP::PS, KIND == 1 ? p.t0 : p.t0 - lo, 4 * p.g_base - 2, s.T, s.F, nullptr, nullptr, alpha, 0, 0, nullptr);
         };
+        const bool stage = !(dbg & DBG_NOSTAGE);              // (measurement hooks of tools/c2m_fused_probe2.py: garbage results)
         int item = -1, it = 0;
         Work w = next_work(s, sc, wg, item, nitems);
-        if (w.ng > 0) load_piece(work_pos(s, w));
+        if (w.ng > 0 && stage) load_piece(work_pos(s, w));
         while (w.ng > 0) {
             const TilePos p = work_pos(s, w);
             wait_for(2 + (it & 1), NMW * (it >> 1));
-            commit_piece(p, lds + (it & 1) * BUF);
+            if (stage) commit_piece(p, lds + (it & 1) * BUF);
             signal(it & 1);
             w = next_work(s, sc, wg, item, nitems);
-            if (w.ng > 0) load_piece(work_pos(s, w));
+            if (w.ng > 0 && stage) load_piece(work_pos(s, w));
             ++it;
         }
         __syncthreads();
@@ -959,6 +980,8 @@ __global__ __launch_bounds__(8 * 64, 1) void bwd_ws_kernel(
                 for (int q = 0; q < NPL; ++q) {
                     const u16* wp = wa + (kt * NPL + q) * TKP;
                     wf[kt][q] = cat(*reinterpret_cast<const bf16x4*>(wp), *reinterpret_cast<const bf16x4*>(wp + 4));
+                    // (C2M_PIN_WF, off: see its definition)
+                    if (C2M_PIN_WF) asm volatile("" : "+v"(wf[kt][q]));
                 }
         }
         f32x4 acc[KT][2];
@@ -981,14 +1004,14 @@ __global__ __launch_bounds__(8 * 64, 1) void bwd_ws_kernel(
             const u16* pcur = lds + (it & 1) * BUF;
             wait_for(it & 1, 4 * ((it >> 1) + 1));
             // ---- the convolution over P: dx (KIND 1, masked by the layer input) / cot_dy (KIND 2)
-            fwd_piece<SP, DIL, OUTMASK, PMASK, NPL, true, NMW, 0>(pcur, nullptr, wf, cur, s, wave, lane, it, bv0, qsrc, y, false, alpha, true, false);
+            fwd_piece<SP, DIL, OUTMASK, PMASK, NPL, true, NMW, 0>(pcur, nullptr, wf, cur, s, wave, lane, it, bv0, qsrc, y, false, alpha, !(dbg & DBG_NOSTORE), (dbg & (DBG_NOMFMA | 16)) != 0);
             // ---- the weight gradient: K step = 16 rows x 2 adjacent bin groups, both operands read transposed
             const u16* abase0 = pcur + aoff + bin_off(2 + (li & 3));
             const u16* abase1 = pcur + aoff + bin_off(6 + (li & 3));
             const u16* dbase0 = pcur + doff + bin_off(0 + (li & 3));
             const u16* dbase1 = pcur + doff + bin_off(4 + (li & 3));
             const u16* dbase2 = pcur + doff + bin_off(8 + (li & 3));
-            const int ng2 = (cur.ng + 1) >> 1;
+            const int ng2 = (dbg & (DBG_NOMFMA | 32)) ? 0 : (cur.ng + 1) >> 1;
             for (int gp = (wave + it) & 3; gp < ng2; gp += 4) {
                 const bool second = 2 * gp + 1 < cur.ng;         // wave-uniform
                 bf16x8 af[NPL];
@@ -998,20 +1021,26 @@ __global__ __launch_bounds__(8 * 64, 1) void bwd_ws_kernel(
                     if (!second) h1 = __builtin_bit_cast(bf16x4, (u32x2){0u, 0u});
                     af[p] = cat(h0, h1);
                 }
-#pragma unroll
-                for (int kt = 0; kt < KT; ++kt) {
-                    bf16x4 d0[NPL], d1[NPL], d2[NPL];
+                // the dy fragments of kernel row kt + 1 are requested before the MFMAs of row kt (two register sets): a wave does not
+                // sit out an LDS round trip per kernel row -- it is the only multiplying wave of its SIMD
+                bf16x4 dq[2][3][NPL];
+                auto read_d = [&](int kt, bf16x4 (&d)[3][NPL]) {
 #pragma unroll
                     for (int p = 0; p < NPL; ++p) {
                         const int off = 32 * gp + p * SP::PS + (KT - 1 - kt) * DIL * SP::RS;
-                        d0[p] = tr_read(dbase0 + off);
-                        d1[p] = tr_read(dbase1 + off);
-                        d2[p] = tr_read(dbase2 + off);
+                        d[0][p] = tr_read(dbase0 + off);
+                        d[1][p] = tr_read(dbase1 + off);
+                        d[2][p] = tr_read(dbase2 + off);
                     }
+                };
+                read_d(0, dq[0]);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    if (kt + 1 < KT) read_d(kt + 1, dq[(kt + 1) & 1]);
 #define C2M_MM(PA_, PW_)                                                                                                 \
                     { constexpr int PA = PA_ < NPL ? PA_ : 0, PW = PW_ < NPL ? PW_ : 0;                                  \
-                    acc[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA], cat(d0[PW], d1[PW]), acc[kt][0], 0, 0, 0);   \
-                    acc[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA], cat(d1[PW], d2[PW]), acc[kt][1], 0, 0, 0); }
+                    acc[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA], cat(dq[kt & 1][0][PW], dq[kt & 1][1][PW]), acc[kt][0], 0, 0, 0);   \
+                    acc[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA], cat(dq[kt & 1][1][PW], dq[kt & 1][2][PW]), acc[kt][1], 0, 0, 0); }
                     C2M_PRODUCTS_NPL(NPL, C2M_MM);
 #undef C2M_MM
                 }
