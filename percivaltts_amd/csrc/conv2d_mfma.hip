@@ -69,6 +69,15 @@ constexpr int DBG_FOUR_WAVES = 1 << 16;      // host side only: launch the four-
 #ifndef C2M_WS_FLAGS
 #define C2M_WS_FLAGS 1
 #endif
+#ifndef C2M_BW_ROT
+#define C2M_BW_ROT 0       // fused backward kernel: offset of the wave that takes the odd weight-gradient pair against the one that takes the odd bin group
+#endif
+#ifndef C2M_BW_NMAX
+#define C2M_BW_NMAX 0      // fused backward kernel: bin groups per pass of its convolution (0: fwd_piece's default, 4 with mask values)
+#endif
+#ifndef C2M_BW_WREG
+#define C2M_BW_WREG 1      // fused backward kernel: the convolution's table fragments from global memory / registers (1) or from a copy in the LDS (0)
+#endif
 #ifndef C2M_PIN_WF
 // 1: the wave-specialised kernels' table fragments pinned in registers by an empty asm.  The table is `const __restrict__`, and the
 // compiler RE-LOADS the lane's fifteen fragments from global memory (L2) in every pass instead of keeping 60 registers -- which is the
@@ -886,11 +895,14 @@ __global__ __launch_bounds__(THREADS, DIL <= 2 ? 2 : 1) void wgrad_kernel(
 // piece's last pair may lie beyond the piece (odd number of groups): its half of the A fragment is zeroed by a wave-uniform select
 // (P carries the convolution's frequency halo there, which the weight gradient must not count).
 // ------------------------------------------------------------------------------------------------------------
-template <int KIND, int NPL>
-__global__ __launch_bounds__(8 * 64, 1) void bwd_ws_kernel(
+// SPLIT (round 4, second form): TWELVE waves -- 0..3 only convolve, 4..7 only run the weight-gradient products, 8..11 stage -- three per SIMD
+// (<= 168 registers each), so that every SIMD has one wave of each kind: a SIMD's single multiplying wave spends as long on its LDS reads as on
+// its MFMAs and nothing overlaps the two (tools/c2m_fused_probe2.py: 5 us per piece for 1.75 us of matrix work).
+template <int KIND, int NPL, bool SPLIT>
+__global__ __launch_bounds__((SPLIT ? 12 : 8) * 64, 1) void bwd_ws_kernel(
     const void* __restrict__ psrc, const void* __restrict__ qsrc, const void* __restrict__ mask_src, const u16* __restrict__ tab,
     void* __restrict__ y, float* __restrict__ partials, Shape s, Sched sc, float alpha, int dbg, unsigned* status) {
-    constexpr int DIL = 1, NMW = 4;
+    constexpr int DIL = 1, NMW = 4, NCW = SPLIT ? 8 : 4, NT = (NCW + 4) * 64;      // waves that share a piece's groups / pairs; consumer waves; threads
     typedef Stage<4 * (GPB + 1) + 4, 16 + (KT - 1) * DIL> SP;                              // the convolved tile, with its time halo
     typedef Stage<4 * (GPB + 1) + 4, KIND == 1 ? 16 : 16 + (KT - 1) * DIL> SQ;             // the other operand of the weight gradient
     static_assert(SP::RS == SQ::RS, "one row stride");
@@ -901,13 +913,17 @@ __global__ __launch_bounds__(8 * 64, 1) void bwd_ws_kernel(
     extern __shared__ __attribute__((aligned(16))) u16 lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool stager = wave8 >= NMW;
+    const bool stager = wave8 >= NCW;
     const int wave = wave8 & (NMW - 1);
     const int lo = (KT - 1) * DIL - s.pad_t;          // staged P row r <-> t = t0 - lo + r (pad_t = 2: symmetric halo of two rows)
     const int wg = blockIdx.x, nitems = sched_items(sc, wg);
 
     int* const flags = reinterpret_cast<int*>(lds + 2 * BUF);       // ready[2] | done[2]
+    u16* const wl = lds + 2 * BUF + 32;                             // (C2M_BW_WREG == 0: the operand table, behind the counters)
     if (tid == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0; }
+    if (!C2M_BW_WREG)
+        for (int i = tid; i < KT * NPL * TKP / 8; i += NT)
+            *reinterpret_cast<bf16x8*>(wl + (size_t)i * 8) = *reinterpret_cast<const bf16x8*>(tab + (size_t)i * 8);
     const bool force_timeout = (dbg & DBG_FORCE_TIMEOUT) != 0;
     auto wait_for = [&](int idx, int target) {
         const int bound = force_timeout ? 8 : (1 << 14);
@@ -921,9 +937,7 @@ __global__ __launch_bounds__(8 * 64, 1) void bwd_ws_kernel(
     };
     // The counters order LDS traffic only: a staging wave's commit (ds_write) before `ready`, a multiplying wave's fragment reads before
     // `done`.  The LDS executes a wave's operations in order and lgkmcnt(0) says they have completed, so the count goes up with a
-    // RELAXED add behind an explicit s_waitcnt lgkmcnt(0).  (A release add made the multiplying waves drain their GLOBAL stores as
-    // well -- vmcnt(0), a write acknowledged by the L2, about a microsecond under load -- once per piece: 13.6 of the 63 us of the fused
-    // backward kernel at 2B, tools/c2m_fused_probe2.py "no stores".)
+    // RELAXED add behind an explicit s_waitcnt lgkmcnt(0) (a release add also drains the wave's global stores: vmcnt(0)).
     auto signal = [&](int idx) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(flags + idx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -937,8 +951,8 @@ __global__ __launch_bounds__(8 * 64, 1) void bwd_ws_kernel(
     // b (piece p lives in buffer p & 1, use u = p >> 1: a multiplying wave starts it at ready == 4 (u + 1)), done[b] the multiplying
     // waves that have finished with it (a staging wave overwrites it at done == NMW u).
     if (stager) {
-        Slots<SP> slp; slp.init(tid - NMW * 64);
-        Slots<SQ> slq; slq.init(tid - NMW * 64);
+        Slots<SP> slp; slp.init(tid - NCW * 64);
+        Slots<SQ> slq; slq.init(tid - NCW * 64);
         Pref<SP::NB, PMASK> pp;
         Pref<SQ::NB, false> pq;
         f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
@@ -960,7 +974,7 @@ __global__ __launch_bounds__(8 * 64, 1) void bwd_ws_kernel(
         if (w.ng > 0 && stage) load_piece(work_pos(s, w));
         while (w.ng > 0) {
             const TilePos p = work_pos(s, w);
-            wait_for(2 + (it & 1), NMW * (it >> 1));
+            wait_for(2 + (it & 1), NCW * (it >> 1));
             if (stage) commit_piece(p, lds + (it & 1) * BUF);
             signal(it & 1);
             w = next_work(s, sc, wg, item, nitems);
@@ -968,51 +982,59 @@ __global__ __launch_bounds__(8 * 64, 1) void bwd_ws_kernel(
             ++it;
         }
         __syncthreads();
-        *reinterpret_cast<f32x4*>(bs + (tid - NMW * 64) * 4) = bsum;
+        *reinterpret_cast<f32x4*>(bs + (tid - NCW * 64) * 4) = bsum;
     } else {
         const int li = lane & 15, lg = lane >> 4;
-        bf16x8 wf[KT][NPL];
-        {
+        const bool do_conv = !SPLIT || wave8 < NMW, do_wg = !SPLIT || wave8 >= NMW;
+        // ---- the convolution over P: dx (KIND 1, masked by the layer input) / cot_dy (KIND 2)
+        auto conv_role = [&](auto&& also) {
+            bf16x8 wf[KT][NPL];
             const u16* wa = tab + (li & 3) * TROW + (2 * lg - (li >> 2) + 3) * C;
+            if (C2M_BW_WREG) {
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
+                for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-                for (int q = 0; q < NPL; ++q) {
-                    const u16* wp = wa + (kt * NPL + q) * TKP;
-                    wf[kt][q] = cat(*reinterpret_cast<const bf16x4*>(wp), *reinterpret_cast<const bf16x4*>(wp + 4));
-                    // (C2M_PIN_WF, off: see its definition)
-                    if (C2M_PIN_WF) asm volatile("" : "+v"(wf[kt][q]));
-                }
-        }
+                    for (int q = 0; q < NPL; ++q) {
+                        const u16* wp = wa + (kt * NPL + q) * TKP;
+                        wf[kt][q] = cat(*reinterpret_cast<const bf16x4*>(wp), *reinterpret_cast<const bf16x4*>(wp + 4));
+                        if (C2M_PIN_WF) asm volatile("" : "+v"(wf[kt][q]));      // (off: see its definition)
+                    }
+            }
+            const f32x4 bv0 = {0.f, 0.f, 0.f, 0.f};
+            int item = -1, it = 0;
+            Work w = next_work(s, sc, wg, item, nitems);
+            while (w.ng > 0) {
+                const TilePos cur = work_pos(s, w);
+                const u16* pcur = lds + (it & 1) * BUF;
+                wait_for(it & 1, 4 * ((it >> 1) + 1));
+                fwd_piece<SP, DIL, OUTMASK, PMASK, NPL, C2M_BW_WREG != 0, NMW, C2M_BW_NMAX>(pcur, wl, wf, cur, s, wave, lane, it, bv0, qsrc, y, false, alpha, !(dbg & DBG_NOSTORE), (dbg & (DBG_NOMFMA | 16)) != 0);
+                also(cur, pcur, it);
+                signal(2 + (it & 1));
+                w = next_work(s, sc, wg, item, nitems);
+                ++it;
+            }
+        };
+        // ---- the weight gradient: K step = 16 rows x 2 adjacent bin groups, both operands read transposed
         f32x4 acc[KT][2];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) { acc[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         // transposed-read addresses of this lane inside a 4 rows x 16 columns block: bin li & 3 of the block's row li >> 2.  WHICH four
         // time rows make up the block of lane group lg is free (the reduction index of both operands is permuted alike): the 32 lanes
-        // the LDS serves per cycle (lg = 0, 1, then 2, 3) take the EVEN rows 0, 2, .. 14, then the odd ones -- rows two apart are
-        // 312 dwords = 56 mod 64 banks apart, so their eight 8-bank windows tile the 64 banks; with consecutive rows (156 dwords = 28
-        // mod 64) the windows of rows r and r + 7 overlap by half: SQ_LDS_BANK_CONFLICT 30 % of the LDS cycles (profiles/r04_*)
+        // the LDS serves per cycle (lg = 0, 1, then 2, 3) take the EVEN rows 0, 2, .. 14, then the odd ones -- the a-fragments' 8-bank
+        // windows of rows two apart (312 dwords = 56 mod 64 banks) tile the 64 banks.  (The dy-fragments' windows are split in two by
+        // the forward pass's unit swizzle and stay two-way conflicted either way: SQ_LDS_BANK_CONFLICT 30 -> 28 % of the LDS cycles.)
         const int trow = 2 * (4 * (lg & 1) + (li >> 2)) + (lg >> 1);
         const int aoff = (KIND == 1 ? NPL * SP::PS : lo * SP::RS) + trow * SP::RS;          // a: Q (16 rows) / P's own rows
         constexpr int APS = KIND == 1 ? SQ::PS : SP::PS;                                     // ... and its plane stride
         const int doff = (KIND == 1 ? 0 : NPL * SP::PS) + trow * SP::RS;                     // dy with its halo: P / Q
-        const f32x4 bv0 = {0.f, 0.f, 0.f, 0.f};
-        int item = -1, it = 0;
-        Work w = next_work(s, sc, wg, item, nitems);
-        while (w.ng > 0) {
-            const TilePos cur = work_pos(s, w);
-            const u16* pcur = lds + (it & 1) * BUF;
-            wait_for(it & 1, 4 * ((it >> 1) + 1));
-            // ---- the convolution over P: dx (KIND 1, masked by the layer input) / cot_dy (KIND 2)
-            fwd_piece<SP, DIL, OUTMASK, PMASK, NPL, true, NMW, 0>(pcur, nullptr, wf, cur, s, wave, lane, it, bv0, qsrc, y, false, alpha, !(dbg & DBG_NOSTORE), (dbg & (DBG_NOMFMA | 16)) != 0);
-            // ---- the weight gradient: K step = 16 rows x 2 adjacent bin groups, both operands read transposed
+        auto wgrad_piece = [&](const TilePos& cur, const u16* pcur, int it) {
             const u16* abase0 = pcur + aoff + bin_off(2 + (li & 3));
             const u16* abase1 = pcur + aoff + bin_off(6 + (li & 3));
             const u16* dbase0 = pcur + doff + bin_off(0 + (li & 3));
             const u16* dbase1 = pcur + doff + bin_off(4 + (li & 3));
             const u16* dbase2 = pcur + doff + bin_off(8 + (li & 3));
             const int ng2 = (dbg & (DBG_NOMFMA | 32)) ? 0 : (cur.ng + 1) >> 1;
-            for (int gp = (wave + it) & 3; gp < ng2; gp += 4) {
+            for (int gp = (wave + it + C2M_BW_ROT) & 3; gp < ng2; gp += 4) {
                 const bool second = 2 * gp + 1 < cur.ng;         // wave-uniform
                 bf16x8 af[NPL];
 #pragma unroll
@@ -1021,8 +1043,7 @@ __global__ __launch_bounds__(8 * 64, 1) void bwd_ws_kernel(
                     if (!second) h1 = __builtin_bit_cast(bf16x4, (u32x2){0u, 0u});
                     af[p] = cat(h0, h1);
                 }
-                // the dy fragments of kernel row kt + 1 are requested before the MFMAs of row kt (two register sets): a wave does not
-                // sit out an LDS round trip per kernel row -- it is the only multiplying wave of its SIMD
+                // the dy fragments of kernel row kt + 1 are requested before the MFMAs of row kt (two register sets)
                 bf16x4 dq[2][3][NPL];
                 auto read_d = [&](int kt, bf16x4 (&d)[3][NPL]) {
 #pragma unroll
@@ -1045,22 +1066,38 @@ __global__ __launch_bounds__(8 * 64, 1) void bwd_ws_kernel(
 #undef C2M_MM
                 }
             }
-            signal(2 + (it & 1));
-            w = next_work(s, sc, wg, item, nitems);
-            ++it;
+        };
+        if (!SPLIT) {
+            conv_role(wgrad_piece);                        // one wave does both, piece by piece
+        } else if (do_conv) {
+            conv_role([](const TilePos&, const u16*, int) {});
+        } else {
+            int item = -1, it = 0;
+            Work w = next_work(s, sc, wg, item, nitems);
+            while (w.ng > 0) {
+                const TilePos cur = work_pos(s, w);
+                const u16* pcur = lds + (it & 1) * BUF;
+                wait_for(it & 1, 4 * ((it >> 1) + 1));
+                wgrad_piece(cur, pcur, it);
+                signal(2 + (it & 1));
+                w = next_work(s, sc, wg, item, nitems);
+                ++it;
+            }
         }
         __syncthreads();
         // ---- one reduction per workgroup, fixed order (wgrad_kernel's): red[wave][kt][hb][r][lane]
+        if (do_wg) {
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
+            for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-            for (int hb = 0; hb < 2; ++hb)
+                for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[(((wave * KT + kt) * 2 + hb) * 4 + r) * 64 + lane] = acc[kt][hb][r];
+                    for (int r = 0; r < 4; ++r) red[(((wave * KT + kt) * 2 + hb) * 4 + r) * 64 + lane] = acc[kt][hb][r];
+        }
     }
     __syncthreads();
     float* out = partials + (size_t)blockIdx.x * NPART;
-    for (int i = tid; i < KT * KF * 16; i += 8 * 64) {
+    for (int i = tid; i < KT * KF * 16; i += NT) {
         const int co = i & 3, ci = (i >> 2) & 3, kf = (i >> 4) % KF, kt = (i >> 4) / KF;
         float sum = 0.f;
 #pragma unroll
@@ -1365,6 +1402,13 @@ extern "C" int ptts_conv2d_mfma_wgrad_partials(const void* dy, const void* x, co
     return check_launch("conv2d_mfma_wgrad");
 }
 
+// the fused backward kernel with its multiplying waves split by role (twelve waves: PTTS_C2M_BW_SPLIT=1) or not (eight waves)
+static bool bwd_split() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PTTS_C2M_BW_SPLIT"); v = e ? atoi(e) : 0; }
+    return v != 0;
+}
+
 extern "C" size_t ptts_conv2d_mfma_bwd_fused_workspace_bytes(int B, int T) {
     (void)B; (void)T;
     return 4096 + (size_t)NCU * NPART * sizeof(float);
@@ -1403,14 +1447,16 @@ extern "C" int ptts_conv2d_mfma_bwd_fused(const void* p, const void* q, const vo
 #define C2M_BF(KIND)                                                                                                     \
     do {                                                                                                                 \
         typedef Stage<4 * (GPB + 1) + 4, KIND == 1 ? 16 : 16 + (KT - 1)> SQ;                                             \
-        constexpr size_t lds = (size_t)2 * NP * (SP::PS + SQ::PS) * sizeof(u16) + 64;                                    \
+        constexpr size_t lds = (size_t)2 * NP * (SP::PS + SQ::PS) * sizeof(u16) + 64 + (size_t)KT * NP * TKP * sizeof(u16);   \
         static_assert(lds <= LDS_MAX, "tile does not fit the LDS");                                                      \
         static_assert((size_t)(4 * KT * 2 * 4 * 64 + 256 * 4) * sizeof(float) <= lds, "reduction scratch");             \
         static bool attr = false;                                                                                        \
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_ws_kernel<KIND, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX); attr = true; } \
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_ws_kernel<KIND, NP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX); \
+                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_ws_kernel<KIND, NP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX); attr = true; } \
         const Sched sc = sched_for(s.ntiles, lds, 1, 2);                                                                 \
         grid = sc.G;                                                                                                     \
-        hipLaunchKernelGGL((bwd_ws_kernel<KIND, NP>), dim3(grid), dim3(8 * 64), lds, st, p, q, mask_src, (const u16*)table, y, parts, s, sc, alpha, g_dbg, status_words()); \
+        if (bwd_split()) hipLaunchKernelGGL((bwd_ws_kernel<KIND, NP, true>), dim3(grid), dim3(12 * 64), lds, st, p, q, mask_src, (const u16*)table, y, parts, s, sc, alpha, g_dbg, status_words()); \
+        else hipLaunchKernelGGL((bwd_ws_kernel<KIND, NP, false>), dim3(grid), dim3(8 * 64), lds, st, p, q, mask_src, (const u16*)table, y, parts, s, sc, alpha, g_dbg, status_words()); \
     } while (0)
     if (kind == 1) C2M_BF(1); else C2M_BF(2);
 #undef C2M_BF

@@ -10,7 +10,7 @@ cd percivaltts_amd/csrc
 OBJS=$(ls ../../build/csrc/*.o | grep -v conv2d_mfma.o)
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $OBJS ../../build/ab/conv2d_mfma.o -o ../../build/ab/libpercival_hip_ab.so || exit 1
 cd ../..
-for i in 1 2 3; do
+for i in 1 2; do
   echo "== as built ($i)"; python tools/c2m_ab_probe.py
   echo "== -D$D ($i)"; PTTS_LIB_PATH=$PWD/build/ab/libpercival_hip_ab.so python tools/c2m_ab_probe.py
 done
