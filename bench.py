@@ -365,6 +365,7 @@ def build_optimizer(args, ctx, spec, nm, batch, errtype, gated=False, bf16=None,
     cfg.train_wgan_hoist_side_backward = os.environ.get('PTTS_HOIST_SIDE_BWD', '1') == '1'      # (A/B switch)
     cfg.train_wgan_side_backward_first = os.environ.get('PTTS_SIDE_BWD_FIRST', '0') == '1'     # (A/B switch) the BLSTM's autograd node created last
     cfg.train_wgan_split_bf16 = not args.fp32_mfma
+    cfg.train_wgan_ctx_stream = os.environ.get('PTTS_CTX_STREAM', '0') == '1'          # (A/B switch) the critic's context branch on a side stream
     cfg.train_sync_batchnorm = bool(getattr(args, 'sync_bn', False))
     voc = vocoders.VocoderPML(16000, 0.005, spec, nm)
     with contextlib.redirect_stdout(io.StringIO()):

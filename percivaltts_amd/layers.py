@@ -730,7 +730,7 @@ class Model(nn.Module):
                     o.record_stream(cur)
         return results
 
-    def forward_multi_at(self, node, variants, feed, training=False, memo=None, parallel_streams=False):
+    def forward_multi_at(self, node, variants, feed, training=False, memo=None, parallel_streams=False, shared_stream=False):
         """forward_multi with the varying value at an INTERNAL node (`variants` are values of `node`, e.g. the critic's spectral slice:
         the stacked real / fake spectra and the interpolated sample, built by the optimiser without materialising the 86-column
         inputs they would be sliced from).  `feed` = {input node: tensor} for the inputs the rest of the graph needs; nodes that only
@@ -748,24 +748,59 @@ class Model(nn.Module):
         up(node)
         feed = {id(k): v for k, v in feed.items()}
         shared = {}
-        for n in self.order:
-            if id(n) in desc:
-                continue
-            if not n.parents:
-                if id(n) in feed:
-                    shared[id(n)] = feed[id(n)]
+        # shared_stream: the part of the graph that does not depend on `node` (the critic's context branch: Conv1D + two Dense layers and
+        # its product with the first post-concat kernel) runs on a side stream BESIDE the variants' own part up to the first node that
+        # needs it (the concatenation); autograd replays the fork in the backward pass.  One fork and one join per pass.
+        side_sh = cur_sh = ev_sh = None
+        join_nodes = None
+        if shared_stream and torch.cuda.is_available() and not parallel_streams:
+            join_nodes = set(id(n) for n in self.order if id(n) in desc and any(id(p) not in desc and id(p) not in anc for p in n.parents))
+            if join_nodes:
+                side_sh = side_streams(1, 'shared')[0]
+                cur_sh = torch.cuda.current_stream()
+                side_sh.wait_stream(cur_sh)
+        import contextlib as _ctx
+        with (torch.cuda.stream(side_sh) if side_sh is not None else _ctx.nullcontext()):
+            for n in self.order:
+                if id(n) in desc:
+                    continue
+                if not n.parents:
+                    if id(n) in feed:
+                        shared[id(n)] = feed[id(n)]
+                    else:
+                        assert id(n) in anc, 'forward_multi_at: input {} is needed but was not fed'.format(n.name)
+                        shared[id(n)] = None
+                elif id(n) in anc and any(shared.get(id(p)) is None for p in n.parents):
+                    shared[id(n)] = None                  # feeds only `node`: its value is given
                 else:
-                    assert id(n) in anc, 'forward_multi_at: input {} is needed but was not fed'.format(n.name)
-                    shared[id(n)] = None
-            elif id(n) in anc and any(shared.get(id(p)) is None for p in n.parents):
-                shared[id(n)] = None                  # feeds only `node`: its value is given
-            else:
-                shared[id(n)] = n.layer.compute([shared[id(p)] for p in n.parents], training, memo)
-        for n in self.order:
-            if isinstance(n.layer, Dense) and id(n) in desc and isinstance(n.parents[0].layer, Concatenate):
-                for i, pn in enumerate(n.parents[0].parents):
-                    if i > 0 and id(pn) in shared and shared[id(pn)] is not None:
-                        n.layer.prime_part(i, [pp.shape[-1] for pp in n.parents[0].parents], shared[id(pn)], memo)
+                    shared[id(n)] = n.layer.compute([shared[id(p)] for p in n.parents], training, memo)
+            for n in self.order:
+                if isinstance(n.layer, Dense) and id(n) in desc and isinstance(n.parents[0].layer, Concatenate):
+                    for i, pn in enumerate(n.parents[0].parents):
+                        if i > 0 and id(pn) in shared and shared[id(pn)] is not None:
+                            n.layer.prime_part(i, [pp.shape[-1] for pp in n.parents[0].parents], shared[id(pn)], memo)
+            if side_sh is not None:
+                ev_sh = side_sh.record_event()
+        if side_sh is not None:
+            # the variants' own part first, all of them, then the join, then the rest
+            results, partial = [], []
+            for x in variants:
+                values = dict(shared)
+                values[id(node)] = x
+                partial.append(self._run({}, training, memo, values, hold=join_nodes))
+            cur_sh.wait_event(ev_sh)
+            for v in shared.values():
+                t = v.z if isinstance(v, Lazy) else v
+                if torch.is_tensor(t):
+                    t.record_stream(cur_sh)
+            for k, t in memo.items():
+                if isinstance(k, tuple) and k and k[0] == 'dense_part' and torch.is_tensor(t):
+                    t.record_stream(cur_sh)
+            for values in partial:
+                values = self._run({}, training, memo, values)
+                outs = [to_tensor(values[id(o)]) for o in self.outputs]
+                results.append(outs[0] if self.single_output else outs)
+            return results
         results = []
         streams = self._variant_streams(len(variants)) if parallel_streams else None
         cur = torch.cuda.current_stream() if parallel_streams else None

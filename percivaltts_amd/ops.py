@@ -715,7 +715,8 @@ def _affine_act_bwd_raw(dy, x, y, scale, shift, act, alpha, want_dx=True):
     ws = _workspace(nws, x.device)
     call('ptts_affine_act_bwd', ptr(dy), ptr(x), ptr(y), ptr(scale), ptr(shift), ptr(dx), ptr(dsums), ptr(ws),
          ws.numel(), rows, C, act, alpha, stream())
-    return dx, dsums[:C].to(torch.float32), dsums[C:].to(torch.float32)
+    d32 = dsums.to(torch.float32)            # (one cast for both sums)
+    return dx, d32[:C], d32[C:]
 
 
 # ----------------------------------------------------------------------------------------------

@@ -135,6 +135,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         cfg.train_wgan_parallel_streams = False      # the critic evaluations on separate HIP streams
         cfg.train_wgan_side_backward_first = False   # generator step: the BLSTM's autograd node created last (its launches go out first), so that its backward chain is enqueued first.  Measured: the chain then ends 1 ms earlier, the step does not (the main stream's backward becomes the tail): off
         cfg.train_wgan_stack_real_fake = True        # critic(real) and critic(fake) as one stacked 2B pass (exact: no BatchNorm)
+        cfg.train_wgan_ctx_stream = False            # critic step: the context branch on a side stream beside the spectral stacks (one fork / join per pass; measured, see DESIGN)
         cfg.train_wgan_feed_spectra = True           # the critic is fed at its spectral slice (real / fake / interpolated spectra built directly; False: whole 86-column samples through the slice, as the reference's graph does)
         cfg.train_wgan_reuse_ctx_conv = True         # generator step reuses the critic step's G-context-Conv1D product (same batch)
         cfg.train_wgan_early_critic = True           # generator step: critic starts on the spectral branch, BLSTM joins for the LS term
@@ -276,7 +277,8 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             if getattr(self.cfg, 'train_wgan_stack_real_fake', True) and self._critic_is_per_sample():
                 # no BatchNorm in the critic: critic(real) and critic(fake) are one pass over the stacked 2B batch (half the launches,
                 # one weight-gradient product per layer instead of two; the context branch stays shared, at B)
-                both, v_hat = self.critic_net.forward_multi_at(node, [spec2, x_hat], feed, training=training, parallel_streams=streams)
+                both, v_hat = self.critic_net.forward_multi_at(node, [spec2, x_hat], feed, training=training, parallel_streams=streams,
+                                                                shared_stream=bool(getattr(self.cfg, 'train_wgan_ctx_stream', False)))
                 l_valid, l_fake = ops.wasserstein_pair(both, B)
             else:
                 valid, fake_v, v_hat = self.critic_net.forward_multi_at(node, [spec2[:B], spec2[B:], x_hat], feed, training=training,
