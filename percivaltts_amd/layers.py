@@ -191,6 +191,27 @@ class Dense(Layer):
         return _apply_activation(z, self.activation)
 
 
+def _dense_compute_pair(self, vals0, vals1, training, memo):
+    """Dense of two evaluations whose inputs lie back to back (Model.forward_multi_at's lockstep form): one forward launch (ops.dense_pair)."""
+    v0, v1 = vals0[0], vals1[0]
+    if isinstance(v0, LazyConcat) and isinstance(v1, LazyConcat) and memo is not None and len(v0.parts) == 2 and len(v1.parts) == 2 and \
+            v0.parts[1].z is v1.parts[1].z and ('dense_part', id(self), 1, id(v0.parts[1].z)) in memo:
+        y = memo[('dense_part', id(self), 1, id(v0.parts[1].z))]
+        k0 = v0.parts[0].shape[-1]
+        R = y.numel() // y.shape[-1]
+        lead = lambda p: int(np.prod(p.shape[:-1]))
+        if lead(v0.parts[0]) % R == 0 and lead(v1.parts[0]) % R == 0:
+            z0, z1 = ops.dense_pair(v0.parts[0], v1.parts[0], self.kernel[:k0], self.bias, res=y)
+            return _apply_activation(z0, self.activation), _apply_activation(z1, self.activation)
+    if not isinstance(v0, LazyConcat) and not isinstance(v1, LazyConcat):
+        z0, z1 = ops.dense_pair(v0, v1, self.kernel, self.bias)
+        return _apply_activation(z0, self.activation), _apply_activation(z1, self.activation)
+    return self.compute(vals0, training, memo), self.compute(vals1, training, memo)
+
+
+Dense.compute_pair = _dense_compute_pair
+
+
 def _apply_activation(z, activation):
     if activation in (None, 'linear'):
         return z
@@ -282,6 +303,16 @@ class Conv2D(Layer):
             v = v.tensor()
         z = ops.conv2d(v, self.kernel, self.bias, self.dil_t, ops.PAD_CAUSAL if self.causal else ops.PAD_SAME, self.bf16)
         return _apply_activation(z, self.activation)
+
+
+def _conv2d_compute_pair(self, vals0, vals1, training, memo):
+    v0, v1 = vals0[0], vals1[0]
+    if isinstance(v0, LazyConcat) or isinstance(v1, LazyConcat) or self.activation not in (None, 'linear'):
+        return self.compute(vals0, training, memo), self.compute(vals1, training, memo)
+    return ops.conv2d_pair(v0, v1, self.kernel, self.bias, self.dil_t, ops.PAD_CAUSAL if self.causal else ops.PAD_SAME, self.bf16)
+
+
+Conv2D.compute_pair = _conv2d_compute_pair
 
 
 class Conv2DStack(Layer):
@@ -730,7 +761,7 @@ class Model(nn.Module):
                     o.record_stream(cur)
         return results
 
-    def forward_multi_at(self, node, variants, feed, training=False, memo=None, parallel_streams=False, shared_stream=False):
+    def forward_multi_at(self, node, variants, feed, training=False, memo=None, parallel_streams=False, shared_stream=False, pair=False):
         """forward_multi with the varying value at an INTERNAL node (`variants` are values of `node`, e.g. the critic's spectral slice:
         the stacked real / fake spectra and the interpolated sample, built by the optimiser without materialising the 86-column
         inputs they would be sliced from).  `feed` = {input node: tensor} for the inputs the rest of the graph needs; nodes that only
@@ -802,6 +833,26 @@ class Model(nn.Module):
                 results.append(outs[0] if self.single_output else outs)
             return results
         results = []
+        if pair and len(variants) == 2 and not parallel_streams and ops._PairFlags.enabled and \
+                not any(getattr(n, 'stream', 0) for n in self.order if id(n) in desc):
+            # LOCKSTEP: the two evaluations walk the graph together, layer by layer; a layer that can (Conv2D, Dense: compute_pair) runs
+            # both forwards as ONE launch when their inputs lie back to back in one buffer -- which its own two outputs then do for the
+            # next layer.  The backward passes stay per evaluation (ops.Conv2dPairFn).
+            vals = [dict(shared), dict(shared)]
+            vals[0][id(node)], vals[1][id(node)] = variants[0], variants[1]
+            for n in self.order:
+                if id(n) not in desc or id(n) == id(node):
+                    continue
+                pv = [[vals[v][id(p)] for p in n.parents] for v in (0, 1)]
+                if hasattr(n.layer, 'compute_pair'):
+                    o0, o1 = n.layer.compute_pair(pv[0], pv[1], training, memo)
+                else:
+                    o0, o1 = n.layer.compute(pv[0], training, memo), n.layer.compute(pv[1], training, memo)
+                vals[0][id(n)], vals[1][id(n)] = o0, o1
+            for v in (0, 1):
+                outs = [to_tensor(vals[v][id(o)]) for o in self.outputs]
+                results.append(outs[0] if self.single_output else outs)
+            return results
         streams = self._variant_streams(len(variants)) if parallel_streams else None
         cur = torch.cuda.current_stream() if parallel_streams else None
         for vi, x in enumerate(variants):

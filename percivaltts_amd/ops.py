@@ -843,6 +843,80 @@ def conv2d(v, w, b=None, dil_t=1, pad_mode=PAD_SAME, bf16=None):
 
 
 # ----------------------------------------------------------------------------------------------
+# Two evaluations of one layer as ONE forward launch (round 4): the critic step evaluates its critic on the stacked real / fake batch (2B)
+# and on the interpolated sample (B) with the same weights.  Their forward passes are the same kernels on independent rows, so when the two
+# inputs lie back to back in one buffer the forward is ONE launch over 3B rows, and its outputs -- two views of one buffer -- lie back to
+# back for the next layer.  The backward passes differ (first-order for the stacked batch, the gradient penalty's passes for x^): each
+# evaluation's backward is the single-evaluation Function's, run on that evaluation's tensors alone.
+# ----------------------------------------------------------------------------------------------
+class _PairFlags(object):
+    enabled = os.environ.get('PTTS_PAIR_FORWARD', '1') == '1'
+
+
+def pair_forward(on):
+    _PairFlags.enabled = (os.environ.get('PTTS_PAIR_FORWARD', '1') == '1') if on is None else bool(on)
+
+
+def _adjacent(x0, x1):
+    return (torch.is_tensor(x0) and torch.is_tensor(x1) and x0.is_cuda and x0.dtype == torch.float32 and x1.dtype == torch.float32 and
+            x0.is_contiguous() and x1.is_contiguous() and x0.shape[1:] == x1.shape[1:] and
+            x1.data_ptr() == x0.data_ptr() + x0.numel() * 4 and
+            x0.untyped_storage().data_ptr() == x1.untyped_storage().data_ptr())
+
+
+def _cat_view(x0, x1):
+    """The rows of x0 followed by the rows of x1 as one tensor (no copy: the two lie back to back in one storage)."""
+    return torch.as_strided(x0, (x0.shape[0] + x1.shape[0],) + tuple(x0.shape[1:]), x0.stride())
+
+
+class _FakeCtx(object):
+    """What a single-evaluation Function's backward reads from its ctx (the pair Functions run it on one evaluation's tensors)."""
+    def __init__(self, saved, needs, **attrs):
+        self.saved_tensors, self.needs_input_grad = saved, needs
+        for k, v in attrs.items():
+            setattr(self, k, v)
+
+
+def _sum_opt(a, b):
+    return b if a is None else (a if b is None else a + b)
+
+
+class Conv2dPairFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, x1, w, b, mode, alpha, dil_t, pad_mode):
+        y = _conv2d_fwd_raw(_cat_view(x0, x1), w, b, None, None, None, mode, alpha, dil_t, pad_mode, 3, False)
+        ctx.save_for_backward(x0, x1, w)
+        ctx.has_b = b is not None
+        ctx.cfg = (mode, alpha, dil_t, pad_mode)
+        ctx.gw = grad_target(w) if _Deferred.active else None
+        ctx.gb = grad_target(b) if (_Deferred.active and b is not None) else None
+        ctx.set_materialize_grads(False)
+        return y[:x0.shape[0]], y[x0.shape[0]:]
+
+    @staticmethod
+    def backward(ctx, dy0, dy1):
+        x0, x1, w = ctx.saved_tensors
+        nig = ctx.needs_input_grad
+        dxs, dw, db = [None, None], None, None
+        for i, (dy, x) in enumerate(((dy0, x0), (dy1, x1))):
+            if dy is None:
+                continue
+            c = _FakeCtx((x, w, None, None), (nig[i], nig[2], nig[3], False, False), has_b=ctx.has_b, cfg=ctx.cfg, planes=3, gw=ctx.gw, gb=ctx.gb)
+            g = Conv2dFn.backward(c, dy)
+            dxs[i], dw, db = g[0], _sum_opt(dw, g[1]), _sum_opt(db, g[2])
+        return dxs[0], dxs[1], dw, db, None, None, None, None
+
+
+def conv2d_pair(v0, v1, w, b=None, dil_t=1, pad_mode=PAD_SAME, bf16=None):
+    """conv2d of two evaluations; ONE forward launch when their inputs lie back to back, else two calls."""
+    z0, mode0, sc0, sh0, al0 = _prep(v0)
+    z1, mode1, sc1, sh1, al1 = _prep(v1)
+    if _PairFlags.enabled and bf16 is None and sc0 is None and sc1 is None and mode0 == mode1 and al0 == al1 and _adjacent(z0, z1):
+        return Conv2dPairFn.apply(z0, z1, w, b, mode0, al0, dil_t, pad_mode)
+    return conv2d(v0, w, b, dil_t, pad_mode, bf16), conv2d(v1, w, b, dil_t, pad_mode, bf16)
+
+
+# ----------------------------------------------------------------------------------------------
 # The critic's whole Conv2D stack per launch (csrc/conv2d_chain.hip; networks_critic.py:64-70): bf16 storage path of
 # BASELINE configs[2].  L x (Conv2D 5x5, 4 filters, bias, LeakyReLU) with the maps between the layers held in the LDS;
 # the stored maps are POST-activation (they serve as operands and as LeakyReLU masks: slope > 0 keeps the sign).
@@ -1167,6 +1241,48 @@ class DenseBwdDataFn(torch.autograd.Function):
                 gemm_raw(u2, dy.view(M, N), cot_w, K, N, M, transA=1, lda=K, rows_per_seg=M,
                          mode=m2, mask_src=msk, alpha=alpha)
         return cot_dy, None, cot_w, None, None, None
+
+
+class DensePairFn(torch.autograd.Function):
+    """See Conv2dPairFn.  res (optional): the shared part's product, added to every R-row block of the 3B rows."""
+    @staticmethod
+    def forward(ctx, x0, x1, w, b, mode, alpha, res):
+        K, N = w.shape
+        xc = _cat_view(x0, x1)
+        M = xc.numel() // K
+        y = torch.empty(xc.shape[:-1] + (N,), dtype=torch.float32, device=xc.device)
+        gemm_raw(xc, w, y, M, N, K, bias=b, mode=mode, alpha=alpha, res=res)
+        ctx.save_for_backward(x0, x1, w)
+        ctx.has_b = b is not None
+        ctx.cfg = (mode, alpha)
+        ctx.res_shape = None if res is None else tuple(res.shape)
+        ctx.gw = grad_target(w) if _Deferred.active else None
+        ctx.gb = grad_target(b) if (_Deferred.active and b is not None) else None
+        ctx.set_materialize_grads(False)
+        return y[:x0.shape[0]], y[x0.shape[0]:]
+
+    @staticmethod
+    def backward(ctx, dy0, dy1):
+        x0, x1, w = ctx.saved_tensors
+        nig = ctx.needs_input_grad
+        dxs, dw, db, dres = [None, None], None, None, None
+        for i, (dy, x) in enumerate(((dy0, x0), (dy1, x1))):
+            if dy is None:
+                continue
+            c = _FakeCtx((x, w, None, None), (nig[i], nig[2], nig[3], False, False, False, False, nig[6]), has_b=ctx.has_b, cfg=ctx.cfg,
+                         res_shape=ctx.res_shape, gw=ctx.gw, gb=ctx.gb)
+            g = DenseFn.backward(c, dy)
+            dxs[i], dw, db, dres = g[0], _sum_opt(dw, g[1]), _sum_opt(db, g[2]), _sum_opt(dres, g[7])
+        return dxs[0], dxs[1], dw, db, None, None, dres
+
+
+def dense_pair(v0, v1, w, b=None, res=None):
+    """dense of two evaluations; ONE forward launch when their inputs lie back to back, else two calls."""
+    z0, mode0, sc0, sh0, al0 = _prep(v0)
+    z1, mode1, sc1, sh1, al1 = _prep(v1)
+    if _PairFlags.enabled and sc0 is None and sc1 is None and mode0 == mode1 and al0 == al1 and _adjacent(z0, z1):
+        return DensePairFn.apply(z0, z1, w, b, mode0, al0, None if res is None else res.contiguous())
+    return dense(v0, w, b, res), dense(v1, w, b, res)
 
 
 def dense(v, w, b=None, res=None):
@@ -2063,11 +2179,14 @@ def lstm(v, W, U, b, reverse=False, pre=None):
 # ----------------------------------------------------------------------------------------------
 # WGAN-GP pieces (optimizertts_wgan.py:44-79)
 # ----------------------------------------------------------------------------------------------
-def gp_interpolate(real, fake, alpha_b):
+def gp_interpolate(real, fake, alpha_b, out=None):
     """RandomWeightedAverage: alpha_b [B] per-sample weights (optimizertts_wgan.py:44-51)."""
     f32c(real, 'gp.real'); f32c(fake, 'gp.fake'); f32c(alpha_b, 'gp.alpha')
     assert real.shape == fake.shape and alpha_b.numel() == real.shape[0]
-    out = torch.empty_like(real)
+    if out is None:
+        out = torch.empty_like(real)
+    else:
+        f32c(out, 'gp.out'); assert out.shape == real.shape
     B = real.shape[0]
     call('ptts_gp_interpolate', ptr(real), ptr(fake), ptr(alpha_b), ptr(out), B, real.numel() // B, stream())
     return out

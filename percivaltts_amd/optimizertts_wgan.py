@@ -135,6 +135,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         cfg.train_wgan_parallel_streams = False      # the critic evaluations on separate HIP streams
         cfg.train_wgan_side_backward_first = False   # generator step: the BLSTM's autograd node created last (its launches go out first), so that its backward chain is enqueued first.  Measured: the chain then ends 1 ms earlier, the step does not (the main stream's backward becomes the tail): off
         cfg.train_wgan_stack_real_fake = True        # critic(real) and critic(fake) as one stacked 2B pass (exact: no BatchNorm)
+        cfg.train_wgan_pair_forward = True           # critic step: the forward of the stacked real / fake batch (2B) and of x^ (B) as ONE launch per layer over 3B rows (their backward passes stay separate)
         cfg.train_wgan_ctx_stream = False            # critic step: the context branch on a side stream beside the spectral stacks (one fork / join per pass; measured, see DESIGN)
         cfg.train_wgan_feed_spectra = True           # the critic is fed at its spectral slice (real / fake / interpolated spectra built directly; False: whole 86-column samples through the slice, as the reference's graph does)
         cfg.train_wgan_reuse_ctx_conv = True         # generator step reuses the critic step's G-context-Conv1D product (same batch)
@@ -267,18 +268,22 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             # and x^ is interpolated between those halves.  d D(x^) / d x^ is zero in the columns the critic does not read, so the
             # penalty's norm over [T,spec] IS the reference's norm over [T,out] (optimizertts_wgan.py:53-68).
             F = self._model.vocoder.specsize()
-            spec2 = torch.empty((2 * B, Y.shape[1], F), dtype=torch.float32, device=Y.device)
+            # (one buffer of 3B samples: the stacked pair and x^ lie back to back, so that a layer's forward over both evaluations is
+            # ONE launch over 3B rows -- Model.forward_multi_at(pair=True), ops.Conv2dPairFn)
+            spec3 = torch.empty((3 * B, Y.shape[1], F), dtype=torch.float32, device=Y.device)
+            spec2 = spec3[:2 * B]
             spec2[:B].copy_(self._spec_of(Y))
             spec2[B:].copy_(self._spec_of(fake))
             if alpha is None:
                 alpha = torch.rand(B, device=Y.device, dtype=torch.float32)
-            x_hat = ops.gp_interpolate(spec2[:B], spec2[B:], alpha.reshape(-1).contiguous()).requires_grad_(True)
+            x_hat = ops.gp_interpolate(spec2[:B], spec2[B:], alpha.reshape(-1).contiguous(), out=spec3[2 * B:]).detach().requires_grad_(True)
             feed = {self.critic.input_ctx: X}
             if getattr(self.cfg, 'train_wgan_stack_real_fake', True) and self._critic_is_per_sample():
                 # no BatchNorm in the critic: critic(real) and critic(fake) are one pass over the stacked 2B batch (half the launches,
                 # one weight-gradient product per layer instead of two; the context branch stays shared, at B)
                 both, v_hat = self.critic_net.forward_multi_at(node, [spec2, x_hat], feed, training=training, parallel_streams=streams,
-                                                                shared_stream=bool(getattr(self.cfg, 'train_wgan_ctx_stream', False)))
+                                                                shared_stream=bool(getattr(self.cfg, 'train_wgan_ctx_stream', False)),
+                                                                pair=bool(getattr(self.cfg, 'train_wgan_pair_forward', True)))
                 l_valid, l_fake = ops.wasserstein_pair(both, B)
             else:
                 valid, fake_v, v_hat = self.critic_net.forward_multi_at(node, [spec2[:B], spec2[B:], x_hat], feed, training=training,

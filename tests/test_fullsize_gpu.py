@@ -289,6 +289,32 @@ def test_critic_fed_at_its_spectral_slice_equals_whole_samples(setup):
     assert rel_l2(g1, g2) < 2e-5
 
 
+def test_one_forward_launch_for_both_evaluations_equals_two(setup):
+    """cfg.train_wgan_pair_forward (default on, round 4): the stacked real / fake batch (2B) and the interpolated sample (B) lie back to
+    back in one buffer and walk the critic in lockstep -- a Conv2D / Dense layer's forward is ONE launch over 3B rows
+    (ops.Conv2dPairFn / DensePairFn), its two outputs again back to back; the backward passes stay per evaluation.  Same kernels on
+    the same rows: losses and gradients equal to the run-to-run spread of the atomics; a third fewer forward launches (asserted)."""
+    from percivaltts_amd import _hip
+    cfg, opt, crit, X, Y = setup
+    g = torch.Generator().manual_seed(14)
+    alpha = torch.rand(B, generator=g).cuda()
+    with torch.no_grad():
+        fake = opt._fake_sample(X, True).detach()
+    res, counts = [], []
+    for pair in (True, False):
+        opt.cfg.train_wgan_pair_forward = pair
+        with _hip.KernelTimer() as kt:
+            res.append(_critic_grads(opt, X, Y, alpha, fake))
+        names = [r[0] for r in kt.records]
+        counts.append((names.count('ptts_conv2d_mfma_fwd'), names.count('ptts_conv2d_fwd'), names.count('ptts_dense_bf16x6') + names.count('ptts_dense_bf16x6_res')))
+    opt.cfg.train_wgan_pair_forward = True
+    (t1, p1, g1), (t2, p2, g2) = res
+    assert counts[0][0] == counts[1][0] - 7 and counts[0][1] == counts[1][1] - 1 and counts[0][2] == counts[1][2] - 3, counts
+    for a, b, nm in zip(p1, p2, ('valid', 'fake', 'gp')):
+        close(a, b, 1e-6, 1e-7, 'one launch vs two: ' + nm)      # (the loss reductions add with fp32 atomics: last bits vary from run to run)
+    assert rel_l2(g1, g2) < 2e-5
+
+
 def test_batch_gradient_is_the_mean_of_the_shard_gradients(setup):
     """What data parallelism relies on: with per-sample interpolation weights fixed, the critic loss is a mean over the
     samples (no BatchNorm in the critic), so grad(batch) = (grad(first half) + grad(second half)) / 2."""
