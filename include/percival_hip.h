@@ -424,6 +424,10 @@ int ptts_bn_batch_stats(const float* x, long long rows, int C, const float* gamm
 int ptts_bn_bwd_coefs(const float* dscale, const float* dshift, const float* mean, const float* rstd,
                       const float* gamma /*NULL = 1*/, long long count, int C,
                       float* dgamma, float* dbeta, float* c0, float* c2, void* stream);
+/* ... with dgamma / dbeta ADDED into the buffers given (the parameters' gradient buffers: no separate accumulation launch per parameter) */
+int ptts_bn_bwd_coefs_acc(const float* dscale, const float* dshift, const float* mean, const float* rstd,
+                      const float* gamma /*NULL = 1*/, long long count, int C,
+                      float* dgamma, float* dbeta, float* c0, float* c2, void* stream);
 
 /* y = act(x*scale[c]+shift[c]) materialised (used where no consumer can fuse it: LSTM input, final outputs). */
 int ptts_affine_act(const float* x, const float* scale, const float* shift, float* y,

@@ -113,6 +113,7 @@ SIGNATURES = {
     'ptts_bn_batch_stats_supported': (c_i, [c_ll, c_i]),
     'ptts_bn_batch_stats': (c_i, [c_p, c_ll, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_sz, c_p, c_p]),
     'ptts_bn_bwd_coefs': (c_i, [c_p] * 5 + [c_ll, c_i] + [c_p] * 4 + [c_p]),
+    'ptts_bn_bwd_coefs_acc': (c_i, [c_p] * 5 + [c_ll, c_i] + [c_p] * 4 + [c_p]),
     'ptts_affine_act': (c_i, [c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_f, c_p]),
     'ptts_affine_act_bwd': (c_i, [c_p] * 7 + [c_p, c_sz, c_ll, c_i, c_i, c_f, c_p]),
     'ptts_gated_mul_fwd': (c_i, [c_p] * 3 + [c_ll, c_p]),

@@ -462,7 +462,7 @@ __global__ void bn_bwd_coefs_kernel(const float* __restrict__ dscale, const floa
                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                     const float* __restrict__ gamma, long long count, int C,
                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                    float* __restrict__ c0, float* __restrict__ c2) {
+                                    float* __restrict__ c0, float* __restrict__ c2, int accumulate) {
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
         const double g = gamma ? (double)gamma[c] : 1.0;
         const double mu = mean[c], rs = rstd[c];
@@ -470,8 +470,8 @@ __global__ void bn_bwd_coefs_kernel(const float* __restrict__ dscale, const floa
         const double dmean = -(double)dshift[c] * g * rs;
         const double dvar = -0.5 * dsc * g * rs * rs * rs;
         const double k2 = 2.0 * dvar / (double)count;
-        if (dgamma) dgamma[c] = (float)(dsc * rs);
-        if (dbeta) dbeta[c] = dshift[c];
+        if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)(dsc * rs);      // (one thread per channel: no race)
+        if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + dshift[c];
         c2[c] = (float)k2;
         c0[c] = (float)(dmean / (double)count - k2 * mu);
     }
@@ -746,8 +746,18 @@ extern "C" int ptts_bn_bwd_coefs(const float* dscale, const float* dshift, const
                                  float* c0, float* c2, void* stream) {
     PTTS_REQUIRE(dscale && dshift && mean && rstd && c0 && c2 && C > 0 && count > 0, "bn_bwd_coefs: bad args");
     hipLaunchKernelGGL(bn_bwd_coefs_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, dscale, dshift,
-                       mean, rstd, gamma, count, C, dgamma, dbeta, c0, c2);
+                       mean, rstd, gamma, count, C, dgamma, dbeta, c0, c2, 0);
     return check_launch("bn_bwd_coefs");
+}
+
+// the same with dgamma / dbeta ADDED to what the buffers hold: the parameters' gradient buffers themselves (no per-parameter add launch)
+extern "C" int ptts_bn_bwd_coefs_acc(const float* dscale, const float* dshift, const float* mean, const float* rstd,
+                                     const float* gamma, long long count, int C, float* dgamma, float* dbeta,
+                                     float* c0, float* c2, void* stream) {
+    PTTS_REQUIRE(dscale && dshift && mean && rstd && c0 && c2 && C > 0 && count > 0, "bn_bwd_coefs_acc: bad args");
+    hipLaunchKernelGGL(bn_bwd_coefs_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, dscale, dshift,
+                       mean, rstd, gamma, count, C, dgamma, dbeta, c0, c2, 1);
+    return check_launch("bn_bwd_coefs_acc");
 }
 
 extern "C" int ptts_affine_act(const float* x, const float* scale, const float* shift, float* y, long long rows,

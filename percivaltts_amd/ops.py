@@ -1864,6 +1864,9 @@ class BatchNormTrainFn(torch.autograd.Function):
         mean = torch.empty(C, dtype=torch.float32, device=dev)
         rstd = torch.empty(C, dtype=torch.float32, device=dev)
         ctx.sync = _SyncBN.world
+        # inside deferred_weight_grads(): dgamma / dbeta are added straight into the parameters' gradient buffers by the kernel that
+        # computes them (two AccumulateGrad add launches per BatchNorm layer less: 30 per generator step)
+        ctx.gt = (grad_target(gamma), grad_target(beta)) if _Deferred.active else None
         if ctx.sync <= 1 and z.data_ptr() % 16 == 0 and _hip.lib().ptts_bn_batch_stats_supported(rows, C):
             # the conv stacks' few-channel maps: statistics and affine in one launch
             ws = _workspace(_hip.lib().ptts_colstats_workspace_bytes(rows, C), dev)
@@ -1891,12 +1894,23 @@ class BatchNormTrainFn(torch.autograd.Function):
         dev = z.device
         dscale = dscale.contiguous() if dscale is not None else torch.zeros(C, dtype=torch.float32, device=dev)
         dshift = dshift.contiguous() if dshift is not None else torch.zeros(C, dtype=torch.float32, device=dev)
-        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
         c0 = torch.empty(C, dtype=torch.float32, device=dev)
         c2 = torch.empty(C, dtype=torch.float32, device=dev)
-        call('ptts_bn_bwd_coefs', ptr(dscale), ptr(dshift), ptr(mean), ptr(rstd), ptr(gamma), rows, C,
-             ptr(dgamma), ptr(dbeta), ptr(c0), ptr(c2), stream())
+        gt = ctx.gt
+        direct = gt is not None and gt[0] is not None and gt[1] is not None and _Deferred.active and not _Flags.deterministic and \
+            ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
+        if direct:
+            call('ptts_bn_bwd_coefs_acc', ptr(dscale), ptr(dshift), ptr(mean), ptr(rstd), ptr(gamma), rows, C,
+                 ptr(gt[0]), ptr(gt[1]), ptr(c0), ptr(c2), stream())
+            cur = torch.cuda.current_stream()
+            if all(cur.cuda_stream != q.cuda_stream for q in _Deferred.streams):
+                _Deferred.streams.append(cur)             # flush_weight_grads() joins this stream before the optimiser reads the buffer
+            dgamma = dbeta = None
+        else:
+            dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+            dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+            call('ptts_bn_bwd_coefs', ptr(dscale), ptr(dshift), ptr(mean), ptr(rstd), ptr(gamma), rows, C,
+                 ptr(dgamma), ptr(dbeta), ptr(c0), ptr(c2), stream())
         if ctx.sync > 1:
             # the terms through the statistics carry every rank's loss: their coefficients come from the all-reduced sums
             # over the global row count; dgamma / dbeta stay this rank's own share (the flat-gradient all-reduce adds them)
