@@ -214,6 +214,10 @@ __global__ __launch_bounds__(256) void split3_dense_weight_strided_kernel(SplitS
         *reinterpret_cast<uint4*>(planes + p * ps + (size_t)idx * 8) = make_uint4(q[p][0], q[p][1], q[p][2], q[p][3]);
 }
 
+#ifndef DNS_DEPTH
+#define DNS_DEPTH 2        // register stages of the A operand in dense_bf16x6_kernel (1 = the single stage of rounds 2-3; measured 1 / 2 / 3 / 4 / 6:
+                           // 25.6 / 25.0 / 25.6 / 26.5 / 29.8 us at 25 600 rows, 82.4 / 75.3 / 80.3 / 83.0 / 86.0 at 76 800: the loads are not what bounds it)
+#endif
 struct DenseArgs {
     const float* A; const float* mask_src; const float* in_scale; const float* in_shift;
     const u16* planes; const float* bias; const float* out_mask; float* C;
@@ -338,22 +342,27 @@ __global__ __launch_bounds__(THREADS) void dense_bf16x6_kernel(DenseArgs g) {
     // One basic block per k-step: the staging of step s+1 (transform, split, LDS stores into the other buffer) and the loads
     // of step s+2 sit between the MFMAs of step s.  (A wave whose columns lie beyond N runs the same code on the first
     // tile's planes: the MFMAs are cheap next to a divergent barrier structure, and nothing of it is stored.)
-    Stage sg;
+    // DEPTH register stages of A: the loads of k-step s + DEPTH are issued while step s is multiplied.  The kernel's time is linear in M
+    // from 25 600 rows up (tools/dense_ramp_probe.py: 1.0 us per 1000 rows, 130 TF) and hardly moves with DEPTH: what bounds a k-step is
+    // the matrix pipe -- TWO waves per SIMD x 84 six-product MFMAs x 16 cycles = 2 700 cycles at the ~1.8 GHz it holds under that load.
+    constexpr int DEPTH = DNS_DEPTH;
+    Stage sg[DEPTH];
     bf16x8 wc[2][NPL], wn[2][NPL];
-    load_a(0, sg);
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) load_a(j, sg[j]);
     load_w(0, wc);
-    commit(sg, As[0]);
-    load_a(1, sg);
+    commit(sg[0], As[0]);
+    load_a(DEPTH, sg[0]);
     __syncthreads();
     // The two waves of a SIMD leave every barrier together; with the staging at the same place of their instruction streams
     // both would do vector work at the same time and leave the matrix pipe idle.  Waves 0-3 (one per SIMD) stage after two
     // row tiles, waves 4-7 after MT - 2.
-    auto step = [&](int s, int cut) {
+    auto step = [&](int s, int cut, Stage& nx) {             // nx: the stage that holds step s + 1 (slot (s + 1) % DEPTH), refilled with step s + 1 + DEPTH
         const u16* as = As[s & 1];
         load_w(s + 1 < KS ? s + 1 : s, wn);
         mfma_rows(as, wc, 0, cut);
-        commit(sg, As[(s + 1) & 1]);                          // the other buffer: every wave left it at the last barrier
-        load_a(s + 2, sg);
+        commit(nx, As[(s + 1) & 1]);                          // the other buffer: every wave left it at the last barrier
+        load_a(s + 1 + DEPTH, nx);
         mfma_rows(as, wc, cut, MT);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -361,8 +370,17 @@ __global__ __launch_bounds__(THREADS) void dense_bf16x6_kernel(DenseArgs g) {
             for (int p = 0; p < NPL; ++p) wc[j][p] = wn[j][p];
         __syncthreads();
     };
-    if (wave < 4) { for (int s = 0; s < KS; ++s) step(s, 2); }
-    else { for (int s = 0; s < KS; ++s) step(s, MT - 2); }
+    auto run = [&](int cut) {
+        int s = 0;
+        for (; s + DEPTH <= KS; s += DEPTH) {                 // (s % DEPTH == 0: the stage indices are compile-time)
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j) step(s + j, cut, sg[(j + 1) % DEPTH]);
+        }
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j)
+            if (s + j < KS) step(s + j, cut, sg[(j + 1) % DEPTH]);
+    };
+    if (wave < 4) run(2); else run(MT - 2);
     if (!wave_live) return;
     // ---- store: lane (li, lg) of acc[i][j] holds row m0 + 16 i + li, columns n0 + 32 wave + 16 j + 4 lg .. + 3
     const bool interior = m0 + TBM <= g.M;                    // no row guards: the mask / old-value loads go out together
