@@ -25,6 +25,12 @@ def _worker(rank, world, port, q):
     g = torch.arange(10, dtype=torch.float32) * (rank + 1)
     scale = parallel.allreduce_sum_(g)
     ok = torch.allclose(g * scale, torch.arange(10, dtype=torch.float32) * 1.5) and abs(scale - 0.5) < 1e-12
+    # the explicit form the optimiser's update uses: start the collective, order it with work.wait(), then consume
+    g2 = torch.arange(6, dtype=torch.float32) * (rank + 1)
+    work, scale2 = parallel.allreduce_sum_async(g2)
+    ok = ok and work is not None
+    work.wait()
+    ok = ok and torch.allclose(g2 * scale2, torch.arange(6, dtype=torch.float32) * 1.5) and abs(scale2 - 0.5) < 1e-12
     lo, hi = parallel.shard_batch(128)
     ok = ok and (lo, hi) == (rank * 64, (rank + 1) * 64)
     p = torch.full((5,), float(rank + 7))
@@ -58,3 +64,4 @@ def test_single_process_is_a_noop():
     from percivaltts_amd import parallel
     g = torch.ones(4)
     assert parallel.allreduce_sum_(g) == 1.0 and parallel.world_size() == 1 and parallel.shard_batch(10) == (0, 10)
+    assert parallel.allreduce_sum_async(g) == (None, 1.0)
