@@ -48,6 +48,7 @@ def parse():
     ap.add_argument('--errtype', default='WLSWGAN')
     ap.add_argument('--graph', action='store_true', help='capture each step once and replay it as a hipGraph (single stream)')
     ap.add_argument('--no-hoist', action='store_true', help="do not launch the generator's forward before the critic step of a batch that trains both (cfg.train_wgan_hoist_generator)")
+    ap.add_argument('--no-lookahead', action='store_true', help="do not launch a generator step's forward one batch ahead (cfg.train_wgan_generator_lookahead)")
     ap.add_argument('--no-graph', action='store_true', help="never replay a step as a hipGraph (the default, cfg.train_wgan_hipgraph = 'tune', times eager launches against a replay per step kind on the first batch and keeps the faster)")
     ap.add_argument('--eager', action='store_true', help='(default) eager launches; kept for compatibility')
     ap.add_argument('--graph-critic', choices=['on', 'off'], default=None, help="pin the critic step's form: hipGraph replay (on) or eager launches (off), instead of the 'tune' timing comparison on the first batch -- so that a profile and a bench run time ONE program")
@@ -362,6 +363,7 @@ def build_optimizer(args, ctx, spec, nm, batch, errtype, gated=False, bf16=None,
     cfg.train_wgan_reuse_ctx_conv = not args.no_ctx_reuse
     cfg.train_wgan_early_critic = not args.no_early_critic
     cfg.train_wgan_hoist_generator = (not args.no_hoist) and os.environ.get('PTTS_HOIST', '1') == '1'
+    cfg.train_wgan_generator_lookahead = (not getattr(args, 'no_lookahead', False)) and os.environ.get('PTTS_LOOKAHEAD', '1') == '1'
     cfg.train_wgan_hoist_side_backward = os.environ.get('PTTS_HOIST_SIDE_BWD', '1') == '1'      # (A/B switch)
     cfg.train_wgan_side_backward_first = os.environ.get('PTTS_SIDE_BWD_FIRST', '0') == '1'     # (A/B switch) the BLSTM's autograd node created last
     cfg.train_wgan_split_bf16 = not args.fp32_mfma
@@ -396,7 +398,9 @@ def timed_loop(opt, batches, nsteps, warmup, dev, cycle=5):
     def run(n, start, events=None):
         for i in range(n):
             X, Y = batches[(start + i) % nbuf]
-            opt.device_step(start + i, X, Y)
+            # the next batch is named (as the training driver does from its prefetcher, optimizertts.train_oneparamset): a generator step's
+            # forward is launched one batch ahead.  Not on the last step of a run: the timed region holds the work of its own steps only
+            opt.device_step(start + i, X, Y, nxt=batches[(start + i + 1) % nbuf] if i + 1 < n else None)
             if events is not None and (i + 1) % cycle == 0:
                 ev = torch.cuda.Event(enable_timing=True); ev.record(); events.append(ev)
 
@@ -557,8 +561,9 @@ def main():
         pf = data.BatchPrefetcher(lambda i: pool[i % nbuf], nh, device=dev, depth=2)
         parallel.barrier(); torch.cuda.synchronize()
         th = time.time()
-        for i, (hx, hy) in enumerate(pf):
-            opt.device_step(i, hx, hy)
+        from percivaltts_amd.optimizertts import _with_next
+        for i, (hx, hy), nx in _with_next(pf):
+            opt.device_step(i, hx, hy, nxt=nx)
         torch.cuda.synchronize(); parallel.barrier()
         dth = parallel.max_over_ranks(time.time() - th, dev)
         pf.close()
@@ -628,6 +633,7 @@ def main():
                        'stack_real_fake_critic_pass': bool(cfg.train_wgan_stack_real_fake),
                        'reuse_generator_ctx_conv_within_train_on_batch': bool(cfg.train_wgan_reuse_ctx_conv),
                        'generator_forward_hoisted_before_the_critic_step': bool(cfg.train_wgan_hoist_generator),
+                       'generator_forward_one_batch_ahead': bool(cfg.train_wgan_hoist_generator and cfg.train_wgan_generator_lookahead),
                        'ctx_conv1d_forward_and_weight_gradient': (('frequency domain (DFT, per-frequency products, inverse DFT; correlation theorem for the weight gradient), every product a '
                                                                    if (ops._C1FFT.enabled and not cfg.train_wgan_bf16_products) else '') + 'bf16x6 split (bf16 MFMA, fp32 accumulate)'
                                                                   + (' -- ONE bf16 product (time domain)' if cfg.train_wgan_bf16_products else '')) if cfg.train_wgan_split_bf16 else 'fp32 MFMA',

@@ -34,6 +34,21 @@ def lse_loss(y_true, y_pred):
     return ops.wlse(y_pred, y_true, None)
 
 
+def _with_next(it):
+    """(index, item, next item or None) over an iterator: one item of look-ahead."""
+    it = iter(it)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    i = 0
+    for nx in it:
+        yield i, cur, nx
+        cur = nx
+        i += 1
+    yield i, cur, None
+
+
 class OptimizerTTS:
 
     _model = None    # the model whose parameters are optimised
@@ -201,8 +216,9 @@ class OptimizerTTS:
 
             # batches are loaded, pinned and copied to the device two ahead of the step that consumes them
             prefetch = data.BatchPrefetcher(make_batch, nbbatches, device=self.device, depth=2)
-            for batchid, (X_trab, Y_trab) in enumerate(self._closing(prefetch)):
+            for batchid, (X_trab, Y_trab), nxt in _with_next(self._closing(prefetch)):
                 t0 = time.time()
+                self.hint_next_batch(*(nxt if nxt is not None else (None, None)))     # (the prefetcher has it on the device already)
                 print_tty('\r    Training batch {}/{}'.format(1 + batchid, nbbatches))
                 load_times.append(prefetch.load_seconds - sum(load_times))
                 print_tty(' (iter load: {:.6f}s); training '.format(load_times[-1]))
@@ -361,6 +377,10 @@ class OptimizerTTS:
                 yield item
         finally:
             prefetch.close()
+
+    def hint_next_batch(self, X_next, Y_next):
+        """The training loop names the batch the next train_on_batch will get (or None); optimisers that can use it override this."""
+        pass
 
     def _local_shard(self, X, Y):
         """Host (numpy) batches are the global batch: keep this rank's rows.  Device tensors come from

@@ -135,6 +135,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         cfg.train_wgan_parallel_streams = False      # the critic evaluations on separate HIP streams
         cfg.train_wgan_side_backward_first = False   # generator step: the BLSTM's autograd node created last (its launches go out first), so that its backward chain is enqueued first.  Measured: the chain then ends 1 ms earlier, the step does not (the main stream's backward becomes the tail): off
         cfg.train_wgan_stack_real_fake = True        # critic(real) and critic(fake) as one stacked 2B pass (exact: no BatchNorm)
+        cfg.train_wgan_generator_lookahead = True    # a generator step's forward launched one batch ahead when the caller names the next batch (hint_next_batch / device_step(nxt=...))
         cfg.train_wgan_pair_forward = True           # critic step: the forward of the stacked real / fake batch (2B) and of x^ (B) as ONE launch per layer over 3B rows (their backward passes stay separate)
         cfg.train_wgan_ctx_stream = False            # critic step: the context branch on a side stream beside the spectral stacks (one fork / join per pass; measured, see DESIGN)
         cfg.train_wgan_feed_spectra = True           # the critic is fed at its spectral slice (real / fake / interpolated spectra built directly; False: whole 86-column samples through the slice, as the reference's graph does)
@@ -689,9 +690,22 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             return False
         return bool(g)
 
-    def device_step(self, batchid, X, Y, alpha=None):
+    def hint_next_batch(self, X_next, Y_next):
+        """The batch the NEXT train_on_batch will get (device tensors, the very objects that will be passed), or None.  With it a
+        generator step's forward is launched ONE BATCH AHEAD (cfg.train_wgan_generator_lookahead, see device_step)."""
+        self._next_batch = None if X_next is None else (X_next, Y_next)
+
+    def device_step(self, batchid, X, Y, alpha=None, nxt=None):
         """One `train_on_batch` worth of device work on resident tensors; returns (critic_loss, generator_loss|None)
-        as device scalars."""
+        as device scalars.
+
+        `nxt` = (X, Y) of the next batch (the tensors the next call will be given), optional.  The reference trains the generator on
+        every critic_runs-th batch (optimizertts_wgan.py:225-240); its forward depends on the generator's weights -- untouched since
+        the previous generator step -- and on that batch's labels only.  Knowing the next batch, the forward (and, as with the hoist
+        inside a batch, the BLSTM branch's backward) of a generator step is launched BEFORE the critic step of the batch in front of
+        it: the two 400-step recurrence chains, 5.7 ms on their own, then run under TWO critic steps instead of one, and the
+        generator step itself is left with the critic's evaluation, the backward pass and the update.  Same weights, same inputs,
+        same arithmetic: the results are those of the plain order (tested)."""
         critic_runs = 10 if (self.generator_updates < 25) or (self.generator_updates % 500 == 0) else 5   # (:225-228)
         gen_too = batchid % critic_runs == 0
         # a kernel of an earlier step that gave up on a hand-off has left its code in the device status word: an error at the step
@@ -717,25 +731,53 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
                 lc, lg = self._graphed('batch', X, Y, alpha)
                 self.generator_updates += 1
                 return lc, lg
-            lc, lg = self._batch_steps(X, Y, alpha, gen_too, graph_c, graph_g)
+            if nxt is None:
+                nxt, self._next_batch = getattr(self, '_next_batch', None), None
+            next_gen = nxt is not None and not gen_too and (batchid + 1) % critic_runs == 0
+            lc, lg = self._batch_steps(X, Y, alpha, gen_too, graph_c, graph_g, nxt if next_gen else None)
             if gen_too:
                 self.generator_updates += 1
         finally:
             ops.conv1d_cache(False)
         return lc, lg
 
-    def _batch_steps(self, X, Y, alpha, gen_too, graph_c, graph_g):
+    def _batch_steps(self, X, Y, alpha, gen_too, graph_c, graph_g, nxt=None):
         """The steps of one train_on_batch: critic step, and the generator step when `gen_too` (its forward hoisted in front of the
-        critic step, see generator_forward_early)."""
+        critic step -- or of the previous batch's critic step, see device_step -- by generator_forward_early)."""
         pre = fake = None
-        if gen_too and not graph_g and bool(getattr(self.cfg, 'train_wgan_hoist_generator', True)) and self._can_split_generator():
-            # G's forward first (see generator_forward_early); inside deferred_weight_grads() so that its layers note their
-            # gradient targets as they do inside the generator step
-            self.gen_opti.zero_grad()
-            with ops.deferred_weight_grads():
-                pre = self.generator_forward_early(X, Y, training=True)
-                self._gen_deferred = ops.deferred_detach()      # (joined and flushed by the generator step's own context)
+        hoist = bool(getattr(self.cfg, 'train_wgan_hoist_generator', True)) and self._can_split_generator()
+        ahead, self._ahead = getattr(self, '_ahead', None), None
+        if ahead is not None and not (gen_too and not graph_g and hoist and ahead['X'] is X and ahead['Y'] is Y and
+                                      ahead['epoch'] == self.gen_opti.flat.epoch):
+            self._drop_ahead(ahead)
+            ahead = None
+        if gen_too and not graph_g and hoist:
+            if ahead is not None:
+                # launched one batch ago (below): nothing of the generator's forward is left to do
+                pre, self._gen_deferred, self._gen_cuts = ahead['pre'], ahead['deferred'], ahead['cuts']
+            else:
+                # G's forward first (see generator_forward_early); inside deferred_weight_grads() so that its layers note their
+                # gradient targets as they do inside the generator step
+                self.gen_opti.zero_grad()
+                with ops.deferred_weight_grads():
+                    pre = self.generator_forward_early(X, Y, training=True)
+                    self._gen_deferred = ops.deferred_detach()      # (joined and flushed by the generator step's own context)
             fake = self.fake_from_early(X, pre)
+        if nxt is not None and hoist and bool(getattr(self.cfg, 'train_wgan_generator_lookahead', True)) and \
+                not self._use_graph(nxt[0], 'generator', nxt[1]):
+            # the NEXT batch trains the generator: its forward goes out now, in front of this batch's critic step
+            Xn, Yn = nxt
+            self._wait_update('generator')          # (the previous generator update reads the gradient buffer zeroed here)
+            self.gen_opti.zero_grad()
+            # the forward moves the BatchNorm moving averages: kept (one launch) for the case that another batch comes (_drop_ahead)
+            bufs = [b for b in self._model.kerasmodel.buffers() if b.numel() > 0]
+            kept = torch.cat([b.detach().reshape(-1) for b in bufs]) if bufs else None
+            with ops.deferred_weight_grads():
+                pre_n = self.generator_forward_early(Xn, Yn, training=True)
+                dfr = ops.deferred_detach()
+            self._ahead = {'X': Xn, 'Y': Yn, 'pre': pre_n, 'deferred': dfr, 'cuts': self._gen_cuts, 'epoch': self.gen_opti.flat.epoch,
+                           'buffers': (bufs, kept)}
+            self._gen_cuts = None
         ops._lstm_mark('critic_step_begin')
         if graph_c:
             lc = self._graphed('critic', X, Y, alpha, fake)
@@ -749,6 +791,22 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             else:
                 lg = self.generator_step(X, Y) if pre is None else self.generator_step(X, Y, pre)
         return lc, lg
+
+    def _drop_ahead(self, ahead):
+        """A generator forward launched one batch ahead for a batch that did not come (the caller named another one, the weights were
+        restored, the step kind changed): everything it changed is put back -- the BatchNorm moving averages it moved, the gradient
+        buffer its side branch's early backward pass added into (behind that branch's stream) -- and its queued weight-gradient
+        products are forgotten."""
+        cur = torch.cuda.current_stream()
+        for q in ahead['deferred'][2]:
+            cur.wait_stream(q)
+        bufs, kept = ahead['buffers']
+        off = 0
+        with torch.no_grad():
+            for b in bufs:
+                b.copy_(kept[off:off + b.numel()].view_as(b))
+                off += b.numel()
+        self.gen_opti.zero_grad()
 
     def _use_batch_graph(self, X, Y, graph_c):
         """cfg.train_wgan_hipgraph = 'tune' (one process): is a batch that trains both networks replayed as ONE graph?  Timed on the first
@@ -786,7 +844,13 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
     def train_on_batch(self, batchid, X_trab, Y_trab):
         X_trab, Y_trab = self._local_shard(X_trab, Y_trab)
         X, Y = self._to_dev(X_trab), self._to_dev(Y_trab)
-        lc, lg = self.device_step(batchid, X, Y)
+        nb = getattr(self, '_next_batch', None)
+        if nb is not None and torch.is_tensor(nb[0]) and nb[0].is_cuda:
+            nb = (self._to_dev(nb[0]), self._to_dev(nb[1]))           # (identity for resident float32 tensors: the objects stay the same)
+        else:
+            nb = None                                                  # host arrays: no look-ahead (they would be copied twice)
+        self._next_batch = None
+        lc, lg = self.device_step(batchid, X, Y, nxt=nb)
         # the critic's loss stays on the device (no host synchronisation on the 4 of 5 batches that do not train the generator)
         self.costs_tra_critic_batches.append_device(lc)
         return None if lg is None else float(lg.item())

@@ -476,6 +476,68 @@ def test_hoisted_generator_forward_gives_the_same_train_step(setup):
             close(a, b, 1e-5, 1e-6, 'BatchNorm moving statistics after the step (' + what + ')')
 
 
+def test_generator_forward_one_batch_ahead_gives_the_same_two_batches(setup):
+    """cfg.train_wgan_generator_lookahead (default on) with the next batch named (device_step(nxt=...), as the training driver does from
+    its prefetcher): the forward of a generator step -- and its BLSTM branch's backward -- is launched in front of the critic step of the
+    batch BEFORE it.  The generator's weights are not touched in between (reference optimizertts_wgan.py:225-240: the critic alone trains
+    on that batch; its fake sample is drawn with the BatchNorm moving averages frozen), so two consecutive batches give the same losses,
+    gradients, weights and moving statistics as the plain order; a look-ahead made for a batch that does not come is dropped."""
+    from percivaltts_amd import _hip
+    cfg, opt, crit, X, Y = setup
+    X2, Y2 = X.flip(0).contiguous(), Y.flip(0).contiguous()
+    state = (opt.critic_opti.flat.flat, opt.critic_opti.m, opt.critic_opti.v, opt.critic_opti.step_count,
+             opt.gen_opti.flat.flat, opt.gen_opti.m, opt.gen_opti.v, opt.gen_opti.step_count)
+    snap = [t.detach().clone() for t in state]
+    moving = [t for k, t in opt._model.kerasmodel.weights() if 'moving' in k]
+    moving0 = [t.detach().clone() for t in moving]
+    gu0 = opt.generator_updates
+
+    def restore():
+        opt.wait_updates()
+        for dst, src in zip(state, snap):
+            dst.copy_(src)
+        for dst, src in zip(moving, moving0):
+            dst.copy_(src)
+        opt.critic_opti.flat.epoch += 1; opt.gen_opti.flat.epoch += 1
+        opt.generator_updates = 26                          # steady state: every fifth batch trains the generator (:225-228)
+        opt._ahead = None
+
+    results = {}
+    try:
+        # batch 4 (critic only) on (X2, Y2), batch 5 (critic + generator) on (X, Y)
+        for what, named in (('ahead', (X, Y)), ('plain', None), ('ahead of another batch', (X2, Y2))):
+            restore()
+            torch.manual_seed(5)
+            with _hip.KernelTimer() as k4:
+                lc4, lg4 = opt.device_step(4, X2, Y2, nxt=named)
+            with _hip.KernelTimer() as k5:
+                lc5, lg5 = opt.device_step(5, X, Y)
+            opt.wait_updates(); torch.cuda.synchronize()
+            assert lg4 is None and lg5 is not None
+            results[what] = (float(lc4), float(lc5), float(lg5), opt.critic_opti.flat.grad.detach().clone(), opt.gen_opti.flat.grad.detach().clone(),
+                             opt.critic_opti.flat.flat.detach().clone(), opt.gen_opti.flat.flat.detach().clone(), [t.detach().clone() for t in moving],
+                             [r[0] for r in k4.records].count('ptts_lstm_fwd'), [r[0] for r in k5.records].count('ptts_lstm_fwd'))
+    finally:
+        restore()
+        opt.generator_updates = gu0
+    ref = results['plain']
+    assert (ref[8], ref[9]) == (0, 1)
+    assert (results['ahead'][8], results['ahead'][9]) == (1, 0)                          # the recurrence ran one batch early, and once
+    assert (results['ahead of another batch'][8], results['ahead of another batch'][9]) == (1, 1)      # dropped and done again on the batch that came
+    for what in ('ahead', 'ahead of another batch'):
+        r = results[what]
+        for i in range(3):
+            assert abs(r[i] - ref[i]) <= 1e-4 * max(1.0, abs(ref[i])), (what, i, r[i], ref[i])
+        assert rel_l2(r[3], ref[3]) < 3e-4, (what, rel_l2(r[3], ref[3]))
+        assert rel_l2(r[4], ref[4]) < 1e-3, (what, rel_l2(r[4], ref[4]))
+        # both networks' weights after the two batches (Adam's first steps are sign-like -- an element whose gradient is noise moves by
+        # +- the learning rate either way -- so: as a norm over the network)
+        assert rel_l2(r[5], ref[5]) < 1e-3, (what, rel_l2(r[5], ref[5]))
+        assert rel_l2(r[6], ref[6]) < 1e-3, (what, rel_l2(r[6], ref[6]))
+        for a, b in zip(r[7], ref[7]):
+            close(a, b, 1e-5, 1e-6, 'BatchNorm moving statistics after two batches (' + what + ')')
+
+
 def test_train_step_with_the_bf16x6_context_conv_matches_the_fp32_one(setup):
     """device_step at BASELINE configs[1] sizes with the context-Conv1D forward as a bf16x6 split product in the time domain
     (cfg.train_wgan_split_bf16, csrc/split.hip) and in the frequency domain (ops._C1FFT, the default) against the same step on

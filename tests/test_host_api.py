@@ -275,3 +275,25 @@ def test_batch_prefetcher_host_mode_order_and_errors():
     with pytest.raises(IOError):
         next(it)
     it.close()
+
+
+def test_training_loop_names_the_next_batch():
+    """optimizertts._with_next: the batch loop of train_oneparamset sees (index, batch, next batch or None) -- the very objects the
+    prefetcher yields, so that OptimizerTTSWGAN.hint_next_batch can recognise the batch when it comes (device_step's look-ahead)."""
+    from percivaltts_amd import data
+    from percivaltts_amd.optimizertts import _with_next
+
+    assert list(_with_next([])) == []
+    assert list(_with_next(['a'])) == [(0, 'a', None)]
+    assert list(_with_next('abc')) == [(0, 'a', 'b'), (1, 'b', 'c'), (2, 'c', None)]
+    items = list(_with_next(data.BatchPrefetcher(lambda i: (np.full(2, float(i), dtype=np.float32),), 4, device=None, depth=2)))
+    assert [i for i, _, _ in items] == [0, 1, 2, 3] and items[-1][2] is None
+    for (i, cur, nx), (_, cur1, _) in zip(items[:-1], items[1:]):
+        assert nx is cur1 and float(cur[0][0]) == float(i)          # identity, not equality: the optimiser compares with `is`
+    # the base optimiser ignores the hint; the WGAN optimiser keeps it for the next train_on_batch only
+    assert optimizertts.OptimizerTTS.hint_next_batch(None, 1, 2) is None
+    class W(optimizertts_wgan.OptimizerTTSWGAN):
+        def __init__(self): pass
+    w = W()
+    w.hint_next_batch('x', 'y'); assert w._next_batch == ('x', 'y')
+    w.hint_next_batch(None, None); assert w._next_batch is None
