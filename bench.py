@@ -364,6 +364,7 @@ def build_optimizer(args, ctx, spec, nm, batch, errtype, gated=False, bf16=None,
     cfg.train_wgan_early_critic = not args.no_early_critic
     cfg.train_wgan_hoist_generator = (not args.no_hoist) and os.environ.get('PTTS_HOIST', '1') == '1'
     cfg.train_wgan_generator_lookahead = (not getattr(args, 'no_lookahead', False)) and os.environ.get('PTTS_LOOKAHEAD', '1') == '1'
+    cfg.train_wgan_fake_ahead = os.environ.get('PTTS_FAKE_AHEAD', '0') == '1'          # (A/B switch)
     cfg.train_wgan_hoist_side_backward = os.environ.get('PTTS_HOIST_SIDE_BWD', '1') == '1'      # (A/B switch)
     cfg.train_wgan_side_backward_first = os.environ.get('PTTS_SIDE_BWD_FIRST', '0') == '1'     # (A/B switch) the BLSTM's autograd node created last
     cfg.train_wgan_split_bf16 = not args.fp32_mfma
@@ -633,6 +634,7 @@ def main():
                        'stack_real_fake_critic_pass': bool(cfg.train_wgan_stack_real_fake),
                        'reuse_generator_ctx_conv_within_train_on_batch': bool(cfg.train_wgan_reuse_ctx_conv),
                        'generator_forward_hoisted_before_the_critic_step': bool(cfg.train_wgan_hoist_generator),
+                       'fake_sample_one_batch_ahead_on_a_side_stream': bool(cfg.train_wgan_fake_ahead),
                        'generator_forward_one_batch_ahead': bool(cfg.train_wgan_hoist_generator and cfg.train_wgan_generator_lookahead),
                        'ctx_conv1d_forward_and_weight_gradient': (('frequency domain (DFT, per-frequency products, inverse DFT; correlation theorem for the weight gradient), every product a '
                                                                    if (ops._C1FFT.enabled and not cfg.train_wgan_bf16_products) else '') + 'bf16x6 split (bf16 MFMA, fp32 accumulate)'

@@ -135,6 +135,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         cfg.train_wgan_parallel_streams = False      # the critic evaluations on separate HIP streams
         cfg.train_wgan_side_backward_first = False   # generator step: the BLSTM's autograd node created last (its launches go out first), so that its backward chain is enqueued first.  Measured: the chain then ends 1 ms earlier, the step does not (the main stream's backward becomes the tail): off
         cfg.train_wgan_stack_real_fake = True        # critic(real) and critic(fake) as one stacked 2B pass (exact: no BatchNorm)
+        cfg.train_wgan_fake_ahead = False            # (measured, off) the frozen generator's sample of the NEXT critic-only batch drawn on a side stream beside this batch's critic step: cycle 29.55 -> 29.85 ms -- the step's graph then transforms the context input a second time, and the overlap does not pay for it
         cfg.train_wgan_generator_lookahead = True    # a generator step's forward launched one batch ahead when the caller names the next batch (hint_next_batch / device_step(nxt=...))
         cfg.train_wgan_pair_forward = True           # critic step: the forward of the stacked real / fake batch (2B) and of x^ (B) as ONE launch per layer over 3B rows (their backward passes stay separate)
         cfg.train_wgan_ctx_stream = False            # critic step: the context branch on a side stream beside the spectral stacks (one fork / join per pass; measured, see DESIGN)
@@ -734,14 +735,15 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             if nxt is None:
                 nxt, self._next_batch = getattr(self, '_next_batch', None), None
             next_gen = nxt is not None and not gen_too and (batchid + 1) % critic_runs == 0
-            lc, lg = self._batch_steps(X, Y, alpha, gen_too, graph_c, graph_g, nxt if next_gen else None)
+            lc, lg = self._batch_steps(X, Y, alpha, gen_too, graph_c, graph_g, nxt if next_gen else None,
+                                       nxt if (nxt is not None and not gen_too and not next_gen) else None)
             if gen_too:
                 self.generator_updates += 1
         finally:
             ops.conv1d_cache(False)
         return lc, lg
 
-    def _batch_steps(self, X, Y, alpha, gen_too, graph_c, graph_g, nxt=None):
+    def _batch_steps(self, X, Y, alpha, gen_too, graph_c, graph_g, nxt=None, nxt_critic=None):
         """The steps of one train_on_batch: critic step, and the generator step when `gen_too` (its forward hoisted in front of the
         critic step -- or of the previous batch's critic step, see device_step -- by generator_forward_early)."""
         pre = fake = None
@@ -763,6 +765,15 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
                     pre = self.generator_forward_early(X, Y, training=True)
                     self._gen_deferred = ops.deferred_detach()      # (joined and flushed by the generator step's own context)
             fake = self.fake_from_early(X, pre)
+        fa, self._fake_ahead = getattr(self, '_fake_ahead', None), None
+        if fa is not None and fake is None and fa['X'] is X and fa['epoch'] == self.gen_opti.flat.epoch:
+            # the frozen generator's sample of this batch was drawn one batch ago on a side stream (below)
+            cur = torch.cuda.current_stream()
+            cur.wait_event(fa['event'])
+            fake = fa['fake']
+            fake.record_stream(cur)
+        if nxt_critic is not None and bool(getattr(self.cfg, 'train_wgan_fake_ahead', False)):
+            self._fake_sample_ahead(nxt_critic[0])
         if nxt is not None and hoist and bool(getattr(self.cfg, 'train_wgan_generator_lookahead', True)) and \
                 not self._use_graph(nxt[0], 'generator', nxt[1]):
             # the NEXT batch trains the generator: its forward goes out now, in front of this batch's critic step
@@ -791,6 +802,23 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             else:
                 lg = self.generator_step(X, Y) if pre is None else self.generator_step(X, Y, pre)
         return lc, lg
+
+    def _fake_sample_ahead(self, Xn):
+        """The next batch trains the critic alone and the generator is not updated before it: the frozen generator's sample of THAT batch
+        (reference optimizertts_wgan.py:126-131 -- it depends on the generator's weights and the batch's labels only) is drawn now, on a
+        side stream, beside this batch's critic step instead of in front of the next one.  The critic step's launches are single-round
+        and latency-bound: a second, independent chain of launches fills the compute units they leave idle.  The
+        step's own stream -- and its hipGraph, which then takes the sample as an input -- stays a single stream."""
+        cur = torch.cuda.current_stream()
+        self._wait_update('generator')                  # on the step's stream (the pending update is known to ONE waiter) ...
+        side = getattr(self, '_fake_stream', None)
+        if side is None:
+            side = self._fake_stream = kl.side_streams(2)[0]       # (an existing one: every stream created costs every later launch)
+        side.wait_stream(cur)                           # ... and the side stream behind it
+        with torch.cuda.stream(side):
+            f = self._fake_sample(Xn, True)
+            ev = side.record_event()
+        self._fake_ahead = {'X': Xn, 'fake': f, 'event': ev, 'epoch': self.gen_opti.flat.epoch}
 
     def _drop_ahead(self, ahead):
         """A generator forward launched one batch ahead for a batch that did not come (the caller named another one, the weights were
