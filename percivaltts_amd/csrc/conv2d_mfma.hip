@@ -78,6 +78,12 @@ constexpr int DBG_FOUR_WAVES = 1 << 16;      // host side only: launch the four-
 #ifndef C2M_BW_WREG
 #define C2M_BW_WREG 1      // fused backward kernel: the convolution's table fragments from global memory / registers (1) or from a copy in the LDS (0)
 #endif
+#ifndef C2M_PROBE_STAMPS
+#define C2M_PROBE_STAMPS 0   // (probe build: s_memtime stamps inside the wave-specialised forward kernel's piece loop; needs a debug buffer of 16 words per workgroup)
+#endif
+#ifndef C2M_PROBE_BREUSE
+#define C2M_PROBE_BREUSE 0   // (timing probe, tools/ab_file.sh: garbage results)
+#endif
 #ifndef C2M_PIN_WF
 // 1: the wave-specialised kernels' table fragments pinned in registers by an empty asm.  The table is `const __restrict__`, and the
 // compiler RE-LOADS the lane's fifteen fragments from global memory (L2) in every pass instead of keeping 60 registers -- which is the
@@ -256,6 +262,37 @@ __device__ __forceinline__ Work next_work(const Shape& s, const Sched& c, int wg
     return w;
 }
 
+// The same list, walked: next() fills the position of the next non-empty item.  The whole tiles of the full rounds -- all but the
+// last item of a workgroup when the first tile is not cut (FS == 1) and a row is one block (nfb == 1: F <= 68) -- are wg, wg + G,
+// wg + 2 G, ...: their (utterance, time tile) advance by (G / ntt, G % ntt) with one carry, a handful of scalar instructions.  The
+// general path costs ~100 scalar instructions and a dozen branches per item, which the wave-specialised kernels' multiplying waves
+// -- ONE per SIMD, nothing else feeds the matrix pipe meanwhile -- paid between every two pieces: 0.39 of the 2.6 us a piece of the
+// forward kernel took (s_memtime stamps, tools/c2m_ws_stamps.py).
+struct PieceWalk {
+    int it, nitems, nwhole, b, tb, db, dtb, TF;
+    __device__ __forceinline__ void init(const Shape& s, const Sched& c, int wg, int nitems_) {
+        it = -1; nitems = nitems_;
+        nwhole = (c.FS == 1 && s.nfb == 1 && c.R >= 1) ? min(c.R, nitems_) : 0;
+        b = s.ntt > 1 ? (int)__umulhi((unsigned)wg, s.magic_ntt) : wg; tb = wg - b * s.ntt;
+        db = s.ntt > 1 ? (int)__umulhi((unsigned)c.G, s.magic_ntt) : c.G; dtb = c.G - db * s.ntt;
+        TF = s.T * s.F;
+    }
+    __device__ __forceinline__ bool next(const Shape& s, const Sched& c, int wg, TilePos& p) {
+        if (it + 1 < nwhole) {
+            if (++it > 0) {
+                b += db; tb += dtb;
+                if (tb >= s.ntt) { tb -= s.ntt; ++b; }
+            }
+            p.img = (long long)b * TF; p.t0 = tb * 16; p.g_base = 0; p.ng = min(GPB, s.NG);
+            return true;
+        }
+        const Work w = next_work(s, c, wg, it, nitems);
+        if (w.ng <= 0) return false;
+        p = work_pos(s, w);
+        return true;
+    }
+};
+
 // What a lane needs to know about its NB staging slots, computed once per workgroup (tile-independent):
 // slot idx = tid + 256 u -> staged row r = idx / SB, staged bin c = idx % SB
 template <class ST>
@@ -386,6 +423,8 @@ __device__ __forceinline__ void fwd_pass(const u16* __restrict__ planes, const u
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             mv[j] = f32x4{1.f, 1.f, 1.f, 1.f};
+            // (inside the branch on purpose: loaded unconditionally from a clamped position the backward-data launch measured 54.6 -> 65.7 us
+            // at [192,400,65,4] -- the compiler then counts the loads exactly and lets the stores overtake, tools/c2m_ws_phases.py)
             if (rowok && f0 + 4 * j < F) mv[j] = load_px(mrow, (f0 + 4 * j) * C, out_bf16);
         }
     }
@@ -408,8 +447,18 @@ __device__ __forceinline__ void fwd_pass(const u16* __restrict__ planes, const u
 #pragma unroll
         for (int j = 0; j < N; ++j)
 #pragma unroll
-            for (int p = 0; p < NPL; ++p)
+            for (int p = 0; p < NPL; ++p) {
+                if (C2M_PROBE_BREUSE && kt > 0) {
+                    // (timing probe only, wrong results: what the pass costs if the fragments of rows kt > 0 came out of registers -- one
+                    // vector move per register -- instead of out of the LDS)
+                    u32x4v v = __builtin_bit_cast(u32x4v, bq[(kt + 1) & 1][j][p]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_update_dpp(v[e], v[e], 0x101, 0xf, 0xf, false);
+                    br[j][p] = __builtin_bit_cast(bf16x8, v);
+                    continue;
+                }
                 br[j][p] = *reinterpret_cast<const bf16x8*>(((j & 1) ? b1 : b0) + p * ST::PS + kt * DIL * ST::RS + (j >> 1) * 32);
+            }
     };
     read_row(0, a[0], bq[0]);
 #pragma unroll
@@ -459,7 +508,7 @@ __device__ __forceinline__ void fwd_piece(const u16* __restrict__ planes, const 
     const void* mrow = OUTMASK ? ptr_at(out_mask, rowoff, out_bf16) : nullptr;
     const int fbase = 4 * cur.g_base;
     while (n > 0) {
-        const int m = (n + npass - 1) / npass;
+        const int m = npass == 1 ? n : (npass == 2 ? (n + 1) >> 1 : (n + npass - 1) / npass);      // (the division is ~35 scalar instructions)
 #define C2M_PASS(NN) fwd_pass<ST, DIL, NN, OUTMASK, NPL, WREG>(planes, wl, wf, gl, lane, bv, mrow, yrow, out_bf16, fbase, s.F, rowok, alpha, store)
         switch (m) {
             case 1: C2M_PASS(1); break;
@@ -629,16 +678,12 @@ __global__ __launch_bounds__((NMW + 4) * 64, 1) void fwd_ws_kernel(
     bf16x8 wf[KT][NPL];
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     const int wg = blockIdx.x, nitems = sched_items(sc, wg);
-    int item = -1;
-    Work w0 = next_work(s, sc, wg, item, nitems);
-    bool havecur = w0.ng > 0;
-    TilePos cur = work_pos(s, w0), nxt = cur;
-    bool havenxt = false;
-    if (havecur) {
-        const Work w1 = next_work(s, sc, wg, item, nitems);
-        havenxt = w1.ng > 0;
-        if (havenxt) nxt = work_pos(s, w1);
-    }
+    PieceWalk walk;
+    walk.init(s, sc, wg, nitems);
+    TilePos cur = {0, 0, 0, 0};
+    bool havecur = walk.next(s, sc, wg, cur);
+    TilePos nxt = cur;
+    bool havenxt = havecur && walk.next(s, sc, wg, nxt);
     if (stager) {
         sl.init(tid - NMW * 64);
         if (havecur && stage) {
@@ -656,9 +701,16 @@ __global__ __launch_bounds__((NMW + 4) * 64, 1) void fwd_ws_kernel(
             for (int q = 0; q < NPL; ++q) {
                 const u16* wp = wa + (kt * NPL + q) * TKP;
                 wf[kt][q] = cat(*reinterpret_cast<const bf16x4*>(wp), *reinterpret_cast<const bf16x4*>(wp + 4));
-                if (C2M_PIN_WF) asm volatile("" : "+v"(wf[kt][q]));      // (C2M_PIN_WF, off: see its definition)
+                if (C2M_PIN_WF == 1) asm volatile("" : "+v"(wf[kt][q]));      // (C2M_PIN_WF: see its definition)
             }
         if (bias) bv = *reinterpret_cast<const f32x4*>(bias);
+        if (C2M_PIN_WF == 2) {
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) asm volatile("" : "+v"(wf[kt][q]));
+            asm volatile("" : "+v"(bv));
+        }
     }
     // Hand-off of the plane buffers by COUNTERS in the LDS instead of a workgroup barrier per piece (C2M_WS_FLAGS): piece p lives in
     // buffer p & 1, use u = p >> 1.  ready[b] counts the staging waves' commits into buffer b, done[b] the multiplying waves that have
@@ -695,30 +747,39 @@ __global__ __launch_bounds__((NMW + 4) * 64, 1) void fwd_ws_kernel(
     __syncthreads();
     stamp(dbg_buf, dbg, 2);
     int it = 0;
+#if C2M_PROBE_STAMPS
+    // (probe build, tools/c2m_ws_stamps.py) the timeline of piece 3 of every workgroup: wave 0 (multiplying) slots 0..4, wave NMW (staging) 8..12
+#define C2M_TS(SLOT) do { if (dbg_buf != nullptr && it == 3 && lane == 0 && (wave8 == 0 || wave8 == NMW)) dbg_buf[(size_t)blockIdx.x * 16 + (wave8 ? 8 : 0) + (SLOT)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define C2M_TS(SLOT) do { } while (0)
+#endif
     while (havecur) {
+        C2M_TS(0);
         // piece it + 2 (every wave walks the same list)
-        bool have2 = false;
         TilePos p2 = nxt;
-        if (havenxt) {
-            const Work w2 = next_work(s, sc, wg, item, nitems);
-            have2 = w2.ng > 0;
-            if (have2) p2 = work_pos(s, w2);
-        }
+        const bool have2 = havenxt && walk.next(s, sc, wg, p2);
         if (stager) {
             u16* pnxt = planes + ((it + 1) & 1) * NPL * ST::PS;       // every multiplying wave left it at the last barrier / its done count
             if (havenxt) {
                 if (C2M_WS_FLAGS) wait_for(2 + ((it + 1) & 1), NMW * ((it + 1) >> 1));
+                C2M_TS(1);
                 if (stage)
                     pref_commit<ST, MODE, NPL>(pf, sl, pnxt, nxt.t0 - s.pad_t, 4 * nxt.g_base - 2, s.T, s.F, in_scale, in_shift, alpha, 0, 0, nullptr);
+                C2M_TS(2);
                 if (C2M_WS_FLAGS) signal((it + 1) & 1);
+                C2M_TS(3);
             }
             if (have2 && stage)
                 pref_load<ST, MASK>(pf, sl, x, mask_src, in_bf16, p2.img, p2.t0 - s.pad_t, 4 * p2.g_base - 2, s.T, s.F, s.F, 4 * p2.ng + 4);
+            C2M_TS(4);
         } else {
             const u16* pcur = planes + (it & 1) * NPL * ST::PS;
             if (C2M_WS_FLAGS) wait_for(it & 1, 4 * ((it >> 1) + 1));
+            C2M_TS(1);
             fwd_piece<ST, DIL, OUTMASK, MASK, NPL, true, NMW, (NMW == 8 ? 2 : C2M_WS_NMAX)>(pcur, nullptr, wf, cur, s, wave, lane, it, bv, out_mask, y, out_bf16, alpha, store, nomfma);
+            C2M_TS(2);
             if (C2M_WS_FLAGS) signal(2 + (it & 1));
+            C2M_TS(3);
         }
         if (it == 0) stamp(dbg_buf, dbg, 3);
         if (!C2M_WS_FLAGS) __syncthreads();
@@ -969,16 +1030,18 @@ __global__ __launch_bounds__((SPLIT ? 12 : 8) * 64, 1) void bwd_ws_kernel(
             pref_commit<SQ, MODE_Q, NPL>(pq, slq, buf + NPL * SP::PS, KIND == 1 ? p.t0 : p.t0 - lo, 4 * p.g_base - 2, s.T, s.F, nullptr, nullptr, alpha, 0, 0, nullptr);
         };
         const bool stage = !(dbg & DBG_NOSTAGE);              // (measurement hooks of tools/c2m_fused_probe2.py: garbage results)
-        int item = -1, it = 0;
-        Work w = next_work(s, sc, wg, item, nitems);
-        if (w.ng > 0 && stage) load_piece(work_pos(s, w));
-        while (w.ng > 0) {
-            const TilePos p = work_pos(s, w);
+        int it = 0;
+        PieceWalk walk;
+        walk.init(s, sc, wg, nitems);
+        TilePos p = {0, 0, 0, 0};
+        bool have = walk.next(s, sc, wg, p);
+        if (have && stage) load_piece(p);
+        while (have) {
             wait_for(2 + (it & 1), NCW * (it >> 1));
             if (stage) commit_piece(p, lds + (it & 1) * BUF);
             signal(it & 1);
-            w = next_work(s, sc, wg, item, nitems);
-            if (w.ng > 0 && stage) load_piece(work_pos(s, w));
+            have = walk.next(s, sc, wg, p);
+            if (have && stage) load_piece(p);
             ++it;
         }
         __syncthreads();
@@ -997,20 +1060,28 @@ __global__ __launch_bounds__((SPLIT ? 12 : 8) * 64, 1) void bwd_ws_kernel(
                     for (int q = 0; q < NPL; ++q) {
                         const u16* wp = wa + (kt * NPL + q) * TKP;
                         wf[kt][q] = cat(*reinterpret_cast<const bf16x4*>(wp), *reinterpret_cast<const bf16x4*>(wp + 4));
-                        if (C2M_PIN_WF) asm volatile("" : "+v"(wf[kt][q]));      // (off: see its definition)
+                        if (C2M_PIN_WF == 1) asm volatile("" : "+v"(wf[kt][q]));      // (see its definition)
                     }
+                if (C2M_PIN_WF == 2) {
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                        for (int q = 0; q < NPL; ++q) asm volatile("" : "+v"(wf[kt][q]));
+                }
             }
             const f32x4 bv0 = {0.f, 0.f, 0.f, 0.f};
-            int item = -1, it = 0;
-            Work w = next_work(s, sc, wg, item, nitems);
-            while (w.ng > 0) {
-                const TilePos cur = work_pos(s, w);
+            int it = 0;
+            PieceWalk walk;
+            walk.init(s, sc, wg, nitems);
+            TilePos cur = {0, 0, 0, 0};
+            bool have = walk.next(s, sc, wg, cur);
+            while (have) {
                 const u16* pcur = lds + (it & 1) * BUF;
                 wait_for(it & 1, 4 * ((it >> 1) + 1));
                 fwd_piece<SP, DIL, OUTMASK, PMASK, NPL, C2M_BW_WREG != 0, NMW, C2M_BW_NMAX>(pcur, wl, wf, cur, s, wave, lane, it, bv0, qsrc, y, false, alpha, !(dbg & DBG_NOSTORE), (dbg & (DBG_NOMFMA | 16)) != 0);
                 also(cur, pcur, it);
                 signal(2 + (it & 1));
-                w = next_work(s, sc, wg, item, nitems);
+                have = walk.next(s, sc, wg, cur);
                 ++it;
             }
         };
@@ -1072,15 +1143,17 @@ __global__ __launch_bounds__((SPLIT ? 12 : 8) * 64, 1) void bwd_ws_kernel(
         } else if (do_conv) {
             conv_role([](const TilePos&, const u16*, int) {});
         } else {
-            int item = -1, it = 0;
-            Work w = next_work(s, sc, wg, item, nitems);
-            while (w.ng > 0) {
-                const TilePos cur = work_pos(s, w);
+            int it = 0;
+            PieceWalk walk;
+            walk.init(s, sc, wg, nitems);
+            TilePos cur = {0, 0, 0, 0};
+            bool have = walk.next(s, sc, wg, cur);
+            while (have) {
                 const u16* pcur = lds + (it & 1) * BUF;
                 wait_for(it & 1, 4 * ((it >> 1) + 1));
                 wgrad_piece(cur, pcur, it);
                 signal(2 + (it & 1));
-                w = next_work(s, sc, wg, item, nitems);
+                have = walk.next(s, sc, wg, cur);
                 ++it;
             }
         }

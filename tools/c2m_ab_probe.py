@@ -13,7 +13,7 @@ def t_us(fn, n=40):
     return s.elapsed_time(e) / n * 1e3
 g = torch.Generator().manual_seed(3)
 out = []
-for B in (64, 128):
+for B in (64, 128, 192):
     x = torch.randn(B, 400, 65, 4, generator=g).cuda(); dy = torch.randn(B, 400, 65, 4, generator=g).cuda()
     w = (torch.randn(5, 5, 4, 4, generator=g) * 0.2).cuda()
     tf, tb = ops._C2M.table(w, False), ops._C2M.table(w, True)
