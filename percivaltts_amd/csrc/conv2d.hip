@@ -1115,24 +1115,42 @@ constexpr int RG_MAX = 16;
 struct ReduceGroupArgs {
     int n;
     int col_begin[RG_MAX + 1];
-    const float* partials[RG_MAX]; int nblocks[RG_MAX], npart[RG_MAX], nw[RG_MAX];
+    const float* partials[RG_MAX]; int nblocks[RG_MAX], npart[RG_MAX], nw[RG_MAX], ncout[RG_MAX];
     float* dw[RG_MAX]; float* dbias[RG_MAX];
 };
 
-__global__ __launch_bounds__(256) void conv2d_reduce_grouped_kernel(ReduceGroupArgs a) {
-    __shared__ double sh[4];
+// block -> (pass, chunk of RG_COLS consecutive columns, slab of RG_SLAB rows of partial sums); thread (column cx, row phase ry): the rows
+// are read as whole 256-byte runs (one workgroup per COLUMN, as in rounds 1-3, fetched a 64-byte sector per 4-byte value: 20.8 us for
+// 6.7 MB at the critic's 16 queued passes).  The slabs bound a thread's run of dependent iterations whatever the number of rows
+// (256 for the persistent matrix-core kernels, one per tile -- thousands -- for the 1 -> 4 layer's).
+constexpr int RG_COLS = 64, RG_ROWS = 4, RG_SLAB = 128;
+__global__ __launch_bounds__(RG_COLS * RG_ROWS) void conv2d_reduce_grouped_kernel(ReduceGroupArgs a) {
+    __shared__ double sh[RG_ROWS][RG_COLS];
     int gi = 0;
-    while ((int)blockIdx.x >= a.col_begin[gi + 1]) ++gi;
-    const int j = blockIdx.x - a.col_begin[gi];
-    const float* p = a.partials[gi];
-    const int npart = a.npart[gi], nblocks = a.nblocks[gi];
-    double s = 0.0;
-    for (int blk = threadIdx.x; blk < nblocks; blk += 256) s += (double)p[(size_t)blk * npart + j];
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    while ((int)blockIdx.x >= a.col_begin[gi + 1]) ++gi;            // (col_begin counts (chunk, slab) items here)
+    const int cx = threadIdx.x & (RG_COLS - 1), ry = threadIdx.x / RG_COLS;
+    const int npart = a.npart[gi], nblocks = a.nblocks[gi], ncols = a.nw[gi] + a.ncout[gi];
+    const int nchunks = (ncols + RG_COLS - 1) / RG_COLS, r = blockIdx.x - a.col_begin[gi];
+    const int slab = r / nchunks, j = (r - slab * nchunks) * RG_COLS + cx;
+    const int row_end = min(nblocks, (slab + 1) * RG_SLAB);
+    const float* p = a.partials[gi] + j;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (j < ncols) {
+        int blk = slab * RG_SLAB + ry;
+        for (; blk + 3 * RG_ROWS < row_end; blk += 4 * RG_ROWS) {
+            const float v0 = p[(size_t)blk * npart], v1 = p[(size_t)(blk + RG_ROWS) * npart];
+            const float v2 = p[(size_t)(blk + 2 * RG_ROWS) * npart], v3 = p[(size_t)(blk + 3 * RG_ROWS) * npart];
+            s0 += (double)v0; s1 += (double)v1; s2 += (double)v2; s3 += (double)v3;
+        }
+        for (; blk < row_end; blk += RG_ROWS) s0 += (double)p[(size_t)blk * npart];
+    }
+    sh[ry][cx] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const float v = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+    if (ry == 0 && j < ncols) {
+        double t = sh[0][cx];
+#pragma unroll
+        for (int q = 1; q < RG_ROWS; ++q) t += sh[q][cx];
+        const float v = (float)t;
         if (j < a.nw[gi]) { if (a.dw[gi]) atomicAdd(a.dw[gi] + j, v); }
         else if (a.dbias[gi]) atomicAdd(a.dbias[gi] + (j - a.nw[gi]), v);
     }
@@ -1149,12 +1167,12 @@ extern "C" int ptts_conv2d_reduce_grouped(const ptts_conv2d_reduce_desc* descs, 
             PTTS_REQUIRE(d.partials && d.nblocks > 0 && d.nw > 0 && d.cout > 0 && d.npart >= d.nw + d.cout,
                          "conv2d_reduce_grouped: bad pass %d", base + i);
             a.col_begin[i] = cols;
-            cols += d.nw + d.cout;
-            a.partials[i] = d.partials; a.nblocks[i] = d.nblocks; a.npart[i] = d.npart; a.nw[i] = d.nw;
+            cols += ((d.nw + d.cout + RG_COLS - 1) / RG_COLS) * ((d.nblocks + RG_SLAB - 1) / RG_SLAB);
+            a.partials[i] = d.partials; a.nblocks[i] = d.nblocks; a.npart[i] = d.npart; a.nw[i] = d.nw; a.ncout[i] = d.cout;
             a.dw[i] = d.dw; a.dbias[i] = d.dbias;
         }
         a.col_begin[a.n] = cols;
-        hipLaunchKernelGGL(conv2d_reduce_grouped_kernel, dim3(cols), dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(conv2d_reduce_grouped_kernel, dim3(cols), dim3(RG_COLS * RG_ROWS), 0, (hipStream_t)stream, a);
         int rc = check_launch("conv2d_reduce_grouped");
         if (rc) return rc;
     }
