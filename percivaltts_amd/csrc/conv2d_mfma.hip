@@ -78,6 +78,9 @@ constexpr int DBG_FOUR_WAVES = 1 << 16;      // host side only: launch the four-
 #ifndef C2M_BW_WREG
 #define C2M_BW_WREG 1      // fused backward kernel: the convolution's table fragments from global memory / registers (1) or from a copy in the LDS (0)
 #endif
+#ifndef C2M_PROBE_COMMIT
+#define C2M_PROBE_COMMIT 0   // (timing probes of the staging waves' commit: 1 = no LDS writes, 2 = no conversions; garbage results)
+#endif
 #ifndef C2M_PROBE_STAMPS
 #define C2M_PROBE_STAMPS 0   // (probe build: s_memtime stamps inside the wave-specialised forward kernel's piece loop; needs a debug buffer of 16 words per workgroup)
 #endif
@@ -295,10 +298,21 @@ struct PieceWalk {
 
 // What a lane needs to know about its NB staging slots, computed once per workgroup (tile-independent):
 // slot idx = tid + 256 u -> staged row r = idx / SB, staged bin c = idx % SB
+constexpr int ROWS_OOB = (int)0x80000000u;      // a byte offset no image reaches (pref_load_rows wants T F 16 < 2^30)
 template <class ST>
 struct Slots {
     int rc[ST::NB];        // r << 8 | c, or -1 for a slot beyond the tile
     int dst[ST::NB];       // LDS element offset inside a plane
+    int boff[ST::NB];      // (init_rows) byte offset of the slot's pixel from (staged row 0, bin 0 of the image), or ROWS_OOB
+    // Tiles that span whole rows of the image (one block per row: F <= 68): a slot's bin does not depend on the tile, so its
+    // byte offset from the tile's first row is fixed and "this bin is outside the image" is a property of the slot -- see pref_load_rows
+    __device__ __forceinline__ void init_rows(int F) {
+#pragma unroll
+        for (int u = 0; u < ST::NB; ++u) {
+            const int r = rc[u] >> 8, c = rc[u] & 255;
+            boff[u] = (rc[u] >= 0 && c >= 2 && c - 2 < F) ? (r * F + c - 2) * (C * 4) : ROWS_OOB;
+        }
+    }
     __device__ __forceinline__ void init(int t = threadIdx.x) {
 #pragma unroll
         for (int u = 0; u < ST::NB; ++u) {
@@ -350,14 +364,66 @@ __device__ __forceinline__ void pref_load(Pref<ST::NB, MASK>& pf, const Slots<ST
     }
 }
 
+// The same loads for a tile that spans whole rows of an fp32 image (f_org == -2, every bin of the image staged), as RAW BUFFER loads
+// over the utterance [T][F][4]: a 16-byte load whose byte offset lies outside [0, T F 16) returns zeros (checked on gfx950 for negative,
+// straddling and far offsets: tools/hip/buffer_oob_test.hip), so rows above and below the utterance need no test, and the bins left and
+// right of it carry the out-of-range offset in their slot.  One add and one load per slot -- the general form spends four compares,
+// a branch and a 64-bit address on each, and the staging waves, which bound the second-order launch and the forward pass
+// (tools/c2m_fused_stamps.py), spent a fifth of their loop ISSUING loads.
+typedef unsigned u32x4r __attribute__((ext_vector_type(4)));
+template <class ST, bool MASK>
+__device__ __forceinline__ void pref_load_rows(Pref<ST::NB, MASK>& pf, const Slots<ST>& sl, const void* __restrict__ src,
+                                               const void* __restrict__ msk, long long img, int t_org, int T, int F) {
+    const int nbytes = T * F * (C * 4), tb = t_org * F * (C * 4);
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(reinterpret_cast<const float*>(src)) + img * C, 0, nbytes, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < ST::NB; ++u)
+        pf.v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, sl.boff[u] + tb, 0, 0));
+    if (MASK) {
+        __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(reinterpret_cast<const float*>(msk)) + img * C, 0, nbytes, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < ST::NB; ++u)
+            pf.m[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, sl.boff[u] + tb, 0, 0));
+    }
+}
+// One slot of the same loads, as an object: pref_commit calls it for slot u right after it has consumed that slot's registers, with
+// the tile AFTER the one being committed.  The loads of a tile are then in flight for a whole piece time; issued all together behind
+// the commit they had only the staging wave's wait for its buffer (0.2-0.3 us) before the next commit needed them -- the "commit" of
+// the stamps was, for half of its time, a wait for HBM.
+struct NoReload {
+    template <class P> __device__ __forceinline__ void operator()(P&, int) const {}
+};
+template <class ST, bool MASK>
+struct RowsReload {
+    __amdgpu_buffer_rsrc_t rs, rm;
+    int tb;
+    const Slots<ST>* sl;
+    __device__ __forceinline__ RowsReload(const Slots<ST>& sl_, const void* src, const void* msk, long long img, int t_org, int T, int F) {
+        const int nbytes = T * F * (C * 4);
+        tb = t_org * F * (C * 4);
+        sl = &sl_;
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(reinterpret_cast<const float*>(src)) + img * C, 0, nbytes, 0x00020000);
+        rm = rs;
+        if (MASK) rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(reinterpret_cast<const float*>(msk)) + img * C, 0, nbytes, 0x00020000);
+    }
+    __device__ __forceinline__ void operator()(Pref<ST::NB, MASK>& pf, int u) const {
+        pf.v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, sl->boff[u] + tb, 0, 0));
+        if (MASK) pf.m[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, sl->boff[u] + tb, 0, 0));
+    }
+};
+// is the piece a whole-row tile of an image small enough for pref_load_rows?
+__device__ __forceinline__ bool rows_tile(const Shape& s, const TilePos& p) {
+    return s.nfb == 1 && p.g_base == 0 && p.ng == s.NG && (long long)s.T * s.F * (C * 4) < (1LL << 30);
+}
+
 // registers -> transform -> three bf16 planes in LDS.  Slots outside the image were loaded as zeros and stay zero under
 // every transform but the BatchNorm-affine one, which gets its own select.  `sum` (optional) accumulates the raw values
 // of staged rows [sum_r0, sum_r0 + 16), staged bins [2, sum_c1).
-template <class ST, int MODE, int NPL>
-__device__ __forceinline__ void pref_commit(const Pref<ST::NB, MODE == PTTS_IN_MASKMUL>& pf, const Slots<ST>& sl,
+template <class ST, int MODE, int NPL, class RL = NoReload>
+__device__ __forceinline__ void pref_commit(Pref<ST::NB, MODE == PTTS_IN_MASKMUL>& pf, const Slots<ST>& sl,
                                             u16* __restrict__ planes, int t_org, int f_org, int T, int F,
                                             const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-                                            float alpha, int sum_r0, int sum_c1, f32x4* sum) {
+                                            float alpha, int sum_r0, int sum_c1, f32x4* sum, const RL& reload = RL()) {
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     const bool affine = MODE == PTTS_IN_LRELU && in_scale != nullptr;
     if (affine) {
@@ -366,8 +432,16 @@ __device__ __forceinline__ void pref_commit(const Pref<ST::NB, MODE == PTTS_IN_M
     }
 #pragma unroll
     for (int u = 0; u < ST::NB; ++u) {
-        if (sl.rc[u] < 0) continue;
+        // Every lane owns its slots u < TOTAL / THREADS; only the last one can lie beyond the tile.  The test is folded away for the others (the
+        // loop is unrolled): with a branch per slot the compiler kept every slot's chain of dependent conversions in a block of its own --
+        // wait for ITS load, convert, three writes -- and a staging wave, alone of its kind on its SIMD, sat out every latency (the commit
+        // of a piece took 2.5 x its instruction count, tools/c2m_fused_stamps.py: the staging waves, not the multiplying ones, bound the
+        // second-order launch and the forward pass).  In one block the chains of different slots interleave.
+        if ((u + 1) * THREADS > ST::TOTAL && sl.rc[u] < 0) { reload(pf, u); continue; }
         f32x4 a = pf.v[u];
+        f32x4 mk = {0.f, 0.f, 0.f, 0.f};
+        if (MODE == PTTS_IN_MASKMUL) mk = pf.m[u];
+        reload(pf, u);                 // (the slot's registers are free: the next tile's load goes out now)
         if (sum) {
             // the block's own pixels only: rows [sum_r0, sum_r0 + 16), staged bins [2, sum_c1) (the rest is halo)
             const int r = sl.rc[u] >> 8, c = sl.rc[u] & 255;
@@ -384,15 +458,27 @@ __device__ __forceinline__ void pref_commit(const Pref<ST::NB, MODE == PTTS_IN_M
             for (int e = 0; e < 4; ++e) a[e] = max_fast(a[e], alpha * a[e]);      // LeakyReLU for 0 <= alpha <= 1
         } else if (MODE == PTTS_IN_MASKMUL) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) a[e] = a[e] * (pf.m[u][e] > 0.f ? 1.f : alpha);
+            for (int e = 0; e < 4; ++e) a[e] = a[e] * (mk[e] > 0.f ? 1.f : alpha);
         }
         u16* d = planes + sl.dst[u];
         if (NPL == 3) {
             bf16x4 h1, h2, h3;
+#if C2M_PROBE_COMMIT == 2
+            // (timing probe, garbage: no conversions -- the raw bits go to the planes)
+            h1 = __builtin_bit_cast(bf16x4, (u32x2){__builtin_bit_cast(unsigned, a[0]), __builtin_bit_cast(unsigned, a[1])});
+            h2 = __builtin_bit_cast(bf16x4, (u32x2){__builtin_bit_cast(unsigned, a[2]), __builtin_bit_cast(unsigned, a[3])});
+            h3 = h1;
+#else
             split3(a, h1, h2, h3);
+#endif
+#if C2M_PROBE_COMMIT == 1
+            // (timing probe, garbage: the conversions without the three LDS writes)
+            asm volatile("" :: "v"(h1), "v"(h2), "v"(h3), "v"(d));
+#else
             *reinterpret_cast<bf16x4*>(d) = h1;
             *reinterpret_cast<bf16x4*>(d + ST::PS) = h2;
             *reinterpret_cast<bf16x4*>(d + 2 * ST::PS) = h3;
+#endif
         } else {
             *reinterpret_cast<bf16x4*>(d) = __builtin_convertvector(a, bf16x4);       // the one rounding of bf16 arithmetic
         }
@@ -684,14 +770,18 @@ __global__ __launch_bounds__((NMW + 4) * 64, 1) void fwd_ws_kernel(
     bool havecur = walk.next(s, sc, wg, cur);
     TilePos nxt = cur;
     bool havenxt = havecur && walk.next(s, sc, wg, nxt);
+    auto stage_load = [&](const TilePos& p) {
+        if (!in_bf16 && rows_tile(s, p)) pref_load_rows<ST, MASK>(pf, sl, x, mask_src, p.img, p.t0 - s.pad_t, s.T, s.F);
+        else pref_load<ST, MASK>(pf, sl, x, mask_src, in_bf16, p.img, p.t0 - s.pad_t, 4 * p.g_base - 2, s.T, s.F, s.F, 4 * p.ng + 4);
+    };
     if (stager) {
         sl.init(tid - NMW * 64);
+        sl.init_rows(s.F);
         if (havecur && stage) {
-            pref_load<ST, MASK>(pf, sl, x, mask_src, in_bf16, cur.img, cur.t0 - s.pad_t, 4 * cur.g_base - 2, s.T, s.F, s.F, 4 * cur.ng + 4);
+            stage_load(cur);
             pref_commit<ST, MODE, NPL>(pf, sl, planes, cur.t0 - s.pad_t, 4 * cur.g_base - 2, s.T, s.F, in_scale, in_shift, alpha, 0, 0, nullptr);
         }
-        if (havenxt && stage)
-            pref_load<ST, MASK>(pf, sl, x, mask_src, in_bf16, nxt.img, nxt.t0 - s.pad_t, 4 * nxt.g_base - 2, s.T, s.F, s.F, 4 * nxt.ng + 4);
+        if (havenxt && stage) stage_load(nxt);
     } else {
         const int li = lane & 15, lg = lane >> 4;
         const u16* wa = tab + (li & 3) * TROW + (2 * lg - (li >> 2) + 3) * C;
@@ -760,17 +850,25 @@ __global__ __launch_bounds__((NMW + 4) * 64, 1) void fwd_ws_kernel(
         const bool have2 = havenxt && walk.next(s, sc, wg, p2);
         if (stager) {
             u16* pnxt = planes + ((it + 1) & 1) * NPL * ST::PS;       // every multiplying wave left it at the last barrier / its done count
+            bool reloaded = false;
             if (havenxt) {
                 if (C2M_WS_FLAGS) wait_for(2 + ((it + 1) & 1), NMW * ((it + 1) >> 1));
                 C2M_TS(1);
-                if (stage)
-                    pref_commit<ST, MODE, NPL>(pf, sl, pnxt, nxt.t0 - s.pad_t, 4 * nxt.g_base - 2, s.T, s.F, in_scale, in_shift, alpha, 0, 0, nullptr);
+                if (stage) {
+                    if (have2 && !in_bf16 && rows_tile(s, p2)) {
+                        // the loads of piece it + 2 slot by slot, each behind the commit of the same slot of piece it + 1
+                        const RowsReload<ST, MASK> rl(sl, x, mask_src, p2.img, p2.t0 - s.pad_t, s.T, s.F);
+                        pref_commit<ST, MODE, NPL>(pf, sl, pnxt, nxt.t0 - s.pad_t, 4 * nxt.g_base - 2, s.T, s.F, in_scale, in_shift, alpha, 0, 0, nullptr, rl);
+                        reloaded = true;
+                    } else {
+                        pref_commit<ST, MODE, NPL>(pf, sl, pnxt, nxt.t0 - s.pad_t, 4 * nxt.g_base - 2, s.T, s.F, in_scale, in_shift, alpha, 0, 0, nullptr);
+                    }
+                }
                 C2M_TS(2);
                 if (C2M_WS_FLAGS) signal((it + 1) & 1);
                 C2M_TS(3);
             }
-            if (have2 && stage)
-                pref_load<ST, MASK>(pf, sl, x, mask_src, in_bf16, p2.img, p2.t0 - s.pad_t, 4 * p2.g_base - 2, s.T, s.F, s.F, 4 * p2.ng + 4);
+            if (have2 && stage && !reloaded) stage_load(p2);
             C2M_TS(4);
         } else {
             const u16* pcur = planes + (it & 1) * NPL * ST::PS;
@@ -959,6 +1057,14 @@ __global__ __launch_bounds__(THREADS, DIL <= 2 ? 2 : 1) void wgrad_kernel(
 // SPLIT (round 4, second form): TWELVE waves -- 0..3 only convolve, 4..7 only run the weight-gradient products, 8..11 stage -- three per SIMD
 // (<= 168 registers each), so that every SIMD has one wave of each kind: a SIMD's single multiplying wave spends as long on its LDS reads as on
 // its MFMAs and nothing overlaps the two (tools/c2m_fused_probe2.py: 5 us per piece for 1.75 us of matrix work).
+#if C2M_PROBE_STAMPS
+// (probe build, tools/c2m_fused_stamps.py) the timeline of piece 3 of every workgroup of the fused backward kernel: wave 0 (multiplying)
+// slots 0..5, the first staging wave 8..12; read back with ptts_conv2d_mfma_probe_stamps
+__device__ unsigned long long g_bw_stamps[256 * 16];
+#define C2M_BTS(SLOT) do { if (it == 3 && lane == 0 && blockIdx.x < 256 && (wave8 == 0 || wave8 == NCW)) g_bw_stamps[blockIdx.x * 16 + (wave8 ? 8 : 0) + (SLOT)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define C2M_BTS(SLOT) do { } while (0)
+#endif
 template <int KIND, int NPL, bool SPLIT>
 __global__ __launch_bounds__((SPLIT ? 12 : 8) * 64, 1) void bwd_ws_kernel(
     const void* __restrict__ psrc, const void* __restrict__ qsrc, const void* __restrict__ mask_src, const u16* __restrict__ tab,
@@ -1012,14 +1118,19 @@ __global__ __launch_bounds__((SPLIT ? 12 : 8) * 64, 1) void bwd_ws_kernel(
     // b (piece p lives in buffer p & 1, use u = p >> 1: a multiplying wave starts it at ready == 4 (u + 1)), done[b] the multiplying
     // waves that have finished with it (a staging wave overwrites it at done == NMW u).
     if (stager) {
-        Slots<SP> slp; slp.init(tid - NCW * 64);
-        Slots<SQ> slq; slq.init(tid - NCW * 64);
+        Slots<SP> slp; slp.init(tid - NCW * 64); slp.init_rows(s.F);
+        Slots<SQ> slq; slq.init(tid - NCW * 64); slq.init_rows(s.F);
         Pref<SP::NB, PMASK> pp;
         Pref<SQ::NB, false> pq;
         f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
         // the two tiles of a piece: P from t0 - lo (20 rows); Q from t0 (KIND 1: the layer input, 16 rows, zero beyond the piece's own
         // bins) or from t0 - lo (KIND 2: the incoming gradient with its halo)
         auto load_piece = [&](const TilePos& p) {
+            if (rows_tile(s, p)) {
+                pref_load_rows<SP, PMASK>(pp, slp, psrc, mask_src, p.img, p.t0 - lo, s.T, s.F);
+                pref_load_rows<SQ, false>(pq, slq, qsrc, nullptr, p.img, KIND == 1 ? p.t0 : p.t0 - lo, s.T, s.F);
+                return;
+            }
             pref_load<SP, PMASK>(pp, slp, psrc, mask_src, false, p.img, p.t0 - lo, 4 * p.g_base - 2, s.T, s.F, s.F, 4 * p.ng + 4);
             if (KIND == 1) pref_load<SQ, false>(pq, slq, qsrc, nullptr, false, p.img, p.t0, 4 * p.g_base - 2, s.T, s.F, min(s.F, 4 * (p.g_base + p.ng)), 4 * p.ng + 4);
             else pref_load<SQ, false>(pq, slq, qsrc, nullptr, false, p.img, p.t0 - lo, 4 * p.g_base - 2, s.T, s.F, s.F, 4 * p.ng + 4);
@@ -1029,6 +1140,13 @@ __global__ __launch_bounds__((SPLIT ? 12 : 8) * 64, 1) void bwd_ws_kernel(
             pref_commit<SP, MODE_P, NPL>(pp, slp, buf, p.t0 - lo, 4 * p.g_base - 2, s.T, s.F, nullptr, nullptr, alpha, lo, 2 + 4 * p.ng, KIND == 1 ? &bsum : nullptr);
             pref_commit<SQ, MODE_Q, NPL>(pq, slq, buf + NPL * SP::PS, KIND == 1 ? p.t0 : p.t0 - lo, 4 * p.g_base - 2, s.T, s.F, nullptr, nullptr, alpha, 0, 0, nullptr);
         };
+        // the same with the loads of the NEXT piece (a whole-row tile) going out slot by slot behind the commits (RowsReload)
+        auto commit_reload = [&](const TilePos& p, u16* buf, const TilePos& pn) {
+            const RowsReload<SP, PMASK> rp(slp, psrc, mask_src, pn.img, pn.t0 - lo, s.T, s.F);
+            const RowsReload<SQ, false> rq(slq, qsrc, nullptr, pn.img, KIND == 1 ? pn.t0 : pn.t0 - lo, s.T, s.F);
+            pref_commit<SP, MODE_P, NPL>(pp, slp, buf, p.t0 - lo, 4 * p.g_base - 2, s.T, s.F, nullptr, nullptr, alpha, lo, 2 + 4 * p.ng, KIND == 1 ? &bsum : nullptr, rp);
+            pref_commit<SQ, MODE_Q, NPL>(pq, slq, buf + NPL * SP::PS, KIND == 1 ? p.t0 : p.t0 - lo, 4 * p.g_base - 2, s.T, s.F, nullptr, nullptr, alpha, 0, 0, nullptr, rq);
+        };
         const bool stage = !(dbg & DBG_NOSTAGE);              // (measurement hooks of tools/c2m_fused_probe2.py: garbage results)
         int it = 0;
         PieceWalk walk;
@@ -1037,11 +1155,22 @@ __global__ __launch_bounds__((SPLIT ? 12 : 8) * 64, 1) void bwd_ws_kernel(
         bool have = walk.next(s, sc, wg, p);
         if (have && stage) load_piece(p);
         while (have) {
+            C2M_BTS(0);
+            TilePos pn = p;
+            const bool haven = walk.next(s, sc, wg, pn);
+            const bool reload = haven && stage && rows_tile(s, pn);
             wait_for(2 + (it & 1), NCW * (it >> 1));
-            if (stage) commit_piece(p, lds + (it & 1) * BUF);
+            C2M_BTS(1);
+            if (stage) {
+                if (reload) commit_reload(p, lds + (it & 1) * BUF, pn);
+                else commit_piece(p, lds + (it & 1) * BUF);
+            }
+            C2M_BTS(2);
             signal(it & 1);
-            have = walk.next(s, sc, wg, p);
-            if (have && stage) load_piece(p);
+            C2M_BTS(3);
+            if (haven && stage && !reload) load_piece(pn);
+            C2M_BTS(4);
+            p = pn; have = haven;
             ++it;
         }
         __syncthreads();
@@ -1077,11 +1206,17 @@ __global__ __launch_bounds__((SPLIT ? 12 : 8) * 64, 1) void bwd_ws_kernel(
             bool have = walk.next(s, sc, wg, cur);
             while (have) {
                 const u16* pcur = lds + (it & 1) * BUF;
+                C2M_BTS(0);
                 wait_for(it & 1, 4 * ((it >> 1) + 1));
+                C2M_BTS(1);
                 fwd_piece<SP, DIL, OUTMASK, PMASK, NPL, C2M_BW_WREG != 0, NMW, C2M_BW_NMAX>(pcur, wl, wf, cur, s, wave, lane, it, bv0, qsrc, y, false, alpha, !(dbg & DBG_NOSTORE), (dbg & (DBG_NOMFMA | 16)) != 0);
+                C2M_BTS(2);
                 also(cur, pcur, it);
+                C2M_BTS(3);
                 signal(2 + (it & 1));
+                C2M_BTS(4);
                 have = walk.next(s, sc, wg, cur);
+                C2M_BTS(5);
                 ++it;
             }
         };
@@ -1346,6 +1481,15 @@ Sched sched_for(int ntiles, size_t lds, int max_per_cu, int unit) {
 }
 }  // namespace
 
+#if C2M_PROBE_STAMPS
+extern "C" int ptts_conv2d_mfma_probe_stamps(void* host_dst, int clear) {
+    if (clear) {
+        static unsigned long long zeros[256 * 16];
+        return hipMemcpyToSymbol(HIP_SYMBOL(ptts::c2m::g_bw_stamps), zeros, sizeof(zeros)) == hipSuccess ? 0 : -1;
+    }
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(ptts::c2m::g_bw_stamps), sizeof(unsigned long long) * 256 * 16) == hipSuccess ? 0 : -1;
+}
+#endif
 // 1 when the shape has a matrix-core kernel, else 0: 5x5, 4 -> 4 channels, time dilation 1, 2, 4 or 8
 extern "C" int ptts_conv2d_mfma_supported(int F, int Cin, int Cout, int KT_, int KF_, int dil_t) {
     if (!(Cin == 4 && Cout == 4 && KT_ == 5 && KF_ == 5 && F >= 1)) return 0;

@@ -701,8 +701,17 @@ __global__ __launch_bounds__(256) void dense_wgrad_reduce_kernel(DwReduceArgs a)
     if (e >= WPART) return;
     const int S = a.split[gi];
     const float* p = a.partials[gi] + (size_t)tile * S * WPART + e;
-    float v = 0.f;
-    for (int s = 0; s < S; ++s) v += p[(size_t)s * WPART];
+    // eight rows in flight per thread (a fixed order still: the same sums in every run): the plain loop waited for every load in turn
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f;
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {
+        const float* q = p + (size_t)s * WPART;
+        const float t0 = q[0], t1 = q[(size_t)WPART], t2 = q[(size_t)2 * WPART], t3 = q[(size_t)3 * WPART];
+        const float t4 = q[(size_t)4 * WPART], t5 = q[(size_t)5 * WPART], t6 = q[(size_t)6 * WPART], t7 = q[(size_t)7 * WPART];
+        v0 += t0; v1 += t1; v2 += t2; v3 += t3; v4 += t4; v5 += t5; v6 += t6; v7 += t7;
+    }
+    for (; s < S; ++s) v0 += p[(size_t)s * WPART];
+    const float v = ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
     const int tk = tile / a.tiles_n[gi], tn = tile - tk * a.tiles_n[gi];
     if (e < WT * WT) {
         const int k = tk * WT + (e >> 7), n = tn * WT + (e & (WT - 1));
