@@ -4,15 +4,23 @@
 set -u
 TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
-rm -rf $OUT && mkdir -p $OUT
+if [ "${TRACE_ONLY:-0}" = "1" ]; then rm -rf $OUT/trace $OUT/trace_bf16; else rm -rf $OUT; fi
+mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 # the HEADLINE loop only (one geometry per kernel: the averages of the trace are the per-launch times of the bench line), then
 # the same for BASELINE configs[2] (--dtype bf16)
-LEGS="--no-variants --no-unreduced --no-host-leg --no-reference-shape --no-bf16-leg --no-gated-leg --no-cpu-baseline"
+# the step forms are PINNED to what 'tune' picks outside the profiler (critic step replayed, generator step launched eagerly with its
+# forward one batch ahead): under rocprofv3 the timing comparison comes out differently, and the trace and the bench line must time ONE program
+LEGS="--no-variants --no-unreduced --no-host-leg --no-reference-shape --no-bf16-leg --no-gated-leg --no-cpu-baseline --graph-critic on --graph-generator off"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $LEGS --steps 100 --warmup 20 > $OUT/bench.json 2> $OUT/bench.err
 echo "trace done" > $OUT/progress.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_bf16 -- python3 bench.py --dtype bf16 $LEGS --steps 100 --warmup 20 > $OUT/bench_bf16.json 2> $OUT/bench_bf16.err
 echo "bf16 trace done" >> $OUT/progress.txt
+if [ "${TRACE_ONLY:-0}" = "1" ]; then
+  python3 tools/summarize_profiles.py $TAG $OUT/summary > $OUT/summary.log 2>&1
+  rm -f $OUT/*/runc/*_kernel_trace.csv $OUT/*/runc/*_domain_stats.csv
+  exit 0
+fi
 # HBM traffic: FETCH_SIZE and WRITE_SIZE in passes of their own (TCC slots), kernel trace only beside them
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_split -- python3 tools/split_probe.py 3 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_split -- python3 tools/split_probe.py 3 > /dev/null 2>&1
