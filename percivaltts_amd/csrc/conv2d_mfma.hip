@@ -739,6 +739,10 @@ __global__ __launch_bounds__(THREADS, NBUF == 2 ? 2 : (DIL == 1 ? 3 : (DIL == 2 
 // other wave's MFMAs instead of before or after them (in the four-wave form a workgroup's phases alternate and the two workgroups of a
 // CU overlap only when they happen to be in opposite phases), and a workgroup walks twice as many tiles behind one prologue.
 // Same tiles, same pass structure, same arithmetic as fwd_kernel<1, ...>: results are bit-identical.
+// (Round 4, measured: the premise holds only in part.  A SIMD of gfx950 issues another wave's vector instructions at about a tenth of
+// their rate while a wave's MFMAs run -- tools/hip/mfma_valu_overlap_test.hip: both together take 0.9 of the SUM of their times -- so the
+// split does not hide under the MFMAs; what the specialisation does buy is a multiplying wave whose instruction stream holds nothing but
+// LDS reads, MFMAs and stores, with the loads' latency on other waves.  s_memtime stamps of both roles: tools/c2m_ws_stamps.py.)
 // ------------------------------------------------------------------------------------------------------------
 template <int MODE, bool OUTMASK, int NPL, int NMW>
 __global__ __launch_bounds__((NMW + 4) * 64, 1) void fwd_ws_kernel(
