@@ -215,7 +215,7 @@ def test_conv2d_mfma_against_the_oracle_and_the_fp32_stencil(ops, case):
         close(got_s, want, rtol=rt, atol=at, what=nm + ' [fp32 stencil]')
 
 
-@pytest.mark.parametrize('case', [(3, 100, 65), (2, 16, 65), (1, 1, 65), (2, 37, 130), (5, 400, 65), (1, 50, 129), (4, 7, 33), (300, 17, 3), (64, 400, 65)])
+@pytest.mark.parametrize('case', [(3, 100, 65), (2, 16, 65), (1, 1, 65), (2, 37, 130), (5, 400, 65), (1, 50, 129), (4, 7, 33), (300, 17, 3), (17, 270, 65), (70, 59, 68), (64, 400, 65)])
 def test_conv2d_mfma_wave_specialised_form_is_bit_identical(ops, case):
     """The default dilation-1 fp32 forward kernel (c2m::fwd_ws_kernel: eight waves, four stage, four multiply) against the
     four-wave form it replaced (c2m::fwd_kernel, forced by bit 16 of ptts_conv2d_mfma_debug): same tiles, passes and arithmetic,
@@ -248,7 +248,7 @@ def test_conv2d_mfma_wave_specialised_form_is_bit_identical(ops, case):
         assert torch.equal(a, c), nm
 
 
-@pytest.mark.parametrize('case', [(3, 100, 65), (2, 16, 65), (1, 1, 65), (2, 37, 130), (5, 400, 65), (1, 50, 129), (4, 7, 33), (300, 17, 3), (2, 33, 71), (64, 400, 65)])
+@pytest.mark.parametrize('case', [(3, 100, 65), (2, 16, 65), (1, 1, 65), (2, 37, 130), (5, 400, 65), (1, 50, 129), (4, 7, 33), (300, 17, 3), (2, 33, 71), (17, 270, 65), (70, 59, 68), (64, 400, 65)])
 def test_conv2d_mfma_fused_backward_launches(ops, case):
     """The fused backward launches (c2m::bwd_ws_kernel, round 4): dx + dW + dbias of a layer (kind 1) and the second-order sweep's
     masked forward + dW (kind 2), each ONE launch sharing the staging of dy / u, against the separate launches they replace
