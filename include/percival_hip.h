@@ -160,6 +160,15 @@ int ptts_conv2d_mfma_fwd(const void* x, const void* table, const float* bias, co
                          const void* mask_src, const void* out_mask, void* y,
                          int B, int T, int F, int KT, int dil_t, int pad_t, int in_mode, float alpha,
                          int planes, int in_bf16, int out_bf16, void* stream);
+/* The same forward pass (fp32 maps, dilation 1, in_mode NONE / LRELU with or without the BatchNorm affine) that ALSO leaves the
+ * per-workgroup sums of the outputs it stores -- stats[*nrows_out][8] doubles: four channel sums, four channel sums of squares -- for
+ * the kl.BatchNormalization that follows the kl.Conv2D in pCNN2D (networktts.py:122-126): TF computes the layer's batch moments with a
+ * pass of its own over the map (FusedBatchNorm); here they ride on the convolution's stores and ptts_bn_finalize_partials finishes
+ * them.  capacity_rows >= 256.  y is bit-identical to ptts_conv2d_mfma_fwd's. */
+int ptts_conv2d_mfma_fwd_stats_supported(int F, int dil_t, int in_mode);
+int ptts_conv2d_mfma_fwd_stats(const float* x, const void* table, const float* bias, const float* in_scale, const float* in_shift,
+                               float* y, int B, int T, int F, int KT, int pad_t, int in_mode, float alpha,
+                               double* stats, int capacity_rows, int* nrows_out, void* stream);
 size_t ptts_conv2d_mfma_wgrad_workspace_bytes(int B, int T);
 /* x (and mask_src) bf16 when x_bf16, dy bf16 when dy_bf16; the partial sums and the reduced gradients are fp32 always. */
 int ptts_conv2d_mfma_wgrad_partials(const void* dy, const void* x, const void* mask_src, void* workspace,
@@ -416,6 +425,12 @@ int ptts_bn_batch_stats(const float* x, long long rows, int C, const float* gamm
                         float* moving_mean, float* moving_var, float eps, float momentum, int update_moving, int unbiased_moving,
                         float* scale, float* shift, float* mean /*[C] out*/, float* rstd /*[C] out*/,
                         void* workspace, size_t workspace_bytes, int* counter, void* stream);
+
+/* ptts_bn_finalize(training = 1) for sums that lie as nrows partial rows [2 C] doubles (C sums, C sums of squares; C <= 16), added in
+ * index order: the finish of ptts_conv2d_mfma_fwd_stats.  rows = the number of values per channel the sums cover. */
+int ptts_bn_finalize_partials(const double* partials, int nrows, long long rows, int C, const float* gamma, const float* beta,
+                              float* moving_mean, float* moving_var, float eps, float momentum, int update_moving, int unbiased_moving,
+                              float* scale, float* shift, float* mean /*[C] out*/, float* rstd /*[C] out*/, void* stream);
 
 /* BatchNorm backward through the batch statistics.  Given dscale/dshift (gradients w.r.t. the affine that
  * ptts_bn_finalize produced in training mode):  dgamma = (dscale - dshift*mean)*rstd ;  dbeta = dshift ;

@@ -72,6 +72,8 @@ SIGNATURES = {
     'ptts_conv2d_mfma_tables_grouped': (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),
     'ptts_conv2d_mfma_supported': (c_i, [c_i] * 6),
     'ptts_conv2d_mfma_fwd': (c_i, [c_p] * 8 + [c_i] * 7 + [c_f] + [c_i] * 3 + [c_p]),
+    'ptts_conv2d_mfma_fwd_stats_supported': (c_i, [c_i, c_i, c_i]),
+    'ptts_conv2d_mfma_fwd_stats': (c_i, [c_p] * 6 + [c_i] * 6 + [c_f] + [c_p, c_i, c_p, c_p]),
     'ptts_conv2d_mfma_wgrad_workspace_bytes': (c_sz, [c_i, c_i]),
     'ptts_conv2d_mfma_wgrad_partials': (c_i, [c_p] * 4 + [c_sz, c_p, c_p] + [c_i] * 7 + [c_f] + [c_i] * 3 + [c_p]),
     'ptts_conv2d_mfma_bwd_fused_workspace_bytes': (c_sz, [c_i, c_i]),
@@ -111,6 +113,7 @@ SIGNATURES = {
     'ptts_colstats': (c_i, [c_p, c_ll, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_sz, c_p]),
     'ptts_bn_finalize': (c_i, [c_p, c_ll, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     'ptts_bn_batch_stats_supported': (c_i, [c_ll, c_i]),
+    'ptts_bn_finalize_partials': (c_i, [c_p, c_i, c_ll, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     'ptts_bn_batch_stats': (c_i, [c_p, c_ll, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_sz, c_p, c_p]),
     'ptts_bn_bwd_coefs': (c_i, [c_p] * 5 + [c_ll, c_i] + [c_p] * 4 + [c_p]),
     'ptts_bn_bwd_coefs_acc': (c_i, [c_p] * 5 + [c_ll, c_i] + [c_p] * 4 + [c_p]),

@@ -494,10 +494,10 @@ __device__ __forceinline__ void pref_commit(Pref<ST::NB, MODE == PTTS_IN_MASKMUL
 // one pass of a wave over N consecutive bin groups g0 .. g0+N-1 of the staged block: straight-line code (a branch around
 // an MFMA group makes the compiler carry the accumulators through register copies), one LDS base register per parity of
 // the group, everything else immediates
-template <class ST, int DIL, int N, bool OUTMASK, int NPL, bool WREG>
+template <class ST, int DIL, int N, bool OUTMASK, int NPL, bool WREG, bool STATS = false>
 __device__ __forceinline__ void fwd_pass(const u16* __restrict__ planes, const u16* __restrict__ wl, const bf16x8 (&wf)[KT][NPL], int g0, int lane,
                                          f32x4 bv, const void* __restrict__ mrow, void* __restrict__ yrow, bool out_bf16,
-                                         int fbase, int F, bool rowok, float alpha, bool store) {
+                                         int fbase, int F, bool rowok, float alpha, bool store, f32x4* stat = nullptr) {
     const int li = lane & 15, lg = lane >> 4;
     f32x4 acc[N], mv[OUTMASK ? N : 1];
 #pragma unroll
@@ -567,6 +567,7 @@ __device__ __forceinline__ void fwd_pass(const u16* __restrict__ planes, const u
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = o[e] * (mv[j][e] > 0.f ? 1.f : alpha);
                 }
+                if (STATS) { stat[0] += o; stat[1] += o * o; }       // per-channel sum and sum of squares of what is stored (BatchNorm's statistics)
                 store_px(yrow, (f0 + 4 * j) * C, o, out_bf16);
             }
         }
@@ -576,10 +577,10 @@ __device__ __forceinline__ void fwd_pass(const u16* __restrict__ planes, const u
 // the MFMA phase of one staged piece: the wave's share of its bin groups, a contiguous run, in passes of at most NMAX groups
 // of nearly equal size (register budget: a pass keeps N x 3 activation fragments).  The wave that takes the odd group
 // changes from piece to piece: the waves of a workgroup sit on different SIMDs.
-template <class ST, int DIL, bool OUTMASK, bool MASK, int NPL, bool WREG, int NW = 4, int NMAXO = 0>
+template <class ST, int DIL, bool OUTMASK, bool MASK, int NPL, bool WREG, int NW = 4, int NMAXO = 0, bool STATS = false>
 __device__ __forceinline__ void fwd_piece(const u16* __restrict__ planes, const u16* __restrict__ wl, const bf16x8 (&wf)[KT][NPL], const TilePos& cur, const Shape& s,
                                           int wave, int lane, int it, f32x4 bv, const void* __restrict__ out_mask, void* __restrict__ y,
-                                          bool out_bf16, float alpha, bool store, bool nomfma) {
+                                          bool out_bf16, float alpha, bool store, bool nomfma, f32x4* stat = nullptr) {
     static_assert(NW == 4 || NW == 8, "waves that share a piece");
     const int per = cur.ng / NW, rem = cur.ng & (NW - 1), wr = (wave + it) & (NW - 1);
     int gl = wr * per + min(wr, rem);
@@ -595,7 +596,7 @@ __device__ __forceinline__ void fwd_piece(const u16* __restrict__ planes, const 
     const int fbase = 4 * cur.g_base;
     while (n > 0) {
         const int m = npass == 1 ? n : (npass == 2 ? (n + 1) >> 1 : (n + npass - 1) / npass);      // (the division is ~35 scalar instructions)
-#define C2M_PASS(NN) fwd_pass<ST, DIL, NN, OUTMASK, NPL, WREG>(planes, wl, wf, gl, lane, bv, mrow, yrow, out_bf16, fbase, s.F, rowok, alpha, store)
+#define C2M_PASS(NN) fwd_pass<ST, DIL, NN, OUTMASK, NPL, WREG, STATS>(planes, wl, wf, gl, lane, bv, mrow, yrow, out_bf16, fbase, s.F, rowok, alpha, store, stat)
         switch (m) {
             case 1: C2M_PASS(1); break;
             case 2: if (NMAX >= 2) C2M_PASS(NMAX >= 2 ? 2 : 1); break;
@@ -744,12 +745,17 @@ __global__ __launch_bounds__(THREADS, NBUF == 2 ? 2 : (DIL == 1 ? 3 : (DIL == 2 
 // split does not hide under the MFMAs; what the specialisation does buy is a multiplying wave whose instruction stream holds nothing but
 // LDS reads, MFMAs and stores, with the loads' latency on other waves.  s_memtime stamps of both roles: tools/c2m_ws_stamps.py.)
 // ------------------------------------------------------------------------------------------------------------
-template <int MODE, bool OUTMASK, int NPL, int NMW>
+// STATS (round 4): the launch also leaves, per workgroup, the per-channel sum and sum of squares of the outputs it stored --
+// stats[workgroup][8] doubles, [0..3] sums, [4..7] sums of squares -- for the BatchNormalization layer that follows the convolution in the
+// generator's stack (reference networktts.py:122-126): its statistics no longer cost a pass of their own over the map (ptts_bn_batch_stats:
+// 16 us a layer, 8 layers, in every forward of the generator -- the critic step's fake sample included), only ptts_bn_finalize_partials.
+// A lane adds what it stores (fp32: 80 values per launch and channel), the workgroup's 256 lanes are added in double, in a fixed order.
+template <int MODE, bool OUTMASK, int NPL, int NMW, bool STATS = false>
 __global__ __launch_bounds__((NMW + 4) * 64, 1) void fwd_ws_kernel(
     const void* __restrict__ x, const u16* __restrict__ tab, const float* __restrict__ bias,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, const void* __restrict__ mask_src,
     const void* __restrict__ out_mask, void* __restrict__ y, int dt, Shape s, Sched sc, float alpha, int dbg, unsigned long long* dbg_buf,
-    unsigned* status) {
+    unsigned* status, double* __restrict__ stats = nullptr) {
     constexpr int DIL = 1;
     typedef Stage<4 * GPB + 4, 16 + (KT - 1) * DIL> ST;
     extern __shared__ __attribute__((aligned(16))) u16 lds[];
@@ -840,6 +846,7 @@ __global__ __launch_bounds__((NMW + 4) * 64, 1) void fwd_ws_kernel(
     stamp(dbg_buf, dbg, 1);
     __syncthreads();
     stamp(dbg_buf, dbg, 2);
+    f32x4 stat[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     int it = 0;
 #if C2M_PROBE_STAMPS
     // (probe build, tools/c2m_ws_stamps.py) the timeline of piece 3 of every workgroup: wave 0 (multiplying) slots 0..4, wave NMW (staging) 8..12
@@ -878,7 +885,7 @@ __global__ __launch_bounds__((NMW + 4) * 64, 1) void fwd_ws_kernel(
             const u16* pcur = planes + (it & 1) * NPL * ST::PS;
             if (C2M_WS_FLAGS) wait_for(it & 1, 4 * ((it >> 1) + 1));
             C2M_TS(1);
-            fwd_piece<ST, DIL, OUTMASK, MASK, NPL, true, NMW, (NMW == 8 ? 2 : C2M_WS_NMAX)>(pcur, nullptr, wf, cur, s, wave, lane, it, bv, out_mask, y, out_bf16, alpha, store, nomfma);
+            fwd_piece<ST, DIL, OUTMASK, MASK, NPL, true, NMW, (NMW == 8 ? 2 : C2M_WS_NMAX), STATS>(pcur, nullptr, wf, cur, s, wave, lane, it, bv, out_mask, y, out_bf16, alpha, store, nomfma, stat);
             C2M_TS(2);
             if (C2M_WS_FLAGS) signal(2 + (it & 1));
             C2M_TS(3);
@@ -887,6 +894,27 @@ __global__ __launch_bounds__((NMW + 4) * 64, 1) void fwd_ws_kernel(
         if (!C2M_WS_FLAGS) __syncthreads();
         cur = nxt; havecur = havenxt; nxt = p2; havenxt = have2;
         ++it;
+    }
+    if (STATS) {
+        // the workgroup's row: every multiplying lane's eight fp32 sums into the LDS (the plane buffers are free: every piece is done when
+        // every wave is here), then eight lanes add the 64 NMW values of their column in double, in index order
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(lds);
+        if (!stager) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { red[e * (NMW * 64) + tid] = stat[0][e]; red[(4 + e) * (NMW * 64) + tid] = stat[1][e]; }
+        }
+        __syncthreads();
+        if (tid < 256) {
+            // column c = tid / 32, 32 lanes each: a strided partial sum, then a butterfly -- a fixed order of additions
+            constexpr int NV = NMW * 64;
+            const int c = tid >> 5, k = tid & 31;
+            double a = 0.0;
+            for (int i = k; i < NV; i += 32) a += (double)red[c * NV + i];
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
+            if (k == 0) stats[(size_t)blockIdx.x * 8 + c] = a;
+        }
     }
     stamp(dbg_buf, dbg, 4);
 }
@@ -1484,6 +1512,43 @@ Sched sched_for(int ntiles, size_t lds, int max_per_cu, int unit) {
     return c;
 }
 }  // namespace
+
+// The forward pass of a 4 -> 4 layer (fp32 maps, dilation 1, LeakyReLU / BatchNorm-affine + LeakyReLU or no input transform) that also leaves
+// the per-workgroup sums of its outputs for the BatchNormalization layer behind it: stats[*nrows_out][8] doubles (channel sums, channel sums of
+// squares), to be finished by ptts_bn_finalize_partials.  capacity_rows >= 256.
+extern "C" int ptts_conv2d_mfma_fwd_stats_supported(int F, int dil_t, int in_mode) {
+    return (F >= 1 && dil_t == 1 && (in_mode == PTTS_IN_NONE || in_mode == PTTS_IN_LRELU) && fwd_wave_specialised() == 1 && fwd_ws_waves() != 8) ? 1 : 0;
+}
+extern "C" int ptts_conv2d_mfma_fwd_stats(const float* x, const void* table, const float* bias, const float* in_scale, const float* in_shift,
+                                          float* y, int B, int T, int F, int KT_, int pad_t, int in_mode, float alpha,
+                                          double* stats, int capacity_rows, int* nrows_out, void* stream) {
+    PTTS_REQUIRE(x && table && y && stats && nrows_out, "conv2d_mfma_fwd_stats: null pointer");
+    PTTS_REQUIRE(KT_ == KT && B > 0 && T > 0 && F > 0, "conv2d_mfma_fwd_stats: bad shape B=%d T=%d F=%d KT=%d", B, T, F, KT_);
+    PTTS_REQUIRE(ptts_conv2d_mfma_fwd_stats_supported(F, 1, in_mode), "conv2d_mfma_fwd_stats: unsupported (in_mode %d)", in_mode);
+    PTTS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_mfma_fwd_stats: scale/shift must come together");
+    PTTS_REQUIRE(in_mode == PTTS_IN_LRELU || !in_scale, "conv2d_mfma_fwd_stats: scale/shift need PTTS_IN_LRELU");
+    PTTS_REQUIRE(pad_t >= 0 && pad_t <= KT - 1, "conv2d_mfma_fwd_stats: bad pad_t %d", pad_t);
+    PTTS_REQUIRE(alpha >= 0.f && alpha <= 1.f, "conv2d_mfma_fwd_stats: LeakyReLU slope %g outside [0, 1]", alpha);
+    PTTS_REQUIRE((long long)(T + 64) * F * C < (1LL << 31), "conv2d_mfma_fwd_stats: utterance too large for 32-bit tile offsets");
+    if (int rc = check_status("conv2d_mfma_fwd_stats")) return rc;
+    const Shape s = make_shape(B, T, F, pad_t);
+    PTTS_REQUIRE(shape_ok(s), "conv2d_mfma_fwd_stats: too many tiles");
+    constexpr size_t lds = lds_fwd<1, 3, 2>();
+    const Sched sc = sched_for(s.ntiles, lds, 1, 1);
+    PTTS_REQUIRE(capacity_rows >= sc.G, "conv2d_mfma_fwd_stats: room for %d rows of sums, %d needed", capacity_rows, sc.G);
+    hipStream_t st = (hipStream_t)stream;
+#define C2M_ST(MODE)                                                                                                         \
+    do {                                                                                                                     \
+        static bool attr = false;                                                                                            \
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_ws_kernel<MODE, false, 3, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX); attr = true; } \
+        hipLaunchKernelGGL((fwd_ws_kernel<MODE, false, 3, 4, true>), dim3(sc.G), dim3(8 * 64), lds, st, x, (const u16*)table, bias,    \
+                           in_scale, in_shift, nullptr, nullptr, y, 0, s, sc, alpha, g_dbg, g_dbg_buf, status_words(), stats);           \
+    } while (0)
+    if (in_mode == PTTS_IN_LRELU) C2M_ST(PTTS_IN_LRELU); else C2M_ST(PTTS_IN_NONE);
+#undef C2M_ST
+    *nrows_out = sc.G;
+    return check_launch("conv2d_mfma_fwd_stats");
+}
 
 #if C2M_PROBE_STAMPS
 extern "C" int ptts_conv2d_mfma_probe_stamps(void* host_dst, int clear) {

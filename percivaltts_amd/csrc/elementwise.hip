@@ -458,6 +458,51 @@ __global__ __launch_bounds__(EW_THREADS) void bn_stats_fused_kernel(const float*
     if (tid == 0) *counter = 0;
 }
 
+// The same finish for per-workgroup sums that ANOTHER kernel left behind (c2m::fwd_ws_kernel<.., STATS>: the convolution in front of the
+// BatchNormalization layer adds up what it stores): partials[nrows][2 C] doubles -- C sums, C sums of squares -- added in index order by
+// one workgroup, then bn_finalize's arithmetic.  C <= 16.
+__global__ __launch_bounds__(256) void bn_finalize_partials_kernel(const double* __restrict__ partials, int nrows, long long rows, int C,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   float* __restrict__ moving_mean, float* __restrict__ moving_var,
+                                                                   float eps, float momentum, int update_moving, int unbiased_moving,
+                                                                   float* __restrict__ scale, float* __restrict__ shift,
+                                                                   float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    __shared__ double sh[256];
+    __shared__ double tot[32];
+    const int tid = threadIdx.x, n2c = 2 * C, G = 256 / n2c;
+    const int j = tid % n2c, g = tid / n2c;
+    double t = 0.0;
+    if (g < G)
+        for (int b = g; b < nrows; b += G) t += partials[(size_t)b * n2c + j];
+    sh[tid] = (g < G) ? t : 0.0;
+    __syncthreads();
+    if (tid < n2c) {
+        double a = 0.0;
+        for (int k = 0; k < G; ++k) a += sh[k * n2c + tid];
+        tot[tid] = a;
+    }
+    __syncthreads();
+    if (tid < C) {
+        const int c = tid;
+        const double count = (double)rows;
+        const double mean = tot[c] / count;
+        double var = tot[C + c] / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        if (update_moving) {
+            const double vm = (unbiased_moving && rows > 1) ? var * count / (count - 1.0) : var;
+            moving_mean[c] = (float)(moving_mean[c] * (double)momentum + mean * (1.0 - (double)momentum));
+            moving_var[c] = (float)(moving_var[c] * (double)momentum + vm * (1.0 - (double)momentum));
+        }
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        const double gm = gamma ? (double)gamma[c] : 1.0;
+        const double bt = beta ? (double)beta[c] : 0.0;
+        scale[c] = (float)(gm * rstd);
+        shift[c] = (float)(bt - mean * gm * rstd);
+        if (mean_out) mean_out[c] = (float)mean;
+        if (rstd_out) rstd_out[c] = (float)rstd;
+    }
+}
+
 __global__ void bn_bwd_coefs_kernel(const float* __restrict__ dscale, const float* __restrict__ dshift,
                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                     const float* __restrict__ gamma, long long count, int C,
@@ -739,6 +784,17 @@ extern "C" int ptts_bn_batch_stats(const float* x, long long rows, int C, const 
     hipLaunchKernelGGL(bn_stats_fused_kernel, dim3(nb), dim3(EW_THREADS), 0, (hipStream_t)stream, x, rows, C, (double*)workspace, counter,
                        gamma, beta, moving_mean, moving_var, eps, momentum, update_moving, unbiased_moving, scale, shift, mean, rstd);
     return check_launch("bn_batch_stats");
+}
+
+extern "C" int ptts_bn_finalize_partials(const double* partials, int nrows, long long rows, int C, const float* gamma, const float* beta,
+                                         float* moving_mean, float* moving_var, float eps, float momentum, int update_moving,
+                                         int unbiased_moving, float* scale, float* shift, float* mean, float* rstd, void* stream) {
+    PTTS_REQUIRE(partials && scale && shift && nrows > 0 && rows > 0, "bn_finalize_partials: bad args");
+    PTTS_REQUIRE(C >= 1 && C <= 16, "bn_finalize_partials: C = %d (1 .. 16)", C);
+    PTTS_REQUIRE(!update_moving || (moving_mean && moving_var), "bn_finalize_partials: update needs moving stats");
+    hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nrows, rows, C, gamma, beta,
+                       moving_mean, moving_var, eps, momentum, update_moving, unbiased_moving, scale, shift, mean, rstd);
+    return check_launch("bn_finalize_partials");
 }
 
 extern "C" int ptts_bn_bwd_coefs(const float* dscale, const float* dshift, const float* mean, const float* rstd,

@@ -301,6 +301,16 @@ class Conv2D(Layer):
         v = vals[0]
         if isinstance(v, LazyConcat):
             v = v.tensor()
+        if getattr(self, 'bn_follows', False) and training and self.activation in (None, 'linear') and self.bf16 is None:
+            # the BatchNormalization behind this layer takes its statistics from sums the convolution's launch leaves (ops._BNStats)
+            ops._BNStats.want, ops._BNStats.last = True, None
+            try:
+                z = ops.conv2d(v, self.kernel, self.bias, self.dil_t, ops.PAD_CAUSAL if self.causal else ops.PAD_SAME, self.bf16)
+            finally:
+                ops._BNStats.want = False
+            if ops._BNStats.last is not None:
+                z._ptts_bn_partials, ops._BNStats.last = ops._BNStats.last, None
+            return z
         z = ops.conv2d(v, self.kernel, self.bias, self.dil_t, ops.PAD_CAUSAL if self.causal else ops.PAD_SAME, self.bf16)
         return _apply_activation(z, self.activation)
 

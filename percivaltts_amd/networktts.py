@@ -65,7 +65,9 @@ def pCNN1D(input, nbfilters, winlen, bn=True, **kwargs):
 
 def pCNN2D(input, nbfilters, winlen, freqlen, bn=True, **kwargs):
     """Conv2D over (time, frequency), 'same' -> BN -> LeakyReLU(.3) (networktts.py:122-126)"""
-    output = kl.Conv2D(nbfilters, [winlen, freqlen], use_bias=not bn, **kwargs)(input)
+    conv = kl.Conv2D(nbfilters, [winlen, freqlen], use_bias=not bn, **kwargs)
+    conv.bn_follows = bool(bn)        # (the layer's launch also sums its outputs for the BatchNormalization behind it: kl.Conv2D.compute)
+    output = conv(input)
     if bn: output = kl.BatchNormalization()(output)
     return kl.LeakyReLU(alpha=0.3)(output)
 

@@ -375,12 +375,35 @@ def _is16(t):
     return t is not None and t.dtype == torch.bfloat16
 
 
+class _BNStats(object):
+    """A Conv2D layer that feeds a BatchNormalization layer asks its forward launch for the per-channel sums of what it stores
+    (csrc/conv2d_mfma.hip, fwd_ws_kernel<.., STATS>): `want` is set around the layer's ops.conv2d call, `last` = (partial rows
+    [256, 8] float64, number of rows written, values per channel) is what the launch left -- or None when the shape took another kernel.
+    layers.Conv2D hangs it on the map (`_ptts_bn_partials`), BatchNormTrainFn finishes it with ptts_bn_finalize_partials instead of
+    running ptts_bn_batch_stats over the map (16 us a layer and forward pass, 7 such layers in the generator).  PTTS_CONV_BN_STATS=0: off."""
+    enabled = os.environ.get('PTTS_CONV_BN_STATS', '1') == '1'
+    want = False
+    last = None
+
+
+def conv_bn_stats(on):
+    _BNStats.enabled = (os.environ.get('PTTS_CONV_BN_STATS', '1') == '1') if on is None else bool(on)
+
+
 def _conv2d_mfma_fwd(x, w, table, b, scale, shift, mask_src, out_mask, mode, alpha, dil_t, pad_t, planes=3, out_bf16=False):
     B, T, F, _ = x.shape
     assert planes in (1, 3) and (planes == 1 or not (_is16(x) or out_bf16)), 'bf16 tensors need the one-plane (bf16 arithmetic) kernels'
     assert mask_src is None or mask_src.dtype == x.dtype, 'conv2d: the mask source has the input\'s storage type'
     y = torch.empty((B, T, F, 4), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     assert out_mask is None or out_mask.dtype == y.dtype, 'conv2d: the output mask has the output\'s storage type'
+    if _BNStats.want and _BNStats.enabled and planes == 3 and mask_src is None and out_mask is None and \
+            _hip.lib().ptts_conv2d_mfma_fwd_stats_supported(F, dil_t, mode):
+        part = torch.empty((256, 8), dtype=torch.float64, device=x.device)
+        nrows = ctypes.c_int(0)
+        call('ptts_conv2d_mfma_fwd_stats', ptr(x), ptr(table), ptr(b), ptr(scale), ptr(shift), ptr(y), B, T, F, 5, pad_t, mode, alpha,
+             ptr(part), 256, ctypes.byref(nrows), stream(), tag=(B, T, F, 4, 4, mode, 'stats'))
+        _BNStats.last = (part, nrows.value, B * T * F)
+        return y
     call('ptts_conv2d_mfma_fwd', ptr(x), ptr(table), ptr(b), ptr(scale), ptr(shift), ptr(mask_src), ptr(out_mask), ptr(y),
          B, T, F, 5, dil_t, pad_t, mode, alpha, planes, int(_is16(x)), int(out_bf16), stream(),
          tag=(B, T, F, 4, 4, mode, int(out_mask is not None), planes))
@@ -1867,6 +1890,14 @@ class BatchNormTrainFn(torch.autograd.Function):
         # inside deferred_weight_grads(): dgamma / dbeta are added straight into the parameters' gradient buffers by the kernel that
         # computes them (two AccumulateGrad add launches per BatchNorm layer less: 30 per generator step)
         ctx.gt = (grad_target(gamma), grad_target(beta)) if _Deferred.active else None
+        part = getattr(z, '_ptts_bn_partials', None)
+        if part is not None and ctx.sync <= 1 and C == 4 and part[2] == rows:
+            # the convolution that produced z summed what it stored (_BNStats): only the finish is left
+            call('ptts_bn_finalize_partials', ptr(part[0]), part[1], rows, C, ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var),
+                 BN_EPS, BN_MOMENTUM, 1 if update_moving else 0, 1 if unbiased_moving else 0, ptr(scale), ptr(shift), ptr(mean), ptr(rstd),
+                 stream(), tag=(rows, C))
+            ctx.save_for_backward(z, gamma, mean, rstd)
+            return z.view_as(z), scale, shift
         if ctx.sync <= 1 and z.data_ptr() % 16 == 0 and _hip.lib().ptts_bn_batch_stats_supported(rows, C):
             # the conv stacks' few-channel maps: statistics and affine in one launch
             ws = _workspace(_hip.lib().ptts_colstats_workspace_bytes(rows, C), dev)

@@ -538,6 +538,50 @@ def test_generator_forward_one_batch_ahead_gives_the_same_two_batches(setup):
             close(a, b, 1e-5, 1e-6, 'BatchNorm moving statistics after two batches (' + what + ')')
 
 
+def test_batchnorm_statistics_taken_from_the_convolutions_sums(setup):
+    """ops._BNStats (default on): the generator's 4 -> 4 Conv2D layers sum what they store and the BatchNormalization behind each takes its
+    batch moments from those sums (reference networktts.py:122-126: Conv2D -> BatchNormalization -> LeakyReLU).  Same map, same moments up
+    to the order of the additions: the generator step gives the same loss, gradients and moving statistics as with a statistics pass per
+    layer, and seven of the eight passes are gone."""
+    from percivaltts_amd import ops, _hip
+    cfg, opt, crit, X, Y = setup
+    state = (opt.gen_opti.flat.flat, opt.gen_opti.m, opt.gen_opti.v, opt.gen_opti.step_count)
+    snap = [t.detach().clone() for t in state]
+    moving = [t for k, t in opt._model.kerasmodel.weights() if 'moving' in k]
+    moving0 = [t.detach().clone() for t in moving]
+    res = []
+    try:
+        for on in (True, False):
+            opt.wait_updates()
+            for dst, src in zip(state, snap):
+                dst.copy_(src)
+            for dst, src in zip(moving, moving0):
+                dst.copy_(src)
+            opt.gen_opti.flat.epoch += 1
+            ops.conv_bn_stats(on)
+            with _hip.KernelTimer() as kt:
+                lg = opt.generator_step(X, Y)
+            opt.wait_updates(); torch.cuda.synchronize()
+            names = [r[0] for r in kt.records]
+            res.append((float(lg), opt.gen_opti.flat.grad.detach().clone(), [t.detach().clone() for t in moving],
+                        names.count('ptts_bn_finalize_partials'), names.count('ptts_bn_batch_stats'), names.count('ptts_conv2d_mfma_fwd_stats')))
+    finally:
+        ops.conv_bn_stats(None)
+        opt.wait_updates()
+        for dst, src in zip(state, snap):
+            dst.copy_(src)
+        for dst, src in zip(moving, moving0):
+            dst.copy_(src)
+        opt.gen_opti.flat.epoch += 1
+    (l1, g1, m1, nf1, nb1, nc1), (l0, g0, m0, nf0, nb0, nc0) = res
+    assert (nf0, nc0) == (0, 0) and nb0 >= 8
+    assert nf1 == nc1 and nf1 >= 7 and nb1 == nb0 - nf1, (nf1, nc1, nb1, nb0)
+    assert abs(l1 - l0) <= 1e-5 * max(1.0, abs(l0)), (l1, l0)
+    assert rel_l2(g1, g0) < 1e-3, rel_l2(g1, g0)
+    for a, b in zip(m1, m0):
+        close(a, b, 1e-5, 1e-6, 'BatchNorm moving statistics')
+
+
 def test_train_step_with_the_bf16x6_context_conv_matches_the_fp32_one(setup):
     """device_step at BASELINE configs[1] sizes with the context-Conv1D forward as a bf16x6 split product in the time domain
     (cfg.train_wgan_split_bf16, csrc/split.hip) and in the frequency domain (ops._C1FFT, the default) against the same step on

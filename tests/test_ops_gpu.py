@@ -1514,3 +1514,58 @@ def test_frequency_domain_building_blocks(ops):
     G64, t64 = Gt.double().cpu().numpy(), t2.double().cpu().numpy()
     want = np.einsum('fk,fnc->kcn', t64[:, :KW], G64[:, :, :Cin]) + np.einsum('fk,fnc->kcn', t64[:, KW:2 * KW], G64[:, :, Kh:Kh + Cin])
     assert float(np.abs(dW.double().cpu().numpy() - want).max()) < 1e-5 * (1 + float(np.abs(want).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [(3, 100, 65), (1, 1, 65), (2, 37, 130), (300, 17, 3), (17, 270, 65), (64, 400, 65)])
+@pytest.mark.parametrize('mode', ['none', 'lrelu', 'affine'])
+def test_conv2d_forward_that_sums_its_outputs_for_the_batchnorm_behind_it(ops, case, mode):
+    """ptts_conv2d_mfma_fwd_stats (the convolution of pCNN2D, reference networktts.py:122-126, in front of its BatchNormalization): the map
+    is the plain launch's bit for bit, the per-workgroup rows add up to the per-channel sums of the map and of its squares, and
+    ptts_bn_finalize_partials makes of them what ptts_bn_batch_stats makes of a pass over the map -- affine, batch moments, moving
+    averages (fp64 oracle: mean / biased variance of the map)."""
+    import ctypes
+    B, T, F = case
+    g = gen(91)
+    x = torch.randn(B, T, F, 4, generator=g).cuda()
+    w = (torch.randn(5, 5, 4, 4, generator=g) * 0.3).cuda()
+    b = torch.randn(4, generator=g).cuda()
+    sc = (torch.rand(4, generator=g) + 0.5).cuda() if mode == 'affine' else None
+    sh = (torch.randn(4, generator=g) * 0.3).cuda() if mode == 'affine' else None
+    in_mode = ops.IN_NONE if mode == 'none' else ops.IN_LRELU
+    lib = ops._hip.lib()
+    assert lib.ptts_conv2d_mfma_fwd_stats_supported(F, 1, in_mode) == 1
+    y0 = ops._conv2d_fwd_raw(x, w, b, sc, sh, None, in_mode, 0.3, 1, ops.PAD_SAME)
+    ops._BNStats.want, ops._BNStats.last = True, None
+    try:
+        y1 = ops._conv2d_fwd_raw(x, w, b, sc, sh, None, in_mode, 0.3, 1, ops.PAD_SAME)
+    finally:
+        ops._BNStats.want = False
+    part, nrows, count = ops._BNStats.last
+    ops._BNStats.last = None
+    assert torch.equal(y0, y1) and count == B * T * F and 1 <= nrows <= 256
+    sums = part[:nrows].sum(0).cpu()
+    yd = y0.double().reshape(-1, 4).cpu()
+    close(sums[:4], yd.sum(0), 1e-6, 1e-6 * float(yd.abs().sum(0).max()), 'channel sums')
+    close(sums[4:], (yd * yd).sum(0), 1e-6, 0.0, 'channel sums of squares')
+    # the finish against the one-pass statistics kernel and against the oracle's moments
+    gamma = (torch.rand(4, generator=g) + 0.5).cuda(); beta = torch.randn(4, generator=g).cuda()
+    outs = []
+    for which in (0, 1):
+        mm = torch.full((4,), 0.25, device='cuda'); mv = torch.full((4,), 2.0, device='cuda')
+        scale, shift, mean, rstd = (torch.empty(4, device='cuda') for _ in range(4))
+        rows = B * T * F
+        if which == 0:
+            ws = ops._workspace(lib.ptts_colstats_workspace_bytes(rows, 4), x.device)
+            ops.call('ptts_bn_batch_stats', ops.ptr(y0), rows, 4, ops.ptr(gamma), ops.ptr(beta), ops.ptr(mm), ops.ptr(mv), 1e-3, 0.99, 1, 1,
+                     ops.ptr(scale), ops.ptr(shift), ops.ptr(mean), ops.ptr(rstd), ops.ptr(ws), ws.numel(), ops.ptr(ops._stream_counter(x.device)), ops.stream())
+        else:
+            ops.call('ptts_bn_finalize_partials', ops.ptr(part), nrows, rows, 4, ops.ptr(gamma), ops.ptr(beta), ops.ptr(mm), ops.ptr(mv), 1e-3, 0.99, 1, 1,
+                     ops.ptr(scale), ops.ptr(shift), ops.ptr(mean), ops.ptr(rstd), ops.stream())
+        torch.cuda.synchronize()
+        outs.append((scale, shift, mean, rstd, mm, mv))
+    for nm, a, c in zip(('scale', 'shift', 'mean', 'rstd', 'moving mean', 'moving variance'), outs[1], outs[0]):
+        close(a, c.cpu(), 2e-6, 2e-6, nm + ' (partial rows against the one-pass kernel)')
+    mu = yd.mean(0); var = yd.var(0, unbiased=False)
+    close(outs[1][2], mu, 1e-5, 1e-6, 'batch mean against the oracle')
+    close(outs[1][3], 1.0 / torch.sqrt(var + 1e-3), 1e-5, 0.0, 'batch rstd against the oracle')
