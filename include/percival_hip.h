@@ -330,6 +330,13 @@ int ptts_dense_bf16x6_res(const float* A, const void* planes, const float* bias,
                           long long lda, long long ldc, int in_mode, const float* in_scale, const float* in_shift,
                           const float* mask_src, float alpha, const float* res, int res_rows, long long ldr,
                           const float* out_mask, void* stream);
+/* The product of a kl.Dense that feeds a kl.BatchNormalization (pFC, networktts.py:59-63) also leaves, per row tile, the column sums and
+ * the column sums of squares of what it stores: stats[*nrows_out][2 N] doubles, finished by ptts_bn_finalize_partials -- TF's batch
+ * moments are a pass of their own over the activation.  capacity_rows >= ptts_dense_bf16x6_stats_rows(M, N); N % 4 == 0. */
+int ptts_dense_bf16x6_stats_rows(int M, int N);
+int ptts_dense_bf16x6_stats(const float* A, const void* planes, const float* bias, float* C, int M, int N, int K,
+                            long long lda, long long ldc, int in_mode, const float* in_scale, const float* in_shift,
+                            float alpha, double* stats, int capacity_rows, int* nrows_out, void* stream);
 /* Frequency-domain context Conv1D, helper: Ap [NB][2][B][2*Kh] floats with [Xr | .] in part 0 and [Xi | .] in part 1 (columns < Cin)
  * -> columns Kh .. Kh+Cin-1 get -Xi (part 0) and Xr (part 1): the rows [Xr | -Xi], [Xi | Xr] of the real form of a complex product. */
 int ptts_dft_mirror(float* Ap, int NB, int B, int Cin, int Kh, void* stream);
@@ -426,8 +433,8 @@ int ptts_bn_batch_stats(const float* x, long long rows, int C, const float* gamm
                         float* scale, float* shift, float* mean /*[C] out*/, float* rstd /*[C] out*/,
                         void* workspace, size_t workspace_bytes, int* counter, void* stream);
 
-/* ptts_bn_finalize(training = 1) for sums that lie as nrows partial rows [2 C] doubles (C sums, C sums of squares; C <= 16), added in
- * index order: the finish of ptts_conv2d_mfma_fwd_stats.  rows = the number of values per channel the sums cover. */
+/* ptts_bn_finalize(training = 1) for sums that lie as nrows partial rows [2 C] doubles (C sums, C sums of squares), added in
+ * index order: the finish of ptts_conv2d_mfma_fwd_stats and of ptts_dense_bf16x6_stats.  rows = the number of values per channel the sums cover. */
 int ptts_bn_finalize_partials(const double* partials, int nrows, long long rows, int C, const float* gamma, const float* beta,
                               float* moving_mean, float* moving_var, float eps, float momentum, int update_moving, int unbiased_moving,
                               float* scale, float* shift, float* mean /*[C] out*/, float* rstd /*[C] out*/, void* stream);

@@ -227,6 +227,7 @@ struct DenseArgs {
     int accumulate, has_affine, vec_out;
     const float* res; int res_rows; long long ldr;      // residual added in the store: C[m][n] += res[m % res_rows][n] (NULL: none).  accumulate = res == C
     long long bsA, bsP, bsC;          // batched launch (gridDim.z products of one shape): strides of A and C in floats, of the planes in u16
+    double* stats;                    // (ptts_dense_bf16x6_stats) per row tile: the column sums and the column sums of squares of what is stored, [gridDim.x][2 N]
 };
 
 template <int MODE, bool AFFINE, int MT, int NPL>
@@ -414,6 +415,7 @@ __global__ __launch_bounds__(THREADS) void dense_bf16x6_kernel(DenseArgs g) {
         const long long off0 = (long long)(m0 + li) * g.ldc + n;
         // row of the residual: m modulo res_rows (a product shared by k stacked evaluations is added to each of its k row blocks)
         auto res_at = [&](int m) { int mr = m; while (mr >= g.res_rows) mr -= g.res_rows; return g.res + (long long)mr * g.ldr + n; };
+        f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
         if (interior) {
             f32x4 mk[MT], old[MT];
             if (g.out_mask) {
@@ -432,6 +434,7 @@ __global__ __launch_bounds__(THREADS) void dense_bf16x6_kernel(DenseArgs g) {
                     for (int e = 0; e < 4; ++e) v[e] = v[e] * (mk[i][e] > 0.f ? 1.f : g.out_alpha);
                 }
                 if (g.res) v += old[i];
+                if (g.stats) { ssum += v; ssq += v * v; }
                 *reinterpret_cast<f32x4*>(g.C + off0 + (long long)16 * i * g.ldc) = v;
             }
         } else {
@@ -447,7 +450,20 @@ __global__ __launch_bounds__(THREADS) void dense_bf16x6_kernel(DenseArgs g) {
                     for (int e = 0; e < 4; ++e) v[e] = v[e] * (mk[e] > 0.f ? 1.f : g.out_alpha);
                 }
                 if (g.res) v += *reinterpret_cast<const f32x4*>(res_at(m));
+                if (g.stats) { ssum += v; ssq += v * v; }
                 *reinterpret_cast<f32x4*>(g.C + off) = v;
+            }
+        }
+        if (g.stats) {
+            // the tile's column sums: a lane holds MT of the TBM rows of its four columns; the 16 lanes li of a group hold the others
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) { ssum[e] += __shfl_xor(ssum[e], m, 64); ssq[e] += __shfl_xor(ssq[e], m, 64); }
+            if (li == 0) {
+                double* row = g.stats + (size_t)blockIdx.x * 2 * g.N;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { row[n + e] = (double)ssum[e]; row[g.N + n + e] = (double)ssq[e]; }
             }
         }
     }
@@ -824,10 +840,40 @@ extern "C" int ptts_dense_bf16x6(const float* A, const void* planes, const float
 // ... + res[m % res_rows][n] (row stride ldr) in the store: the product of a concat part that several stacked evaluations share (the
 // critic's context branch, computed once at B rows) joins each of the k B-row blocks of the stacked product without an add pass of its
 // own.  res == C, res_rows >= M is the plain accumulate of ptts_dense_bf16x6.
+static int dense_launch(const float* A, const void* planes, const float* bias, float* C, int M, int N, int K,
+                        long long lda, long long ldc, int in_mode, const float* in_scale, const float* in_shift,
+                        const float* mask_src, float alpha, const float* res, int res_rows, long long ldr,
+                        const float* out_mask, double* stats, int stats_capacity_rows, int* stats_rows_out, void* stream);
+
 extern "C" int ptts_dense_bf16x6_res(const float* A, const void* planes, const float* bias, float* C, int M, int N, int K,
                                      long long lda, long long ldc, int in_mode, const float* in_scale, const float* in_shift,
                                      const float* mask_src, float alpha, const float* res, int res_rows, long long ldr,
                                      const float* out_mask, void* stream) {
+    return dense_launch(A, planes, bias, C, M, N, K, lda, ldc, in_mode, in_scale, in_shift, mask_src, alpha, res, res_rows, ldr, out_mask,
+                        nullptr, 0, nullptr, stream);
+}
+
+// The product of a Dense layer that feeds a BatchNormalization layer (pFC, reference networktts.py:59-63): the launch also leaves, per
+// row tile, the column sums and the column sums of squares of what it stores -- stats[*nrows_out][2 N] doubles -- which
+// ptts_bn_finalize_partials finishes: no statistics pass over the [M, N] activation (ptts_colstats: two launches, 16 us at 25 600 x 256).
+extern "C" int ptts_dense_bf16x6_stats(const float* A, const void* planes, const float* bias, float* C, int M, int N, int K,
+                                       long long lda, long long ldc, int in_mode, const float* in_scale, const float* in_shift,
+                                       float alpha, double* stats, int capacity_rows, int* nrows_out, void* stream) {
+    PTTS_REQUIRE(stats && nrows_out && capacity_rows > 0, "dense_bf16x6_stats: no room for the sums");
+    return dense_launch(A, planes, bias, C, M, N, K, lda, ldc, in_mode, in_scale, in_shift, nullptr, alpha, nullptr, 0, 0, nullptr,
+                        stats, capacity_rows, nrows_out, stream);
+}
+// rows of sums ptts_dense_bf16x6_stats writes for an [M, N] product (the caller's capacity)
+extern "C" int ptts_dense_bf16x6_stats_rows(int M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    const int mt = pick_mt(M, (N + NBLK - 1) / NBLK);
+    return (M + 16 * mt - 1) / (16 * mt);
+}
+
+static int dense_launch(const float* A, const void* planes, const float* bias, float* C, int M, int N, int K,
+                        long long lda, long long ldc, int in_mode, const float* in_scale, const float* in_shift,
+                        const float* mask_src, float alpha, const float* res, int res_rows, long long ldr,
+                        const float* out_mask, double* stats, int stats_capacity_rows, int* stats_rows_out, void* stream) {
     const int accumulate = res != nullptr;
     PTTS_REQUIRE(!res || (res_rows > 0 && ldr >= N && M <= 8LL * res_rows), "dense_bf16x6: bad residual (rows %d, ldr %lld)", res_rows, ldr);
     PTTS_REQUIRE(A && planes && C, "dense_bf16x6: null matrix");
@@ -853,6 +899,12 @@ extern "C" int ptts_dense_bf16x6_res(const float* A, const void* planes, const f
     const int cb = (N + NBLK - 1) / NBLK;
     const int mt = pick_mt(M, cb);
     const dim3 grid((unsigned)((M + 16 * mt - 1) / (16 * mt)), (unsigned)cb);
+    g.stats = stats;
+    if (stats) {
+        PTTS_REQUIRE(vec_out, "dense_bf16x6_stats: N and ldc must be multiples of 4, C (and bias) 16-byte aligned");
+        PTTS_REQUIRE(stats_capacity_rows >= (int)grid.x, "dense_bf16x6_stats: room for %d rows of sums, %d needed", stats_capacity_rows, (int)grid.x);
+        *stats_rows_out = (int)grid.x;
+    }
     hipStream_t st = (hipStream_t)stream;
     const bool one = ptts::bf16_products();
 #define DNS_L(MODE, AFF, MT) do { if (one) hipLaunchKernelGGL((dense_bf16x6_kernel<MODE, AFF, MT, 1>), grid, dim3(THREADS), 0, st, g); \
@@ -918,6 +970,7 @@ extern "C" int ptts_dense_bf16x6_batched(const float* A, long long strideA, cons
     g.lda = lda; g.ldc = ldc; g.alpha = 0.f; g.out_alpha = 0.f; g.accumulate = 0; g.has_affine = 0; g.vec_out = vec_out;
     g.res = nullptr; g.res_rows = 1; g.ldr = 0;
     g.bsA = strideA; g.bsP = stride_planes_bytes / 2; g.bsC = strideC;
+    g.stats = nullptr;
     const int cb = (N + NBLK - 1) / NBLK;
     // rows per workgroup: every workgroup of a product reads that product's planes, so fewer row tiles = fewer reads of the right
     // operand, which is most of the traffic of these small-M products

@@ -503,6 +503,59 @@ __global__ __launch_bounds__(256) void bn_finalize_partials_kernel(const double*
     }
 }
 
+// The same for wide layers (the Dense layers' C = 256 ...): a workgroup per 8 channels, 256 lanes = 16 columns (8 sums, 8 sums of squares)
+// x 16 row groups; partials[nrows][2 C].
+__global__ __launch_bounds__(256) void bn_finalize_partials_wide_kernel(const double* __restrict__ partials, int nrows, long long rows, int C,
+                                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                        float* __restrict__ moving_mean, float* __restrict__ moving_var,
+                                                                        float eps, float momentum, int update_moving, int unbiased_moving,
+                                                                        float* __restrict__ scale, float* __restrict__ shift,
+                                                                        float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    __shared__ double sh[16][16];
+    __shared__ double tot[16];
+    const int tid = threadIdx.x, jj = tid & 15, g = tid >> 4;
+    const int c = blockIdx.x * 8 + (jj & 7);
+    const int col = (jj < 8) ? c : C + c;
+    double t = 0.0;
+    if (c < C) {
+        int b = g;
+        for (; b + 48 < nrows; b += 64) {
+            const double v0 = partials[(size_t)b * 2 * C + col], v1 = partials[(size_t)(b + 16) * 2 * C + col];
+            const double v2 = partials[(size_t)(b + 32) * 2 * C + col], v3 = partials[(size_t)(b + 48) * 2 * C + col];
+            t += v0; t += v1; t += v2; t += v3;
+        }
+        for (; b < nrows; b += 16) t += partials[(size_t)b * 2 * C + col];
+    }
+    sh[g][jj] = t;
+    __syncthreads();
+    if (tid < 16) {
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += sh[k][tid];
+        tot[tid] = a;
+    }
+    __syncthreads();
+    if (tid < 8 && blockIdx.x * 8 + tid < C) {
+        const int ch = blockIdx.x * 8 + tid;
+        const double count = (double)rows;
+        const double mean = tot[tid] / count;
+        double var = tot[8 + tid] / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        if (update_moving) {
+            const double vm = (unbiased_moving && rows > 1) ? var * count / (count - 1.0) : var;
+            moving_mean[ch] = (float)(moving_mean[ch] * (double)momentum + mean * (1.0 - (double)momentum));
+            moving_var[ch] = (float)(moving_var[ch] * (double)momentum + vm * (1.0 - (double)momentum));
+        }
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        const double gm = gamma ? (double)gamma[ch] : 1.0;
+        const double bt = beta ? (double)beta[ch] : 0.0;
+        scale[ch] = (float)(gm * rstd);
+        shift[ch] = (float)(bt - mean * gm * rstd);
+        if (mean_out) mean_out[ch] = (float)mean;
+        if (rstd_out) rstd_out[ch] = (float)rstd;
+    }
+}
+
 __global__ void bn_bwd_coefs_kernel(const float* __restrict__ dscale, const float* __restrict__ dshift,
                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                     const float* __restrict__ gamma, long long count, int C,
@@ -790,10 +843,14 @@ extern "C" int ptts_bn_finalize_partials(const double* partials, int nrows, long
                                          float* moving_mean, float* moving_var, float eps, float momentum, int update_moving,
                                          int unbiased_moving, float* scale, float* shift, float* mean, float* rstd, void* stream) {
     PTTS_REQUIRE(partials && scale && shift && nrows > 0 && rows > 0, "bn_finalize_partials: bad args");
-    PTTS_REQUIRE(C >= 1 && C <= 16, "bn_finalize_partials: C = %d (1 .. 16)", C);
+    PTTS_REQUIRE(C >= 1, "bn_finalize_partials: C = %d", C);
     PTTS_REQUIRE(!update_moving || (moving_mean && moving_var), "bn_finalize_partials: update needs moving stats");
-    hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nrows, rows, C, gamma, beta,
-                       moving_mean, moving_var, eps, momentum, update_moving, unbiased_moving, scale, shift, mean, rstd);
+    if (C <= 16)
+        hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nrows, rows, C, gamma, beta,
+                           moving_mean, moving_var, eps, momentum, update_moving, unbiased_moving, scale, shift, mean, rstd);
+    else
+        hipLaunchKernelGGL(bn_finalize_partials_wide_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, partials, nrows, rows, C,
+                           gamma, beta, moving_mean, moving_var, eps, momentum, update_moving, unbiased_moving, scale, shift, mean, rstd);
     return check_launch("bn_finalize_partials");
 }
 

@@ -186,6 +186,16 @@ class Dense(Layer):
                     z = (z.view((k,) + tuple(y.shape)) + y).view(z.shape)
                 else:
                     z = y if z is None else z + y
+        elif getattr(self, 'bn_follows', False) and training and self.activation in (None, 'linear'):
+            # the BatchNormalization behind this layer takes its statistics from sums the product's launch leaves (ops._BNStats)
+            ops._BNStats.want, ops._BNStats.last = True, None
+            try:
+                z = ops.dense(v, self.kernel, self.bias)
+            finally:
+                ops._BNStats.want = False
+            if ops._BNStats.last is not None:
+                z._ptts_bn_partials, ops._BNStats.last = ops._BNStats.last, None
+            return z
         else:
             z = ops.dense(v, self.kernel, self.bias)
         return _apply_activation(z, self.activation)

@@ -15,7 +15,9 @@ from .layers import GaussianNoiseInput   # re-exported: networktts.GaussianNoise
 
 def pFC(input, width, bn=True, **kwargs):
     """Dense(use_bias = not bn) -> BN -> LeakyReLU(.3)   (networktts.py:59-63)"""
-    output = kl.Dense(width, use_bias=not bn, **kwargs)(input)
+    fc = kl.Dense(width, use_bias=not bn, **kwargs)
+    fc.bn_follows = bool(bn)          # (the layer's launch also sums its output's columns for the BatchNormalization behind it: kl.Dense.compute)
+    output = fc(input)
     if bn: output = kl.BatchNormalization()(output)
     return kl.LeakyReLU(alpha=0.3)(output)
 

@@ -376,11 +376,12 @@ def _is16(t):
 
 
 class _BNStats(object):
-    """A Conv2D layer that feeds a BatchNormalization layer asks its forward launch for the per-channel sums of what it stores
-    (csrc/conv2d_mfma.hip, fwd_ws_kernel<.., STATS>): `want` is set around the layer's ops.conv2d call, `last` = (partial rows
-    [256, 8] float64, number of rows written, values per channel) is what the launch left -- or None when the shape took another kernel.
-    layers.Conv2D hangs it on the map (`_ptts_bn_partials`), BatchNormTrainFn finishes it with ptts_bn_finalize_partials instead of
-    running ptts_bn_batch_stats over the map (16 us a layer and forward pass, 7 such layers in the generator).  PTTS_CONV_BN_STATS=0: off."""
+    """A Conv2D / Dense layer that feeds a BatchNormalization layer asks its forward launch for the per-channel sums of what it stores
+    (csrc/conv2d_mfma.hip, fwd_ws_kernel<.., STATS>; csrc/dense.hip, DenseArgs.stats): `want` is set around the layer's ops.conv2d /
+    ops.dense call, `last` = (partial rows [n, 2 C] float64, number of rows written, values per channel) is what the launch left -- or
+    None when the shape took another kernel.  The layer hangs it on its output (`_ptts_bn_partials`), BatchNormTrainFn finishes it with
+    ptts_bn_finalize_partials instead of a statistics pass over the tensor (conv maps: ptts_bn_batch_stats, 16 us a layer and forward
+    pass, 7 such layers in the generator; Dense outputs: ptts_colstats + ptts_bn_finalize, 22 us).  PTTS_CONV_BN_STATS=0: off."""
     enabled = os.environ.get('PTTS_CONV_BN_STATS', '1') == '1'
     want = False
     last = None
@@ -698,6 +699,16 @@ def gemm_raw(A, Bm, C, M, N, K, transA=0, lda=None, rows_per_seg=None, seg_strid
         N1 = N if (N <= 256 or N % 256 == 0 or N % 256 > 32) else N - N % 256
         if _DenseSplit.eligible(A, C, M, N1, K, lda, ldc, (scale, shift, mask_src)):
             planes = _DenseSplit.get(Bm, K, N1, ldb, transB)
+            if planes is not None and _BNStats.want and _BNStats.enabled and N1 == N and N % 4 == 0 and ldc % 4 == 0 and mask_src is None and \
+                    out_mask is None and not accumulate and mode in (IN_NONE, IN_LRELU):
+                # a Dense layer in front of a BatchNormalization layer: the launch leaves the column sums of what it stores (_BNStats)
+                cap = _hip.lib().ptts_dense_bf16x6_stats_rows(M, N)
+                part = torch.empty((cap, 2 * N), dtype=torch.float64, device=A.device)
+                nrows = ctypes.c_int(0)
+                call('ptts_dense_bf16x6_stats', ptr(A), ptr(planes), ptr(bias), ptr(C), M, N, K, lda, ldc, mode, ptr(scale), ptr(shift),
+                     alpha, ptr(part), cap, ctypes.byref(nrows), stream(), tag=(M, N, K, transB, 'stats'))
+                _BNStats.last = (part, nrows.value, M)
+                return C
             if planes is not None:
                 call('ptts_dense_bf16x6', ptr(A), ptr(planes), ptr(bias), ptr(C), M, N1, K, lda, ldc, mode, ptr(scale), ptr(shift),
                      ptr(mask_src), alpha, accumulate, ptr(out_mask), stream(), tag=(M, N1, K, transB))
@@ -1891,7 +1902,7 @@ class BatchNormTrainFn(torch.autograd.Function):
         # computes them (two AccumulateGrad add launches per BatchNorm layer less: 30 per generator step)
         ctx.gt = (grad_target(gamma), grad_target(beta)) if _Deferred.active else None
         part = getattr(z, '_ptts_bn_partials', None)
-        if part is not None and ctx.sync <= 1 and C == 4 and part[2] == rows:
+        if part is not None and ctx.sync <= 1 and part[2] == rows and part[0].shape[1] == 2 * C:
             # the convolution that produced z summed what it stored (_BNStats): only the finish is left
             call('ptts_bn_finalize_partials', ptr(part[0]), part[1], rows, C, ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var),
                  BN_EPS, BN_MOMENTUM, 1 if update_moving else 0, 1 if unbiased_moving else 0, ptr(scale), ptr(shift), ptr(mean), ptr(rstd),

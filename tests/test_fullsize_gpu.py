@@ -539,10 +539,10 @@ def test_generator_forward_one_batch_ahead_gives_the_same_two_batches(setup):
 
 
 def test_batchnorm_statistics_taken_from_the_convolutions_sums(setup):
-    """ops._BNStats (default on): the generator's 4 -> 4 Conv2D layers sum what they store and the BatchNormalization behind each takes its
-    batch moments from those sums (reference networktts.py:122-126: Conv2D -> BatchNormalization -> LeakyReLU).  Same map, same moments up
-    to the order of the additions: the generator step gives the same loss, gradients and moving statistics as with a statistics pass per
-    layer, and seven of the eight passes are gone."""
+    """ops._BNStats (default on): the generator's 4 -> 4 Conv2D layers and its Dense layers sum what they store, and the BatchNormalization
+    behind each takes its batch moments from those sums (reference networktts.py:59-63, 122-126: Dense / Conv2D -> BatchNormalization ->
+    LeakyReLU).  Same tensors, same moments up to the order of the additions: the generator step gives the same loss, gradients and moving
+    statistics as with a statistics pass per layer, and those passes are gone."""
     from percivaltts_amd import ops, _hip
     cfg, opt, crit, X, Y = setup
     state = (opt.gen_opti.flat.flat, opt.gen_opti.m, opt.gen_opti.v, opt.gen_opti.step_count)
@@ -564,7 +564,8 @@ def test_batchnorm_statistics_taken_from_the_convolutions_sums(setup):
             opt.wait_updates(); torch.cuda.synchronize()
             names = [r[0] for r in kt.records]
             res.append((float(lg), opt.gen_opti.flat.grad.detach().clone(), [t.detach().clone() for t in moving],
-                        names.count('ptts_bn_finalize_partials'), names.count('ptts_bn_batch_stats'), names.count('ptts_conv2d_mfma_fwd_stats')))
+                        names.count('ptts_bn_finalize_partials'), names.count('ptts_bn_batch_stats'), names.count('ptts_conv2d_mfma_fwd_stats'),
+                        names.count('ptts_dense_bf16x6_stats'), names.count('ptts_colstats')))
     finally:
         ops.conv_bn_stats(None)
         opt.wait_updates()
@@ -573,9 +574,10 @@ def test_batchnorm_statistics_taken_from_the_convolutions_sums(setup):
         for dst, src in zip(moving, moving0):
             dst.copy_(src)
         opt.gen_opti.flat.epoch += 1
-    (l1, g1, m1, nf1, nb1, nc1), (l0, g0, m0, nf0, nb0, nc0) = res
-    assert (nf0, nc0) == (0, 0) and nb0 >= 8
-    assert nf1 == nc1 and nf1 >= 7 and nb1 == nb0 - nf1, (nf1, nc1, nb1, nb0)
+    (l1, g1, m1, nf1, nb1, nc1, nd1, ns1), (l0, g0, m0, nf0, nb0, nc0, nd0, ns0) = res
+    assert (nf0, nc0, nd0) == (0, 0, 0) and nb0 >= 8
+    # seven convolutions and the Dense layers in front of a BatchNormalization sum their own outputs: so many statistics passes less
+    assert nc1 >= 7 and nd1 >= 3 and nf1 == nc1 + nd1 and nb1 == nb0 - nc1 and ns1 == ns0 - nd1, (nf1, nc1, nd1, nb1, nb0, ns1, ns0)
     assert abs(l1 - l0) <= 1e-5 * max(1.0, abs(l0)), (l1, l0)
     assert rel_l2(g1, g0) < 1e-3, rel_l2(g1, g0)
     for a, b in zip(m1, m0):

@@ -1569,3 +1569,55 @@ def test_conv2d_forward_that_sums_its_outputs_for_the_batchnorm_behind_it(ops, c
     mu = yd.mean(0); var = yd.var(0, unbiased=False)
     close(outs[1][2], mu, 1e-5, 1e-6, 'batch mean against the oracle')
     close(outs[1][3], 1.0 / torch.sqrt(var + 1e-3), 1e-5, 0.0, 'batch rstd against the oracle')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [(2048, 256, 256), (1500, 256, 260), (25600, 256, 256), (3001, 512, 64), (1100, 128, 2048)])
+@pytest.mark.parametrize('mode', ['none', 'lrelu', 'affine'])
+def test_dense_product_that_sums_its_columns_for_the_batchnorm_behind_it(ops, case, mode):
+    """ptts_dense_bf16x6_stats (the Dense of pFC, reference networktts.py:59-63, in front of its BatchNormalization): the product is the plain
+    launch's bit for bit, the per-row-tile rows add up to the column sums of the product and of its squares, and ptts_bn_finalize_partials
+    gives the batch moments of the fp64 oracle."""
+    import ctypes
+    M, N, K = case
+    g = gen(92)
+    from percivaltts_amd import layers
+    x = torch.randn(M, K, generator=g).cuda()
+    w0 = torch.randn(K, N, generator=g) * 0.1
+
+    class Holder(torch.nn.Module):               # (the split kernel keeps planes of weights that live in a flat parameter buffer)
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(w0.clone())
+    h = Holder(); flat = layers.FlatParams(h, 'cuda')
+    w = h.w
+    b = torch.randn(N, generator=g).cuda()
+    sc = (torch.rand(K, generator=g) + 0.5).cuda() if mode == 'affine' else None
+    sh = (torch.randn(K, generator=g) * 0.3).cuda() if mode == 'affine' else None
+    in_mode = ops.IN_NONE if mode == 'none' else ops.IN_LRELU
+    y0 = torch.empty(M, N, device='cuda'); y1 = torch.empty(M, N, device='cuda')
+    ops.gemm_raw(x, w, y0, M, N, K, bias=b, mode=in_mode, scale=sc, shift=sh, alpha=0.3)
+    ops._BNStats.want, ops._BNStats.last = True, None
+    try:
+        ops.gemm_raw(x, w, y1, M, N, K, bias=b, mode=in_mode, scale=sc, shift=sh, alpha=0.3)
+    finally:
+        ops._BNStats.want = False
+    assert ops._BNStats.last is not None, 'the split Dense kernel did not take this shape'
+    part, nrows, count = ops._BNStats.last
+    ops._BNStats.last = None
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1) and count == M and 1 <= nrows <= part.shape[0] and part.shape[1] == 2 * N
+    yd = y0.double().cpu()
+    sums = part[:nrows].sum(0).cpu()
+    close(sums[:N], yd.sum(0), 1e-5, 1e-5 * float(yd.abs().sum(0).max()), 'column sums')
+    close(sums[N:], (yd * yd).sum(0), 1e-5, 0.0, 'column sums of squares')
+    gamma = (torch.rand(N, generator=g) + 0.5).cuda(); beta = torch.randn(N, generator=g).cuda()
+    mm = torch.full((N,), 0.25, device='cuda'); mv = torch.full((N,), 2.0, device='cuda')
+    scale, shift, mean, rstd = (torch.empty(N, device='cuda') for _ in range(4))
+    ops.call('ptts_bn_finalize_partials', ops.ptr(part), nrows, M, N, ops.ptr(gamma), ops.ptr(beta), ops.ptr(mm), ops.ptr(mv), 1e-3, 0.99, 1, 0,
+             ops.ptr(scale), ops.ptr(shift), ops.ptr(mean), ops.ptr(rstd), ops.stream())
+    torch.cuda.synchronize()
+    mu = yd.mean(0); var = yd.var(0, unbiased=False); rs = 1.0 / torch.sqrt(var + 1e-3)
+    close(mean, mu, 1e-5, 1e-5, 'batch mean'); close(rstd, rs, 1e-5, 0.0, 'batch rstd')
+    close(scale, gamma.double().cpu() * rs, 1e-5, 0.0, 'scale'); close(shift, beta.double().cpu() - mu * gamma.double().cpu() * rs, 1e-5, 1e-5, 'shift')
+    close(mm, 0.25 * 0.99 + mu * 0.01, 1e-5, 1e-6, 'moving mean'); close(mv, 2.0 * 0.99 + var * 0.01, 1e-5, 1e-6, 'moving variance')
