@@ -337,6 +337,16 @@ int ptts_dense_bf16x6_stats_rows(int M, int N);
 int ptts_dense_bf16x6_stats(const float* A, const void* planes, const float* bias, float* C, int M, int N, int K,
                             long long lda, long long ldc, int in_mode, const float* in_scale, const float* in_shift,
                             float alpha, double* stats, int capacity_rows, int* nrows_out, void* stream);
+/* Backward-data product of a kl.Dense whose input was the kl.BatchNormalization + kl.LeakyReLU of pFC (networktts.py:59-63), i.e.
+ * lrelu(scale z + shift):  C = dz = (A . B) lrelu'(scale z + shift) scale  with A = dy [M, K], B = W^T (planes of the transposed kernel,
+ * [K, N]), z [M, N]; and per row tile the column sums of (A . B) lrelu'(.) z and of (A . B) lrelu'(.) -- the gradients of scale and
+ * shift -- as stats[*nrows_out][2 N] doubles, which ptts_partial_rows_sum adds.  What TF runs as MatMul + LeakyReluGrad + the reductions of
+ * FusedBatchNormGrad's first stage; replaces ptts_dense_bf16x6 + ptts_affine_act_bwd (a pass over da and z). */
+int ptts_dense_bf16x6_bwd_affine(const float* A, const void* planes, float* C, int M, int N, int K, long long lda, long long ldc,
+                                 const float* z, const float* scale, const float* shift, float alpha,
+                                 double* stats, int capacity_rows, int* nrows_out, void* stream);
+/* out[j] = sum_r partials[r][j] (doubles), rows added in index order. */
+int ptts_partial_rows_sum(const double* partials, int nrows, int ncols, double* out, void* stream);
 /* Frequency-domain context Conv1D, helper: Ap [NB][2][B][2*Kh] floats with [Xr | .] in part 0 and [Xi | .] in part 1 (columns < Cin)
  * -> columns Kh .. Kh+Cin-1 get -Xi (part 0) and Xr (part 1): the rows [Xr | -Xi], [Xi | Xr] of the real form of a complex product. */
 int ptts_dft_mirror(float* Ap, int NB, int B, int Cin, int Kh, void* stream);

@@ -98,6 +98,8 @@ SIGNATURES = {
     'ptts_dense_bf16x6': (c_i, [c_p] * 4 + [c_i] * 3 + [c_ll, c_ll, c_i, c_p, c_p, c_p, c_f, c_i, c_p, c_p]),
     'ptts_dense_bf16x6_stats_rows': (c_i, [c_i, c_i]),
     'ptts_dense_bf16x6_stats': (c_i, [c_p] * 4 + [c_i] * 3 + [c_ll, c_ll, c_i, c_p, c_p, c_f, c_p, c_i, c_p, c_p]),
+    'ptts_dense_bf16x6_bwd_affine': (c_i, [c_p] * 3 + [c_i] * 3 + [c_ll, c_ll, c_p, c_p, c_p, c_f, c_p, c_i, c_p, c_p]),
+    'ptts_partial_rows_sum': (c_i, [c_p, c_i, c_i, c_p, c_p]),
     'ptts_dense_bf16x6_res': (c_i, [c_p] * 4 + [c_i] * 3 + [c_ll, c_ll, c_i, c_p, c_p, c_p, c_f, c_p, c_i, c_ll, c_p, c_p]),
     'ptts_conv1d_freq_kernel_planes': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     'ptts_transpose_batched': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),

@@ -228,6 +228,7 @@ struct DenseArgs {
     const float* res; int res_rows; long long ldr;      // residual added in the store: C[m][n] += res[m % res_rows][n] (NULL: none).  accumulate = res == C
     long long bsA, bsP, bsC;          // batched launch (gridDim.z products of one shape): strides of A and C in floats, of the planes in u16
     double* stats;                    // (ptts_dense_bf16x6_stats) per row tile: the column sums and the column sums of squares of what is stored, [gridDim.x][2 N]
+    const float* om_scale; const float* om_shift;     // (ptts_dense_bf16x6_bwd_affine) out_mask holds z of a BatchNorm-affine + LeakyReLU input: see the store
 };
 
 template <int MODE, bool AFFINE, int MT, int NPL>
@@ -416,6 +417,19 @@ __global__ __launch_bounds__(THREADS) void dense_bf16x6_kernel(DenseArgs g) {
         // row of the residual: m modulo res_rows (a product shared by k stacked evaluations is added to each of its k row blocks)
         auto res_at = [&](int m) { int mr = m; while (mr >= g.res_rows) mr -= g.res_rows; return g.res + (long long)mr * g.ldr + n; };
         f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+        // ptts_dense_bf16x6_bwd_affine: the product is da = dy . W^T of a layer whose input was lrelu(sc z + sh), z = out_mask.  What is
+        // stored is dz = da lrelu'(sc z + sh) sc; the tile's column sums are those of da lrelu'(.) z (ssum: the affine's dscale) and of
+        // da lrelu'(.) (ssq: its dshift) -- ptts_affine_act_bwd's arithmetic, without its pass over da and z
+        f32x4 osc = {1.f, 1.f, 1.f, 1.f}, osh = {0.f, 0.f, 0.f, 0.f};
+        if (g.om_scale) { osc = *reinterpret_cast<const f32x4*>(g.om_scale + n); osh = *reinterpret_cast<const f32x4*>(g.om_shift + n); }
+        auto aff_store = [&](f32x4& v, const f32x4& z) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gd = v[e] * ((z[e] * osc[e] + osh[e]) > 0.f ? 1.f : g.out_alpha);
+                ssum[e] += gd * z[e]; ssq[e] += gd;
+                v[e] = gd * osc[e];
+            }
+        };
         if (interior) {
             f32x4 mk[MT], old[MT];
             if (g.out_mask) {
@@ -429,12 +443,14 @@ __global__ __launch_bounds__(THREADS) void dense_bf16x6_kernel(DenseArgs g) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 f32x4 v = acc[i][j] + bv;
-                if (g.out_mask) {
+                if (g.om_scale) {
+                    aff_store(v, mk[i]);
+                } else if (g.out_mask) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] * (mk[i][e] > 0.f ? 1.f : g.out_alpha);
                 }
                 if (g.res) v += old[i];
-                if (g.stats) { ssum += v; ssq += v * v; }
+                if (g.stats && !g.om_scale) { ssum += v; ssq += v * v; }
                 *reinterpret_cast<f32x4*>(g.C + off0 + (long long)16 * i * g.ldc) = v;
             }
         } else {
@@ -446,11 +462,15 @@ __global__ __launch_bounds__(THREADS) void dense_bf16x6_kernel(DenseArgs g) {
                 f32x4 v = acc[i][j] + bv;
                 if (g.out_mask) {
                     const f32x4 mk = *reinterpret_cast<const f32x4*>(g.out_mask + off);
+                    if (g.om_scale) {
+                        aff_store(v, mk);
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] * (mk[e] > 0.f ? 1.f : g.out_alpha);
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] * (mk[e] > 0.f ? 1.f : g.out_alpha);
+                    }
                 }
                 if (g.res) v += *reinterpret_cast<const f32x4*>(res_at(m));
-                if (g.stats) { ssum += v; ssq += v * v; }
+                if (g.stats && !g.om_scale) { ssum += v; ssq += v * v; }
                 *reinterpret_cast<f32x4*>(g.C + off) = v;
             }
         }
@@ -844,6 +864,8 @@ static int dense_launch(const float* A, const void* planes, const float* bias, f
                         long long lda, long long ldc, int in_mode, const float* in_scale, const float* in_shift,
                         const float* mask_src, float alpha, const float* res, int res_rows, long long ldr,
                         const float* out_mask, double* stats, int stats_capacity_rows, int* stats_rows_out, void* stream);
+static thread_local const float* g_om_scale = nullptr;        // (set around dense_launch by ptts_dense_bf16x6_bwd_affine)
+static thread_local const float* g_om_shift = nullptr;
 
 extern "C" int ptts_dense_bf16x6_res(const float* A, const void* planes, const float* bias, float* C, int M, int N, int K,
                                      long long lda, long long ldc, int in_mode, const float* in_scale, const float* in_shift,
@@ -862,6 +884,21 @@ extern "C" int ptts_dense_bf16x6_stats(const float* A, const void* planes, const
     PTTS_REQUIRE(stats && nrows_out && capacity_rows > 0, "dense_bf16x6_stats: no room for the sums");
     return dense_launch(A, planes, bias, C, M, N, K, lda, ldc, in_mode, in_scale, in_shift, nullptr, alpha, nullptr, 0, 0, nullptr,
                         stats, capacity_rows, nrows_out, stream);
+}
+// Backward-data product of a Dense layer whose input was lrelu(scale z + shift) (a BatchNormalization in front: pFC, networktts.py:59-63):
+// C = dz = (A . B) lrelu'(scale z + shift) scale with A = dy, B = W^T (planes of the transposed kernel), and per row tile the column sums
+// of (A . B) lrelu'(.) z and of (A . B) lrelu'(.) -- the gradients of scale and shift -- as stats[*nrows_out][2 N] doubles
+// (ptts_partial_rows_sum adds the rows).  Replaces the product + ptts_affine_act_bwd's pass over da and z.
+extern "C" int ptts_dense_bf16x6_bwd_affine(const float* A, const void* planes, float* C, int M, int N, int K, long long lda, long long ldc,
+                                            const float* z, const float* scale, const float* shift, float alpha,
+                                            double* stats, int capacity_rows, int* nrows_out, void* stream) {
+    PTTS_REQUIRE(z && scale && shift && stats && nrows_out && capacity_rows > 0, "dense_bf16x6_bwd_affine: null pointer");
+    PTTS_REQUIRE((((uintptr_t)scale | (uintptr_t)shift) & 15) == 0, "dense_bf16x6_bwd_affine: scale / shift must be 16-byte aligned");
+    g_om_scale = scale; g_om_shift = shift;
+    const int rc = dense_launch(A, planes, nullptr, C, M, N, K, lda, ldc, PTTS_IN_NONE, nullptr, nullptr, nullptr, alpha, nullptr, 0, 0, z,
+                                stats, capacity_rows, nrows_out, stream);
+    g_om_scale = g_om_shift = nullptr;
+    return rc;
 }
 // rows of sums ptts_dense_bf16x6_stats writes for an [M, N] product (the caller's capacity)
 extern "C" int ptts_dense_bf16x6_stats_rows(int M, int N) {
@@ -900,6 +937,7 @@ static int dense_launch(const float* A, const void* planes, const float* bias, f
     const int mt = pick_mt(M, cb);
     const dim3 grid((unsigned)((M + 16 * mt - 1) / (16 * mt)), (unsigned)cb);
     g.stats = stats;
+    g.om_scale = g_om_scale; g.om_shift = g_om_shift;
     if (stats) {
         PTTS_REQUIRE(vec_out, "dense_bf16x6_stats: N and ldc must be multiples of 4, C (and bias) 16-byte aligned");
         PTTS_REQUIRE(stats_capacity_rows >= (int)grid.x, "dense_bf16x6_stats: room for %d rows of sums, %d needed", stats_capacity_rows, (int)grid.x);
@@ -970,7 +1008,7 @@ extern "C" int ptts_dense_bf16x6_batched(const float* A, long long strideA, cons
     g.lda = lda; g.ldc = ldc; g.alpha = 0.f; g.out_alpha = 0.f; g.accumulate = 0; g.has_affine = 0; g.vec_out = vec_out;
     g.res = nullptr; g.res_rows = 1; g.ldr = 0;
     g.bsA = strideA; g.bsP = stride_planes_bytes / 2; g.bsC = strideC;
-    g.stats = nullptr;
+    g.stats = nullptr; g.om_scale = g.om_shift = nullptr;
     const int cb = (N + NBLK - 1) / NBLK;
     // rows per workgroup: every workgroup of a product reads that product's planes, so fewer row tiles = fewer reads of the right
     // operand, which is most of the traffic of these small-M products

@@ -839,6 +839,14 @@ extern "C" int ptts_bn_batch_stats(const float* x, long long rows, int C, const 
     return check_launch("bn_batch_stats");
 }
 
+// out[j] = sum over the nrows rows of partials[nrows][ncols] (doubles), in index order: the finish of sums another kernel left per
+// workgroup (ptts_dense_bf16x6_bwd_affine)
+extern "C" int ptts_partial_rows_sum(const double* partials, int nrows, int ncols, double* out, void* stream) {
+    PTTS_REQUIRE(partials && out && nrows > 0 && ncols > 0, "partial_rows_sum: bad args");
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((ncols + 7) / 8), dim3(256), 0, (hipStream_t)stream, partials, nrows, ncols, out);
+    return check_launch("partial_rows_sum");
+}
+
 extern "C" int ptts_bn_finalize_partials(const double* partials, int nrows, long long rows, int C, const float* gamma, const float* beta,
                                          float* moving_mean, float* moving_var, float eps, float momentum, int update_moving,
                                          int unbiased_moving, float* scale, float* shift, float* mean, float* rstd, void* stream) {

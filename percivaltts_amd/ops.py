@@ -1158,6 +1158,22 @@ def _dense_bwd_data(dy2, x2, w, mode, scale, shift, alpha, want_affine):
         # no BatchNorm in front: the LeakyReLU mask of the layer input goes into the GEMM epilogue
         gemm_raw(dy2, w, da, M, K, N, transB=1, ldb=N, alpha=alpha, out_mask=x2)
         return da, None, None
+    if mode == IN_LRELU and _BNStats.enabled and K % 4 == 0 and _DenseSplit.eligible(dy2, da, M, K, N, N, K, (x2, scale, shift)):
+        # a BatchNormalization in front: the mask of lrelu(scale z + shift), the factor scale and the two column sums that are the
+        # affine's gradients go into the product's store (ptts_dense_bf16x6_bwd_affine) -- no pass over da and z behind it
+        planes = _DenseSplit.get(w, N, K, N, 1)
+        if planes is not None:
+            cap = _hip.lib().ptts_dense_bf16x6_stats_rows(M, K)
+            part = torch.empty((cap, 2 * K), dtype=torch.float64, device=dy2.device)
+            nrows = ctypes.c_int(0)
+            call('ptts_dense_bf16x6_bwd_affine', ptr(dy2), ptr(planes), ptr(da), M, K, N, N, K, ptr(x2), ptr(scale), ptr(shift), alpha,
+                 ptr(part), cap, ctypes.byref(nrows), stream(), tag=(M, K, N, 1, 'bwd_affine'))
+            if not want_affine:
+                return da, None, None
+            dsums = torch.empty(2 * K, dtype=torch.float64, device=dy2.device)
+            call('ptts_partial_rows_sum', ptr(part), nrows.value, 2 * K, ptr(dsums), stream())
+            d32 = dsums.to(torch.float32)
+            return da, d32[:K], d32[K:]
     gemm_raw(dy2, w, da, M, K, N, transB=1, ldb=N)
     if mode == IN_NONE:
         return da, None, None

@@ -565,7 +565,8 @@ def test_batchnorm_statistics_taken_from_the_convolutions_sums(setup):
             names = [r[0] for r in kt.records]
             res.append((float(lg), opt.gen_opti.flat.grad.detach().clone(), [t.detach().clone() for t in moving],
                         names.count('ptts_bn_finalize_partials'), names.count('ptts_bn_batch_stats'), names.count('ptts_conv2d_mfma_fwd_stats'),
-                        names.count('ptts_dense_bf16x6_stats'), names.count('ptts_colstats')))
+                        names.count('ptts_dense_bf16x6_stats'), names.count('ptts_colstats'),
+                        names.count('ptts_dense_bf16x6_bwd_affine'), names.count('ptts_affine_act_bwd')))
     finally:
         ops.conv_bn_stats(None)
         opt.wait_updates()
@@ -574,8 +575,11 @@ def test_batchnorm_statistics_taken_from_the_convolutions_sums(setup):
         for dst, src in zip(moving, moving0):
             dst.copy_(src)
         opt.gen_opti.flat.epoch += 1
-    (l1, g1, m1, nf1, nb1, nc1, nd1, ns1), (l0, g0, m0, nf0, nb0, nc0, nd0, ns0) = res
-    assert (nf0, nc0, nd0) == (0, 0, 0) and nb0 >= 8
+    (l1, g1, m1, nf1, nb1, nc1, nd1, ns1, na1, nab1), (l0, g0, m0, nf0, nb0, nc0, nd0, ns0, na0, nab0) = res
+    assert (nf0, nc0, nd0, na0) == (0, 0, 0, 0) and nb0 >= 8
+    # backward: the Dense layers behind a BatchNormalization + LeakyReLU put that input's mask, its scale and the affine's two gradient
+    # sums into their backward-data product's store: so many ptts_affine_act_bwd passes less
+    assert na1 >= 3 and nab1 == nab0 - na1, (na1, nab1, nab0)
     # seven convolutions and the Dense layers in front of a BatchNormalization sum their own outputs: so many statistics passes less
     assert nc1 >= 7 and nd1 >= 3 and nf1 == nc1 + nd1 and nb1 == nb0 - nc1 and ns1 == ns0 - nd1, (nf1, nc1, nd1, nb1, nb0, ns1, ns0)
     assert abs(l1 - l0) <= 1e-5 * max(1.0, abs(l0)), (l1, l0)

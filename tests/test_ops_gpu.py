@@ -1621,3 +1621,44 @@ def test_dense_product_that_sums_its_columns_for_the_batchnorm_behind_it(ops, ca
     close(mean, mu, 1e-5, 1e-5, 'batch mean'); close(rstd, rs, 1e-5, 0.0, 'batch rstd')
     close(scale, gamma.double().cpu() * rs, 1e-5, 0.0, 'scale'); close(shift, beta.double().cpu() - mu * gamma.double().cpu() * rs, 1e-5, 1e-5, 'shift')
     close(mm, 0.25 * 0.99 + mu * 0.01, 1e-5, 1e-6, 'moving mean'); close(mv, 2.0 * 0.99 + var * 0.01, 1e-5, 1e-6, 'moving variance')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [(2048, 256, 256), (25600, 256, 256), (1500, 64, 512), (3001, 260, 128)])
+def test_dense_backward_data_through_a_batchnorm_affine_in_its_store(ops, case):
+    """ptts_dense_bf16x6_bwd_affine (the backward-data product of a Dense whose input was BatchNormalization + LeakyReLU, reference
+    networktts.py:59-63) against the two-launch path it replaces (product, then ptts_affine_act_bwd) and against fp64: dz, and the
+    gradients of the affine's scale and shift."""
+    from percivaltts_amd import layers
+    M, K, N = case                       # the layer: [M, K] . [K, N]; backward data: dy [M, N] -> dz [M, K]
+    g = gen(93)
+    z = torch.randn(M, K, generator=g).cuda()
+    dy = torch.randn(M, N, generator=g).cuda()
+    w0 = torch.randn(K, N, generator=g) * 0.1
+    sc = (torch.rand(K, generator=g) + 0.5).cuda(); sh = (torch.randn(K, generator=g) * 0.3).cuda()
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(w0.clone())
+    h = Holder(); flat = layers.FlatParams(h, 'cuda')
+    w = h.w
+    outs = []
+    for on in (True, False):
+        ops.conv_bn_stats(on)
+        try:
+            with ops._hip.KernelTimer() as kt:
+                dz, dsc, dsh = ops._dense_bwd_data(dy, z, w, ops.IN_LRELU, sc, sh, 0.3, True)
+            torch.cuda.synchronize()
+        finally:
+            ops.conv_bn_stats(None)
+        outs.append((dz, dsc, dsh, [r[0] for r in kt.records]))
+    assert 'ptts_dense_bf16x6_bwd_affine' in outs[0][3] and 'ptts_affine_act_bwd' not in outs[0][3]
+    assert 'ptts_affine_act_bwd' in outs[1][3]
+    da = dy.double().cpu() @ w.detach().double().cpu().t()
+    zd = z.double().cpu()
+    gd = da * torch.where(zd * sc.double().cpu() + sh.double().cpu() > 0, 1.0, 0.3)
+    for (dz, dsc, dsh, _), what in zip(outs, ('in the store', 'two launches')):
+        close(dz, gd * sc.double().cpu(), 2e-4, 2e-4 * float(gd.abs().mean()), 'dz ' + what)
+        close(dsc, (gd * zd).sum(0), 1e-4, 1e-4 * float((gd * zd).abs().sum(0).mean()), 'dscale ' + what)
+        close(dsh, gd.sum(0), 1e-4, 1e-4 * float(gd.abs().sum(0).mean()), 'dshift ' + what)
