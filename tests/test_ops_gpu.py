@@ -509,6 +509,14 @@ def test_gemm_thin_shapes(ops):
         ops.gemm_raw(dev(A), dev(D), W, K, N, M, transA=1, lda=K, rows_per_seg=M, mode=ops.IN_MASKMUL, mask_src=dev(msk), accumulate=1)
         close(W, O.lrelu(A * sc + sh).t() @ D + (A * torch.where(msk > 0, 1.0, 0.3)).t() @ D, rtol=2e-4, atol=1e-2,
               what='wcol maskmul acc N=%d' % N)
+    # ... at the critic's head (25 600 frames) and with a column count that is no multiple of 256 (the four-column kernel's tail lanes)
+    for M2, K2 in ((25600, 256), (5003, 260), (2048, 516)):
+        A2 = torch.randn(M2, K2, generator=g, dtype=torch.float64)
+        D2 = torch.randn(M2, 1, generator=g, dtype=torch.float64)
+        W2 = torch.empty(K2, 1, dtype=torch.float32, device='cuda')
+        ops.gemm_raw(dev(A2), dev(D2), W2, K2, 1, M2, transA=1, lda=K2, rows_per_seg=M2, mode=ops.IN_LRELU)
+        ref = O.lrelu(A2).t() @ D2
+        close(W2, ref, rtol=2e-4, atol=2e-4 * float(ref.abs().max()), what='wcol at [%d, %d]' % (M2, K2))
 
 
 @pytest.mark.parametrize('mode', ['none', 'lrelu', 'affine'])
