@@ -5,6 +5,9 @@
 //   wcol  : C[Mo, N<=2] = T(A)[Kr, Mo]^T . B[Kr, N]   (column sums of A weighted by 1-2 columns of B; fp32 atomics)
 // All are HBM-bound single passes over the big operand.
 #include "common.h"
+#include <mutex>
+#include <vector>
+#include <utility>
 
 namespace ptts {
 
@@ -207,6 +210,144 @@ __global__ __launch_bounds__(256) void wcol_kernel(ThinArgs g, int rows) {
     }
 }
 
+// The same product in TWO stages without atomics (round 4): every workgroup of wcol_part_kernel leaves its share of the rows as one
+// partial row part[row block][Mo][NT], wcol_reduce_kernel adds the row blocks in index order.  With atomics the kernel could not
+// have both enough row blocks to hide the loads' latency (2048 workgroups: 512 per output address) and few enough atomics on its
+// 256 output addresses -- 44 us for the [25 600, 256] activation of the critic's 1-wide head, 0.6 TB/s.  Deterministic as well.
+template <int NT>
+__global__ __launch_bounds__(256) void wcol_part_kernel(ThinArgs g, int rows, float* __restrict__ part) {
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    __shared__ float sh[NT][4][64];
+    const int i = blockIdx.x * 64 + lane;
+    float acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = 0.f;
+    if (i < g.M) {
+        const long long step = (long long)gridDim.y * 4;
+        long long r = (long long)blockIdx.y * 4 + rg;
+        for (; r + 3 * step < rows; r += 4 * step) {
+            float a[4], b[4][NT];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long rr = r + u * step, offa = rr * g.lda + i;
+                a[u] = thin_xform(g.A[offa], g, offa, i);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) b[u][n] = n < g.N ? g.B[rr * g.ldb + n] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = fmaf(a[u], b[u][n], acc[n]);
+        }
+        for (; r < rows; r += step) {
+            const long long offa = r * g.lda + i;
+            const float a = thin_xform(g.A[offa], g, offa, i);
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                if (n < g.N) acc[n] = fmaf(a, g.B[r * g.ldb + n], acc[n]);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) sh[n][rg][lane] = acc[n];
+    __syncthreads();
+    if (rg == 0 && i < g.M) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+            part[((size_t)blockIdx.y * g.M + i) * NT + n] = (sh[n][0][lane] + sh[n][1][lane]) + (sh[n][2][lane] + sh[n][3][lane]);
+    }
+}
+// ... with FOUR columns per lane (16-byte loads; a wave covers 256 columns of a row, the workgroup's four waves four row phases):
+// Mo % 4 == 0, lda % 4 == 0, A and the mask source 16-byte aligned
+template <int NT>
+__global__ __launch_bounds__(256) void wcol_part4_kernel(ThinArgs g, int rows, float* __restrict__ part) {
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    __shared__ float sh[NT][4][256];
+    const int i = blockIdx.x * 256 + 4 * lane;
+    float acc[NT][4];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[n][e] = 0.f;
+    if (i < g.M) {
+        const long long step = (long long)gridDim.y * 4;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto one = [&](long long rr) {
+            const long long offa = rr * g.lda + i;
+            const float4 a = *reinterpret_cast<const float4*>(g.A + offa);
+            const float4 m = g.in_mode == PTTS_IN_MASKMUL ? *reinterpret_cast<const float4*>(g.mask_src + offa) : z4;
+            const float4 t = thin_xform4(a, m, g, i);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const float b = n < g.N ? g.B[rr * g.ldb + n] : 0.f;
+                acc[n][0] = fmaf(t.x, b, acc[n][0]); acc[n][1] = fmaf(t.y, b, acc[n][1]);
+                acc[n][2] = fmaf(t.z, b, acc[n][2]); acc[n][3] = fmaf(t.w, b, acc[n][3]);
+            }
+        };
+        long long r = (long long)blockIdx.y * 4 + rg;
+        for (; r + 3 * step < rows; r += 4 * step) { one(r); one(r + step); one(r + 2 * step); one(r + 3 * step); }
+        for (; r < rows; r += step) one(r);
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sh[n][rg][4 * lane + e] = acc[n][e];
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < g.M) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+            part[((size_t)blockIdx.y * g.M + c) * NT + n] = (sh[n][0][threadIdx.x] + sh[n][1][threadIdx.x]) + (sh[n][2][threadIdx.x] + sh[n][3][threadIdx.x]);
+    }
+}
+// C[i, n] (+)= sum over the row blocks of part[block][i][n]: a workgroup per 16 outputs, 256 lanes = 16 outputs x 16 row phases, four
+// loads in flight per lane (64 outputs x 4 phases left every lane a chain of 128 dependent L2 loads: 17 us for 512 KB)
+template <int NT>
+__global__ __launch_bounds__(256) void wcol_reduce_kernel(const float* __restrict__ part, int nblocks, int Mo, int N, float* __restrict__ C,
+                                                          long long ldc, int accumulate) {
+    __shared__ float sh[16][16];
+    const int oo = threadIdx.x & 15, ph = threadIdx.x >> 4;
+    const int o = blockIdx.x * 16 + oo;
+    const int total = Mo * NT;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (o < total) {
+        int b = ph;
+        for (; b + 48 < nblocks; b += 64) {
+            const float v0 = part[(size_t)b * total + o], v1 = part[(size_t)(b + 16) * total + o];
+            const float v2 = part[(size_t)(b + 32) * total + o], v3 = part[(size_t)(b + 48) * total + o];
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+        }
+        for (; b < nblocks; b += 16) s0 += part[(size_t)b * total + o];
+    }
+    sh[ph][oo] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ph == 0 && o < total) {
+        const int i = o / NT, n = o - i * NT;
+        if (n < N) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v += sh[k][oo];
+            float* c = C + (long long)i * ldc + n;
+            *c = accumulate ? *c + v : v;
+        }
+    }
+}
+// the partial rows' buffer, one per stream (4 MB, allocated at the first call on that stream -- outside a capture: the steps' warm-up
+// runs come first; inside one the allocation is refused and the caller falls back to the atomics kernel)
+constexpr size_t WCOL_WS_BYTES = 4u << 20;
+static float* wcol_workspace(hipStream_t st) {
+    static std::mutex mu;
+    static std::vector<std::pair<hipStream_t, float*>> bufs;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& e : bufs)
+        if (e.first == st) return e.second;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+    float* p = nullptr;
+    if (hipMalloc(&p, WCOL_WS_BYTES) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    bufs.emplace_back(st, p);
+    return p;
+}
+
 static inline bool thin_al16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // returns 1 if the product was handled here, 0 if the caller should use the MFMA kernels, <0 on error
@@ -242,7 +383,33 @@ int thin_gemm_dispatch(const float* A, const float* Bm, const float* bias, float
         int rc = check_launch("thin_k");
         return rc ? rc : 1;
     }
-    if (transA == 1 && transB == 0 && N <= 2 && K >= 1024 && !bias && !out_mask && rows_per_seg >= K && !deterministic()) {
+    if (transA == 1 && transB == 0 && N <= 2 && K >= 1024 && !bias && !out_mask && rows_per_seg >= K) {
+        // two stages, no atomics: enough row blocks to hide the loads, as long as the partial rows fit the stream's buffer
+        const bool vec4 = M % 4 == 0 && lda % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (!mask_src || (reinterpret_cast<uintptr_t>(mask_src) & 15) == 0);
+        const int cbp = vec4 ? (M + 255) / 256 : (M + 63) / 64;
+        int rbp = (vec4 ? 512 : 2048) / cbp;
+        if (rbp > 512) rbp = 512;
+        if (rbp > (K + 15) / 16) rbp = (K + 15) / 16;              // (at least four rows per lane)
+        if (rbp < 1) rbp = 1;
+        float* part = ((size_t)rbp * M * N * sizeof(float) <= WCOL_WS_BYTES) ? wcol_workspace(st) : nullptr;
+        if (part) {
+            if (vec4 && N == 1) {
+                hipLaunchKernelGGL(wcol_part4_kernel<1>, dim3(cbp, rbp), dim3(256), 0, st, g, K, part);
+                hipLaunchKernelGGL(wcol_reduce_kernel<1>, dim3((M + 15) / 16), dim3(256), 0, st, part, rbp, M, N, C, ldc, accumulate);
+            } else if (vec4) {
+                hipLaunchKernelGGL(wcol_part4_kernel<2>, dim3(cbp, rbp), dim3(256), 0, st, g, K, part);
+                hipLaunchKernelGGL(wcol_reduce_kernel<2>, dim3((2 * M + 15) / 16), dim3(256), 0, st, part, rbp, M, N, C, ldc, accumulate);
+            } else if (N == 1) {
+                hipLaunchKernelGGL(wcol_part_kernel<1>, dim3(cbp, rbp), dim3(256), 0, st, g, K, part);
+                hipLaunchKernelGGL(wcol_reduce_kernel<1>, dim3((M + 15) / 16), dim3(256), 0, st, part, rbp, M, N, C, ldc, accumulate);
+            } else {
+                hipLaunchKernelGGL(wcol_part_kernel<2>, dim3(cbp, rbp), dim3(256), 0, st, g, K, part);
+                hipLaunchKernelGGL(wcol_reduce_kernel<2>, dim3((2 * M + 15) / 16), dim3(256), 0, st, part, rbp, M, N, C, ldc, accumulate);
+            }
+            int rcp = check_launch("wcol (two stages)");
+            return rcp ? rcp : 1;
+        }
+        if (deterministic()) return 0;
         if (!accumulate) {
             if (zero_f32_2d(C, (size_t)ldc, (size_t)N, (size_t)M, st) != PTTS_OK) return PTTS_ELAUNCH;
         }
