@@ -214,6 +214,49 @@ __global__ __launch_bounds__(256) void split3_dense_weight_strided_kernel(SplitS
         *reinterpret_cast<uint4*>(planes + p * ps + (size_t)idx * 8) = make_uint4(q[p][0], q[p][1], q[p][2], q[p][3]);
 }
 
+// The same planes for row-major matrices B[K][N] (not transposed, no windows) through the LDS: a workgroup takes the 32 k-rows of one
+// k-step of one matrix, reads them as whole rows with 16-byte loads (a wave per row: 1 KB runs), and builds the fragments -- a lane's
+// 8 consecutive k of ONE column -- out of the LDS.  The direct kernel above reads every value with a 4-byte load of its own (8 per lane,
+// 256 B per wave and instruction): 38 us for the 32 MB of per-frequency products that the frequency-domain Conv1D hands to its inverse
+// transform as the "weight" operand, 3 % of the loop's kernel time.  N % 4 == 0, ldw % 4 == 0, 16-byte aligned source.
+constexpr int SPL_ROW = 256 + 2;         // floats per LDS row: rows 8 apart land 16 banks apart
+__global__ __launch_bounds__(256) void split3_dense_weight_strided_lds_kernel(SplitStridedArgs a) {
+    __shared__ float tile[32 * SPL_ROW];
+    const int z = blockIdx.y, ks = blockIdx.x % a.KS, cb = blockIdx.x / a.KS;          // matrix, k-step, block of 256 columns
+    const float* __restrict__ w = a.w + (long long)z * a.stride_w;
+    u16* __restrict__ planes = a.planes + (long long)z * a.stride_p;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = cb * 256;
+    // rows k = 32 ks + r: wave w loads rows w, w + 4, ...; lane: four columns
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = wave + 4 * j, k = ks * 32 + r, n = n0 + 4 * lane;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < a.K && n < a.N) v = *reinterpret_cast<const f32x4*>(w + (long long)k * a.ldw + n);
+        float* d = tile + r * SPL_ROW + 4 * lane;
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+    __syncthreads();
+    const size_t ps = (size_t)a.NT * a.KS * 512;
+    const int li = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ntl = wave + 4 * j;                                  // column tile inside the block: 0 .. 15
+        const int nt = cb * 16 + ntl;
+        if (nt >= a.NT) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = tile[(8 * lg + e) * SPL_ROW + 16 * ntl + li];
+        unsigned q[3][4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) split3_pair(v[2 * h], v[2 * h + 1], q[0][h], q[1][h], q[2][h]);
+        const size_t idx = ((size_t)nt * a.KS + ks) * 64 + lane;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            *reinterpret_cast<uint4*>(planes + p * ps + idx * 8) = make_uint4(q[p][0], q[p][1], q[p][2], q[p][3]);
+    }
+}
+
 #ifndef DNS_DEPTH
 #define DNS_DEPTH 2        // register stages of the A operand in dense_bf16x6_kernel (1 = the single stage of rounds 2-3; measured 1 / 2 / 3 / 4 / 6:
                            // 25.6 / 25.0 / 25.6 / 26.5 / 29.8 us at 25 600 rows, 82.4 / 75.3 / 80.3 / 83.0 / 86.0 at 76 800: the loads are not what bounds it)
@@ -816,6 +859,13 @@ extern "C" int ptts_split3_dense_weight_strided(const float* w, long long stride
     a.NT = (N + NBLK - 1) / NBLK * (NBLK / 16); a.KS = (K + BK - 1) / BK;
     a.windows = 0; a.T = a.NS = a.S = a.row_off = a.kvalid = 0;
     const long long total = (long long)a.NT * a.KS * 64;
+    static int lds_form = -1;
+    if (lds_form < 0) { const char* e = getenv("PTTS_SPLIT_LDS"); lds_form = e ? atoi(e) : 1; }
+    if (lds_form && !transposed && N % 4 == 0 && ldw % 4 == 0 && stride_w % 4 == 0 && ((uintptr_t)w & 15) == 0) {
+        const unsigned cbn = (unsigned)((N + 255) / 256);
+        hipLaunchKernelGGL(split3_dense_weight_strided_lds_kernel, dim3((unsigned)a.KS * cbn, (unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
+        return check_launch("split3_dense_weight_strided");
+    }
     hipLaunchKernelGGL(split3_dense_weight_strided_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("split3_dense_weight_strided");
 }

@@ -1410,7 +1410,7 @@ def test_conv1d_frequency_domain_forward(ops, case, seg):
 
 
 @pytest.mark.parametrize('case', [(3, 400, 601, 4, 100, -10, 120, 120), (3, 400, 256, 4, 100, 0, 120, 100), (2, 460, 70, 5, 92, -4, 100, 100),
-                                  (5, 37, 13, 1, 37, -1, 40, 40)])
+                                  (5, 37, 13, 1, 37, -1, 40, 40), (2, 300, 260, 3, 100, -5, 110, 104), (2, 200, 512, 2, 100, 0, 100, 100)])
 def test_frame_window_and_strided_planes_bit_for_bit(ops, case):
     """csrc/dense.hip, split3_dense_weight_strided_kernel (ptts_split3_frame_windows / ptts_split3_dense_weight_strided): the planes of
     the overlap-save windows of a frame sequence -- window z = (b, s) = rows x[b][row_off + s S + k], zero outside the utterance and
