@@ -573,12 +573,17 @@ def main():
         # (data.BatchPrefetcher: loader thread + copy stream), as the training driver feeds train_on_batch.  Never `value`.
         from percivaltts_amd import data
         pool = [(bx.cpu().numpy(), by.cpu().numpy()) for bx, by in batches]
-        nh = max(6, min(args.steps, 30))
-        pf = data.BatchPrefetcher(lambda i: pool[i % nbuf], nh, device=dev, depth=2)
+        # (the first `fill` steps -- the loader thread's start, the pipeline's fill, the first look-ahead -- are not timed: a whole number of cycles)
+        fill = 10
+        nh = max(10, min(args.steps, 120)) // 5 * 5
+        pf = data.BatchPrefetcher(lambda i: pool[i % nbuf], fill + nh, device=dev, depth=2)
         parallel.barrier(); torch.cuda.synchronize()
         th = time.time()
         from percivaltts_amd.optimizertts import _with_next
         for i, (hx, hy), nx in _with_next(pf):
+            if i == fill:
+                torch.cuda.synchronize(); parallel.barrier()
+                th = time.time()
             opt.device_step(i, hx, hy, nxt=nx)
         torch.cuda.synchronize(); parallel.barrier()
         dth = parallel.max_over_ranks(time.time() - th, dev)
