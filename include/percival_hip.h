@@ -190,6 +190,14 @@ int ptts_conv2d_mfma_bwd_fused_supported(int F, int dil_t, int planes);
 int ptts_conv2d_mfma_bwd_fused(const void* p, const void* q, const void* mask_src, const void* table, void* y,
                                void* workspace, size_t workspace_bytes, int* nblocks_out, int* npart_out,
                                int B, int T, int F, int KT, int pad_t, int kind, float alpha, void* stream);
+/* Kind 1 for a layer whose input was lrelu(scale x + shift) -- the kl.BatchNormalization + kl.LeakyReLU in front of the generator's
+ * kl.Conv2D layers (networktts.py:122-126): q = the raw map x, y = dx = conv^T(dy) lrelu'(scale x + shift) scale (TF: Conv2DBackpropInput +
+ * LeakyReluGrad + the input half of FusedBatchNormGrad's elementwise stage), and every partial row carries, behind the 400 + 4 sums of
+ * dw / dbias, the 4 + 4 sums that are the gradients of scale and shift (columns 404 .. 411: a second ptts_conv2d_reduce_desc with
+ * partials + 404 floats, nw = 4, cout = 4 reduces them). */
+int ptts_conv2d_mfma_bwd_fused_affine(const float* p, const float* q, const void* table, float* y, void* workspace, size_t workspace_bytes,
+                                      int* nblocks_out, int* npart_out, int B, int T, int F, int KT, int pad_t, float alpha,
+                                      const float* q_scale, const float* q_shift, void* stream);
 int ptts_conv2d_mfma_debug(int flags, void* stamp_buf);
 
 /* ---------------------------------------------------------------------------------------

@@ -78,6 +78,7 @@ SIGNATURES = {
     'ptts_conv2d_mfma_wgrad_partials': (c_i, [c_p] * 4 + [c_sz, c_p, c_p] + [c_i] * 7 + [c_f] + [c_i] * 3 + [c_p]),
     'ptts_conv2d_mfma_bwd_fused_workspace_bytes': (c_sz, [c_i, c_i]),
     'ptts_conv2d_mfma_bwd_fused_supported': (c_i, [c_i, c_i, c_i]),
+    'ptts_conv2d_mfma_bwd_fused_affine': (c_i, [c_p] * 5 + [c_sz, c_p, c_p] + [c_i] * 5 + [c_f, c_p, c_p, c_p]),
     'ptts_conv2d_mfma_bwd_fused': (c_i, [c_p] * 6 + [c_sz, c_p, c_p] + [c_i] * 6 + [c_f, c_p]),
     'ptts_conv2d_chain_supported': (c_i, [c_i] * 6),
     'ptts_conv2d_chain_debug': (c_i, [c_p]),

@@ -497,7 +497,7 @@ __device__ __forceinline__ void pref_commit(Pref<ST::NB, MODE == PTTS_IN_MASKMUL
 template <class ST, int DIL, int N, bool OUTMASK, int NPL, bool WREG, bool STATS = false>
 __device__ __forceinline__ void fwd_pass(const u16* __restrict__ planes, const u16* __restrict__ wl, const bf16x8 (&wf)[KT][NPL], int g0, int lane,
                                          f32x4 bv, const void* __restrict__ mrow, void* __restrict__ yrow, bool out_bf16,
-                                         int fbase, int F, bool rowok, float alpha, bool store, f32x4* stat = nullptr) {
+                                         int fbase, int F, bool rowok, float alpha, bool store, f32x4* stat = nullptr, const f32x4* aff = nullptr) {
     const int li = lane & 15, lg = lane >> 4;
     f32x4 acc[N], mv[OUTMASK ? N : 1];
 #pragma unroll
@@ -563,11 +563,20 @@ __device__ __forceinline__ void fwd_pass(const u16* __restrict__ planes, const u
         for (int j = 0; j < N; ++j) {
             if (f0 + 4 * j < F) {
                 f32x4 o = acc[j];
-                if (OUTMASK) {
+                if (OUTMASK && STATS) {
+                    // backward data of a layer whose input was lrelu(sc x + sh) (a BatchNormalization in front: the generator's stack): the
+                    // mask is that input's, the gradient w.r.t. x carries the factor sc, and the two sums are the gradients of sc and sh
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float gd = o[e] * ((mv[j][e] * aff[0][e] + aff[1][e]) > 0.f ? 1.f : alpha);
+                        stat[0][e] += gd * mv[j][e]; stat[1][e] += gd;
+                        o[e] = gd * aff[0][e];
+                    }
+                } else if (OUTMASK) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = o[e] * (mv[j][e] > 0.f ? 1.f : alpha);
                 }
-                if (STATS) { stat[0] += o; stat[1] += o * o; }       // per-channel sum and sum of squares of what is stored (BatchNorm's statistics)
+                if (STATS && !OUTMASK) { stat[0] += o; stat[1] += o * o; }       // per-channel sum and sum of squares of what is stored (BatchNorm's statistics)
                 store_px(yrow, (f0 + 4 * j) * C, o, out_bf16);
             }
         }
@@ -580,7 +589,7 @@ __device__ __forceinline__ void fwd_pass(const u16* __restrict__ planes, const u
 template <class ST, int DIL, bool OUTMASK, bool MASK, int NPL, bool WREG, int NW = 4, int NMAXO = 0, bool STATS = false>
 __device__ __forceinline__ void fwd_piece(const u16* __restrict__ planes, const u16* __restrict__ wl, const bf16x8 (&wf)[KT][NPL], const TilePos& cur, const Shape& s,
                                           int wave, int lane, int it, f32x4 bv, const void* __restrict__ out_mask, void* __restrict__ y,
-                                          bool out_bf16, float alpha, bool store, bool nomfma, f32x4* stat = nullptr) {
+                                          bool out_bf16, float alpha, bool store, bool nomfma, f32x4* stat = nullptr, const f32x4* aff = nullptr) {
     static_assert(NW == 4 || NW == 8, "waves that share a piece");
     const int per = cur.ng / NW, rem = cur.ng & (NW - 1), wr = (wave + it) & (NW - 1);
     int gl = wr * per + min(wr, rem);
@@ -596,7 +605,7 @@ __device__ __forceinline__ void fwd_piece(const u16* __restrict__ planes, const 
     const int fbase = 4 * cur.g_base;
     while (n > 0) {
         const int m = npass == 1 ? n : (npass == 2 ? (n + 1) >> 1 : (n + npass - 1) / npass);      // (the division is ~35 scalar instructions)
-#define C2M_PASS(NN) fwd_pass<ST, DIL, NN, OUTMASK, NPL, WREG, STATS>(planes, wl, wf, gl, lane, bv, mrow, yrow, out_bf16, fbase, s.F, rowok, alpha, store, stat)
+#define C2M_PASS(NN) fwd_pass<ST, DIL, NN, OUTMASK, NPL, WREG, STATS>(planes, wl, wf, gl, lane, bv, mrow, yrow, out_bf16, fbase, s.F, rowok, alpha, store, stat, aff)
         switch (m) {
             case 1: C2M_PASS(1); break;
             case 2: if (NMAX >= 2) C2M_PASS(NMAX >= 2 ? 2 : 1); break;
@@ -1097,10 +1106,15 @@ __device__ unsigned long long g_bw_stamps[256 * 16];
 #else
 #define C2M_BTS(SLOT) do { } while (0)
 #endif
-template <int KIND, int NPL, bool SPLIT>
+// AFF (KIND 1, round 4): the layer's input was lrelu(q_scale x + q_shift) -- a BatchNormalization in front of it, the generator's stack
+// (networktts.py:122-126).  Q is staged with that affine, dx = conv^T(dy) lrelu'(q_scale x + q_shift) q_scale, and the workgroup's row
+// carries, behind dW and dbias, the sums of conv^T(dy) lrelu'(.) x and conv^T(dy) lrelu'(.) over its pixels: the gradients of scale and shift.
+template <int KIND, int NPL, bool SPLIT, bool AFF = false>
 __global__ __launch_bounds__((SPLIT ? 12 : 8) * 64, 1) void bwd_ws_kernel(
     const void* __restrict__ psrc, const void* __restrict__ qsrc, const void* __restrict__ mask_src, const u16* __restrict__ tab,
-    void* __restrict__ y, float* __restrict__ partials, Shape s, Sched sc, float alpha, int dbg, unsigned* status) {
+    void* __restrict__ y, float* __restrict__ partials, Shape s, Sched sc, float alpha, int dbg, unsigned* status,
+    const float* __restrict__ q_scale = nullptr, const float* __restrict__ q_shift = nullptr) {
+    static_assert(!AFF || (KIND == 1 && !SPLIT), "the affine form is the first-order backward's");
     constexpr int DIL = 1, NMW = 4, NCW = SPLIT ? 8 : 4, NT = (NCW + 4) * 64;      // waves that share a piece's groups / pairs; consumer waves; threads
     typedef Stage<4 * (GPB + 1) + 4, 16 + (KT - 1) * DIL> SP;                              // the convolved tile, with its time halo
     typedef Stage<4 * (GPB + 1) + 4, KIND == 1 ? 16 : 16 + (KT - 1) * DIL> SQ;             // the other operand of the weight gradient
@@ -1170,14 +1184,14 @@ __global__ __launch_bounds__((SPLIT ? 12 : 8) * 64, 1) void bwd_ws_kernel(
         auto commit_piece = [&](const TilePos& p, u16* buf) {
             // the bias gradient rides on the staging of dy (KIND 1 only: the second-order sweep has none): its own 16 rows and bins
             pref_commit<SP, MODE_P, NPL>(pp, slp, buf, p.t0 - lo, 4 * p.g_base - 2, s.T, s.F, nullptr, nullptr, alpha, lo, 2 + 4 * p.ng, KIND == 1 ? &bsum : nullptr);
-            pref_commit<SQ, MODE_Q, NPL>(pq, slq, buf + NPL * SP::PS, KIND == 1 ? p.t0 : p.t0 - lo, 4 * p.g_base - 2, s.T, s.F, nullptr, nullptr, alpha, 0, 0, nullptr);
+            pref_commit<SQ, MODE_Q, NPL>(pq, slq, buf + NPL * SP::PS, KIND == 1 ? p.t0 : p.t0 - lo, 4 * p.g_base - 2, s.T, s.F, AFF ? q_scale : nullptr, AFF ? q_shift : nullptr, alpha, 0, 0, nullptr);
         };
         // the same with the loads of the NEXT piece (a whole-row tile) going out slot by slot behind the commits (RowsReload)
         auto commit_reload = [&](const TilePos& p, u16* buf, const TilePos& pn) {
             const RowsReload<SP, PMASK> rp(slp, psrc, mask_src, pn.img, pn.t0 - lo, s.T, s.F);
             const RowsReload<SQ, false> rq(slq, qsrc, nullptr, pn.img, KIND == 1 ? pn.t0 : pn.t0 - lo, s.T, s.F);
             pref_commit<SP, MODE_P, NPL>(pp, slp, buf, p.t0 - lo, 4 * p.g_base - 2, s.T, s.F, nullptr, nullptr, alpha, lo, 2 + 4 * p.ng, KIND == 1 ? &bsum : nullptr, rp);
-            pref_commit<SQ, MODE_Q, NPL>(pq, slq, buf + NPL * SP::PS, KIND == 1 ? p.t0 : p.t0 - lo, 4 * p.g_base - 2, s.T, s.F, nullptr, nullptr, alpha, 0, 0, nullptr, rq);
+            pref_commit<SQ, MODE_Q, NPL>(pq, slq, buf + NPL * SP::PS, KIND == 1 ? p.t0 : p.t0 - lo, 4 * p.g_base - 2, s.T, s.F, AFF ? q_scale : nullptr, AFF ? q_shift : nullptr, alpha, 0, 0, nullptr, rq);
         };
         const bool stage = !(dbg & DBG_NOSTAGE);              // (measurement hooks of tools/c2m_fused_probe2.py: garbage results)
         int it = 0;
@@ -1210,6 +1224,7 @@ __global__ __launch_bounds__((SPLIT ? 12 : 8) * 64, 1) void bwd_ws_kernel(
     } else {
         const int li = lane & 15, lg = lane >> 4;
         const bool do_conv = !SPLIT || wave8 < NMW, do_wg = !SPLIT || wave8 >= NMW;
+        f32x4 astat[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};       // (AFF) this lane's sums for the gradients of scale / shift
         // ---- the convolution over P: dx (KIND 1, masked by the layer input) / cot_dy (KIND 2)
         auto conv_role = [&](auto&& also) {
             bf16x8 wf[KT][NPL];
@@ -1231,6 +1246,8 @@ __global__ __launch_bounds__((SPLIT ? 12 : 8) * 64, 1) void bwd_ws_kernel(
                 }
             }
             const f32x4 bv0 = {0.f, 0.f, 0.f, 0.f};
+            f32x4 aff[2] = {f32x4{1.f, 1.f, 1.f, 1.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            if (AFF) { aff[0] = *reinterpret_cast<const f32x4*>(q_scale); aff[1] = *reinterpret_cast<const f32x4*>(q_shift); }
             int it = 0;
             PieceWalk walk;
             walk.init(s, sc, wg, nitems);
@@ -1241,7 +1258,7 @@ __global__ __launch_bounds__((SPLIT ? 12 : 8) * 64, 1) void bwd_ws_kernel(
                 C2M_BTS(0);
                 wait_for(it & 1, 4 * ((it >> 1) + 1));
                 C2M_BTS(1);
-                fwd_piece<SP, DIL, OUTMASK, PMASK, NPL, C2M_BW_WREG != 0, NMW, C2M_BW_NMAX>(pcur, wl, wf, cur, s, wave, lane, it, bv0, qsrc, y, false, alpha, !(dbg & DBG_NOSTORE), (dbg & (DBG_NOMFMA | 16)) != 0);
+                fwd_piece<SP, DIL, OUTMASK, PMASK, NPL, C2M_BW_WREG != 0, NMW, C2M_BW_NMAX, AFF>(pcur, wl, wf, cur, s, wave, lane, it, bv0, qsrc, y, false, alpha, !(dbg & DBG_NOSTORE), (dbg & (DBG_NOMFMA | 16)) != 0, AFF ? astat : nullptr, AFF ? aff : nullptr);
                 C2M_BTS(2);
                 also(cur, pcur, it);
                 C2M_BTS(3);
@@ -1334,9 +1351,24 @@ __global__ __launch_bounds__((SPLIT ? 12 : 8) * 64, 1) void bwd_ws_kernel(
 #pragma unroll
                     for (int r = 0; r < 4; ++r) red[(((wave * KT + kt) * 2 + hb) * 4 + r) * 64 + lane] = acc[kt][hb][r];
         }
+        if (AFF) {
+            float* stl = bs + 256 * 4;                     // behind the bias sums: [8][256 multiplying lanes]
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { stl[e * 256 + tid] = astat[0][e]; stl[(4 + e) * 256 + tid] = astat[1][e]; }
+        }
     }
     __syncthreads();
     float* out = partials + (size_t)blockIdx.x * NPART;
+    if (AFF && tid >= 256 && tid < 512) {
+        // the eight affine sums of the workgroup: column c = 32 lanes, a strided partial sum and a butterfly (a fixed order)
+        const float* stl = bs + 256 * 4;
+        const int t2 = tid - 256, c = t2 >> 5, k = t2 & 31;
+        double a = 0.0;
+        for (int i = k; i < 256; i += 32) a += (double)stl[c * 256 + i];
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
+        if (k == 0) out[KT * KF * 16 + 4 + c] = (float)a;
+    }
     for (int i = tid; i < KT * KF * 16; i += NT) {
         const int co = i & 3, ci = (i >> 2) & 3, kf = (i >> 4) % KF, kt = (i >> 4) / KF;
         float sum = 0.f;
@@ -1749,4 +1781,39 @@ extern "C" int ptts_conv2d_mfma_bwd_fused(const void* p, const void* q, const vo
     *nblocks_out = grid;
     *npart_out = NPART;
     return check_launch("conv2d_mfma_bwd_fused");
+}
+
+// Kind 1 for a layer whose input was lrelu(scale x + shift) -- the kl.BatchNormalization + kl.LeakyReLU in front of the generator's
+// kl.Conv2D layers (networktts.py:122-126): q is the raw map x, y = dx = conv^T(dy) lrelu'(scale x + shift) scale, and every partial row
+// carries, behind the 400 kernel-gradient sums and the 4 bias-gradient sums, the 4 + 4 sums that are the gradients of scale and shift
+// (columns 404 .. 411: reduce them with a second descriptor of ptts_conv2d_reduce_grouped -- partials + 404 floats, nw = 4, cout = 4).
+extern "C" int ptts_conv2d_mfma_bwd_fused_affine(const float* p, const float* q, const void* table, float* y, void* workspace, size_t workspace_bytes,
+                                                 int* nblocks_out, int* npart_out, int B, int T, int F, int KT_, int pad_t, float alpha,
+                                                 const float* q_scale, const float* q_shift, void* stream) {
+    if (int rc = check_status("conv2d_mfma_bwd_fused_affine")) return rc;
+    PTTS_REQUIRE(p && q && table && y && workspace && nblocks_out && npart_out && q_scale && q_shift, "conv2d_mfma_bwd_fused_affine: null pointer");
+    PTTS_REQUIRE(B > 0 && T > 0 && F > 0 && KT_ == 5, "conv2d_mfma_bwd_fused_affine: bad dims B=%d T=%d F=%d KT=%d", B, T, F, KT_);
+    PTTS_REQUIRE(pad_t == 2, "conv2d_mfma_bwd_fused_affine: built for 'same' padding at dilation 1 (pad_t 2, got %d)", pad_t);
+    PTTS_REQUIRE(alpha >= 0.f && alpha <= 1.f, "conv2d_mfma_bwd_fused_affine: LeakyReLU slope %g outside [0, 1]", alpha);
+    PTTS_REQUIRE((long long)(T + 64) * F * C < (1LL << 31), "conv2d_mfma_bwd_fused_affine: utterance too large for 32-bit tile offsets");
+    PTTS_REQUIRE((((uintptr_t)q_scale | (uintptr_t)q_shift) & 15) == 0, "conv2d_mfma_bwd_fused_affine: scale / shift must be 16-byte aligned");
+    const Shape s = make_shape(B, T, F, pad_t);
+    PTTS_REQUIRE(shape_ok(s), "conv2d_mfma_bwd_fused_affine: too many tiles");
+    const size_t need = ptts_conv2d_mfma_bwd_fused_workspace_bytes(B, T);
+    if (workspace_bytes < need) { set_error("conv2d_mfma_bwd_fused_affine: workspace %zu < %zu", workspace_bytes, need); return PTTS_EWORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    float* parts = reinterpret_cast<float*>((char*)workspace + 4096);
+    typedef Stage<4 * (GPB + 1) + 4, 16 + (KT - 1)> SP;
+    typedef Stage<4 * (GPB + 1) + 4, 16> SQ;
+    constexpr size_t lds = (size_t)2 * NP * (SP::PS + SQ::PS) * sizeof(u16) + 64 + (size_t)KT * NP * TKP * sizeof(u16);
+    static_assert(lds <= LDS_MAX, "tile does not fit the LDS");
+    static_assert((size_t)(4 * KT * 2 * 4 * 64 + 256 * 4 + 8 * 256) * sizeof(float) <= lds, "reduction scratch");
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_ws_kernel<1, NP, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX); attr = true; }
+    const Sched sc = sched_for(s.ntiles, lds, 1, 2);
+    hipLaunchKernelGGL((bwd_ws_kernel<1, NP, false, true>), dim3(sc.G), dim3(8 * 64), lds, st, p, q, nullptr, (const u16*)table, y, parts, s, sc, alpha,
+                       g_dbg, status_words(), q_scale, q_shift);
+    *nblocks_out = sc.G;
+    *npart_out = NPART;
+    return check_launch("conv2d_mfma_bwd_fused_affine");
 }

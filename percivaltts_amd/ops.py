@@ -456,6 +456,20 @@ def _conv2d_mfma_bwd_fused(kind, p, q, mask_src, w, alpha):
     return y, buf, nblocks.value, npart.value
 
 
+def _conv2d_mfma_bwd_fused_affine(dy, x, w, alpha, scale, shift):
+    """Kind 1 for a layer input lrelu(scale x + shift): (dy, x) -> dx (w.r.t. the raw x), partial rows of dW / dbias / dscale / dshift."""
+    B, T, F, _ = dy.shape
+    f32c(dy, 'conv2d_bwd_fused.dy'); f32c(x, 'conv2d_bwd_fused.x'); f32c(scale); f32c(shift)
+    assert x.shape == dy.shape
+    y = torch.empty_like(dy)
+    nws = _hip.lib().ptts_conv2d_mfma_bwd_fused_workspace_bytes(B, T)
+    buf = torch.empty(int(nws), dtype=torch.uint8, device=dy.device)
+    nblocks, npart = ctypes.c_int(0), ctypes.c_int(0)
+    call('ptts_conv2d_mfma_bwd_fused_affine', ptr(dy), ptr(x), ptr(_C2M.table(w, True)), ptr(y), ptr(buf), buf.numel(),
+         ctypes.byref(nblocks), ctypes.byref(npart), B, T, F, 5, 2, alpha, ptr(scale), ptr(shift), stream(), tag=(B, T, F, 'affine'))
+    return y, buf, nblocks.value, npart.value
+
+
 def _st(t, name='tensor'):
     """Validate a conv2d map of the bf16-storage path: contiguous device tensor, fp32 or bf16."""
     if t is None:
@@ -527,6 +541,33 @@ def _conv2d_bwd_raw(dy, x, w, scale, shift, mask_src, mode, alpha, dil_t, pad_mo
             desc[0].dbias = db.data_ptr() if db is not None else None
             call('ptts_conv2d_reduce_grouped', ctypes.cast(desc, ctypes.c_void_p), 1, stream(), tag=(1,))
         return dx, dw, db, None, None
+    if planes == 3 and scale is not None and mode == IN_LRELU and want_dx and mask_src is None and _C2M.enabled and _BNStats.enabled and \
+            _C2M.eligible(x, w, dil_t) and 0.0 <= alpha <= 1.0 and _C2MFused.ok(x, dil_t, pad_mode, planes) and \
+            scale.data_ptr() % 16 == 0 and shift.data_ptr() % 16 == 0:
+        # a BatchNormalization in front of the layer (the generator's stack): the fused matrix-core launch with that input's affine in its
+        # Q staging, its mask and scale in the store of dx, and the affine's two gradient sums behind dW / dbias in the partial rows
+        dx, buf, nblocks, npart = _conv2d_mfma_bwd_fused_affine(dy, x, w, alpha, scale, shift)
+        nw = KT * KF * Cin * Cout
+        dw = torch.zeros_like(w) if want_dw else None
+        db = torch.zeros(Cout, dtype=torch.float32, device=dev) if want_db else None
+        daff = torch.zeros(2 * Cin, dtype=torch.float32, device=dev) if want_affine else None
+        nd = int(want_dw or want_db) + int(want_affine)
+        if nd:
+            desc = (_hip.Conv2dReduceDesc * nd)()
+            i = 0
+            if want_dw or want_db:
+                desc[i].partials = buf.data_ptr() + 4096
+                desc[i].nblocks, desc[i].npart, desc[i].nw, desc[i].cout = nblocks, npart, nw, Cout
+                desc[i].dw = dw.data_ptr() if dw is not None else None
+                desc[i].dbias = db.data_ptr() if db is not None else None
+                i += 1
+            if want_affine:
+                desc[i].partials = buf.data_ptr() + 4096 + 4 * (nw + Cout)        # (the eight sums behind dW and dbias in every row)
+                desc[i].nblocks, desc[i].npart, desc[i].nw, desc[i].cout = nblocks, npart, Cin, Cin
+                desc[i].dw = daff.data_ptr()
+                desc[i].dbias = daff.data_ptr() + 4 * Cin
+            call('ptts_conv2d_reduce_grouped', ctypes.cast(desc, ctypes.c_void_p), nd, stream(), tag=(nd,))
+        return dx, dw, db, (daff[:Cin] if want_affine else None), (daff[Cin:] if want_affine else None)
     dx = torch.empty_like(x) if want_dx else None
     dw = torch.empty_like(w) if (want_dw or want_db) else None
     db = torch.empty(Cout, dtype=torch.float32, device=dev) if want_db else None

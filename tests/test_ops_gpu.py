@@ -1670,3 +1670,45 @@ def test_dense_backward_data_through_a_batchnorm_affine_in_its_store(ops, case):
         close(dz, gd * sc.double().cpu(), 2e-4, 2e-4 * float(gd.abs().mean()), 'dz ' + what)
         close(dsc, (gd * zd).sum(0), 1e-4, 1e-4 * float((gd * zd).abs().sum(0).mean()), 'dscale ' + what)
         close(dsh, gd.sum(0), 1e-4, 1e-4 * float(gd.abs().sum(0).mean()), 'dshift ' + what)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [(3, 100, 65), (2, 37, 130), (300, 17, 3), (17, 270, 65), (64, 400, 65)])
+def test_conv2d_backward_through_a_batchnorm_affine_input_on_the_matrix_cores(ops, case):
+    """ptts_conv2d_mfma_bwd_fused_affine (the backward of a generator Conv2D whose input was BatchNormalization + LeakyReLU, reference
+    networktts.py:122-126) against the packed-FMA kernel it replaces (which the suite pins against the fp64 oracle) and against fp64 on a
+    crop: dx w.r.t. the raw map, dW, and the gradients of the affine's scale and shift."""
+    B, T, F = case
+    g = gen(94)
+    x = torch.randn(B, T, F, 4, generator=g).cuda()
+    dy = torch.randn(B, T, F, 4, generator=g).cuda()
+    w = (torch.randn(5, 5, 4, 4, generator=g) * 0.3).cuda()
+    sc = (torch.rand(4, generator=g) + 0.5).cuda(); sh = (torch.randn(4, generator=g) * 0.3).cuda()
+    res = []
+    for on in (True, False):
+        ops.conv_bn_stats(on)
+        try:
+            with ops._hip.KernelTimer() as kt:
+                out = ops._conv2d_bwd_raw(dy, x, w, sc, sh, None, ops.IN_LRELU, 0.3, 1, ops.PAD_SAME, True, True, False, True)
+            torch.cuda.synchronize()
+        finally:
+            ops.conv_bn_stats(None)
+        res.append((out, [r[0] for r in kt.records]))
+    (dx1, dw1, _, ds1, dh1), names1 = res[0]
+    (dx0, dw0, _, ds0, dh0), names0 = res[1]
+    assert 'ptts_conv2d_mfma_bwd_fused_affine' in names1 and 'ptts_conv2d_bwd' not in names1
+    assert 'ptts_conv2d_bwd' in names0
+    n = float(B * T * F)
+    close(dx1, dx0.cpu(), 2e-4, 2e-4 * float(dx0.abs().mean()), 'dx')
+    close(dw1, dw0.cpu(), 2e-4, 2e-5 * n ** 0.5, 'dW')
+    close(ds1, ds0.cpu(), 2e-4, 2e-5 * n ** 0.5, 'dscale')
+    close(dh1, dh0.cpu(), 2e-4, 2e-5 * n ** 0.5, 'dshift')
+    # fp64 on the first utterance (autograd through the oracle's layer)
+    xb = x[:1].double().cpu().requires_grad_(True)
+    scd = sc.double().cpu().requires_grad_(True); shd = sh.double().cpu().requires_grad_(True)
+    wd = w.double().cpu()
+    y = O.conv2d_nhwc(O.lrelu(xb * scd + shd), wd, None)
+    y.backward(dy[:1].double().cpu())
+    close(dx1[:1], xb.grad, 2e-4, 2e-4 * float(xb.grad.abs().mean()), 'dx against fp64')
+    if B == 1:
+        close(ds1, scd.grad, 2e-4, 2e-5 * n ** 0.5, 'dscale against fp64')
