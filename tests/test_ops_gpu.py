@@ -103,8 +103,11 @@ def test_conv2d_forward_backward(ops, case, mode):
     close(wd.grad, wr.grad, rtol=2e-4, atol=1e-4, what='dw')
     close(bd.grad, br.grad, rtol=2e-4, atol=1e-4, what='db')
     if mode == 'affine':
-        close(scd.grad, scr.grad, rtol=2e-4, atol=1e-4, what='dscale')
-        close(shd.grad, shr.grad, rtol=2e-4, atol=1e-4, what='dshift')
+        # sums over B T F pixels of terms of either sign (a channel's sum may all but cancel: -0.59 beside 665 at case 6): the absolute
+        # tolerance grows with the number of terms -- 5e-8 per pixel is a third of what fp32 products of O(1) terms allow
+        at = max(1e-4, 5e-8 * B * T * F)
+        close(scd.grad, scr.grad, rtol=2e-4, atol=at, what='dscale')
+        close(shd.grad, shr.grad, rtol=2e-4, atol=at, what='dshift')
 
 
 def test_conv2d_mfma_tables_are_the_split_of_the_toeplitz_blocks(ops):
