@@ -1715,3 +1715,55 @@ def test_conv2d_backward_through_a_batchnorm_affine_input_on_the_matrix_cores(op
     close(dx1[:1], xb.grad, 2e-4, 2e-4 * float(xb.grad.abs().mean()), 'dx against fp64')
     if B == 1:
         close(ds1, scd.grad, 2e-4, 2e-5 * n ** 0.5, 'dscale against fp64')
+
+
+@pytest.mark.gpu
+def test_statistics_entry_points_refuse_what_they_cannot_do(ops):
+    """Error behaviour of the round-4 entry points that leave per-workgroup sums: too few rows of room, an input transform the fused
+    kernels have no form for, unaligned affine vectors -- a HipLibraryError with the reason, nothing launched, nothing written."""
+    import ctypes
+    from percivaltts_amd import layers
+    lib = ops._hip.lib()
+    g = gen(95)
+    x = torch.randn(2, 40, 65, 4, generator=g).cuda()
+    w = (torch.randn(5, 5, 4, 4, generator=g) * 0.3).cuda()
+    tf = ops._C2M.table(w, False)
+    y = torch.full_like(x, 7.0)
+    part = torch.zeros(4, 8, dtype=torch.float64, device='cuda')
+    n = ctypes.c_int(-1)
+    with pytest.raises(ops._hip.HipLibraryError, match='room for'):
+        ops.call('ptts_conv2d_mfma_fwd_stats', ops.ptr(x), ops.ptr(tf), None, None, None, ops.ptr(y), 2, 40, 65, 5, 2, ops.IN_LRELU, 0.3,
+                 ops.ptr(part), 1, ctypes.byref(n), ops.stream())
+    assert lib.ptts_conv2d_mfma_fwd_stats_supported(65, 2, ops.IN_LRELU) == 0 and lib.ptts_conv2d_mfma_fwd_stats_supported(65, 1, ops.IN_MASKMUL) == 0
+    with pytest.raises(ops._hip.HipLibraryError, match='unsupported'):
+        ops.call('ptts_conv2d_mfma_fwd_stats', ops.ptr(x), ops.ptr(tf), None, None, None, ops.ptr(y), 2, 40, 65, 5, 2, ops.IN_MASKMUL, 0.3,
+                 ops.ptr(part), 256, ctypes.byref(n), ops.stream())
+    torch.cuda.synchronize()
+    assert n.value == -1 and float(y.min()) == 7.0 and float(part.abs().max()) == 0.0
+    # the Dense forms
+    M, K, N = 2048, 256, 256
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.randn(K, N, generator=g) * 0.1)
+    h = Holder(); flat = layers.FlatParams(h, 'cuda')
+    planes = ops._DenseSplit.get(h.w, K, N, N, 0)
+    a = torch.randn(M, K, generator=g).cuda(); c = torch.empty(M, N, device='cuda')
+    need = lib.ptts_dense_bf16x6_stats_rows(M, N)
+    assert need >= M // 128 and lib.ptts_dense_bf16x6_stats_rows(0, N) == 0
+    rows = torch.zeros(need, 2 * N, dtype=torch.float64, device='cuda')
+    with pytest.raises(ops._hip.HipLibraryError, match='room for'):
+        ops.call('ptts_dense_bf16x6_stats', ops.ptr(a), ops.ptr(planes), None, ops.ptr(c), M, N, K, K, N, ops.IN_NONE, None, None, 0.3,
+                 ops.ptr(rows), need - 1, ctypes.byref(n), ops.stream())
+    sc = torch.ones(N + 1, device='cuda')
+    with pytest.raises(ops._hip.HipLibraryError, match='aligned'):
+        ops.call('ptts_dense_bf16x6_bwd_affine', ops.ptr(a), ops.ptr(planes), ops.ptr(c), M, N, K, K, N, ops.ptr(c), ops.ptr(sc[1:]), ops.ptr(sc[1:]), 0.3,
+                 ops.ptr(rows), need, ctypes.byref(n), ops.stream())
+    with pytest.raises(ops._hip.HipLibraryError, match='bad args'):
+        ops.call('ptts_partial_rows_sum', ops.ptr(rows), 0, 2 * N, ops.ptr(rows), ops.stream())
+    with pytest.raises(ops._hip.HipLibraryError, match='aligned'):
+        ops.call('ptts_conv2d_mfma_bwd_fused_affine', ops.ptr(x), ops.ptr(x), ops.ptr(ops._C2M.table(w, True)), ops.ptr(y), ops.ptr(rows), rows.numel() * 8,
+                 ctypes.byref(n), ctypes.byref(n), 2, 40, 65, 5, 2, 0.3, ops.ptr(sc[1:]), ops.ptr(sc[1:]), ops.stream())
+    torch.cuda.synchronize()
+    assert float(rows.abs().max()) == 0.0
