@@ -364,6 +364,7 @@ def build_optimizer(args, ctx, spec, nm, batch, errtype, gated=False, bf16=None,
     cfg.train_wgan_early_critic = not args.no_early_critic
     cfg.train_wgan_hoist_generator = (not args.no_hoist) and os.environ.get('PTTS_HOIST', '1') == '1'
     cfg.train_wgan_generator_lookahead = (not getattr(args, 'no_lookahead', False)) and os.environ.get('PTTS_LOOKAHEAD', '1') == '1'
+    cfg.train_wgan_graph_frozen_planes = os.environ.get('PTTS_FROZEN_PLANES', '1') == '1'          # (A/B switch)
     cfg.train_wgan_fake_ahead = os.environ.get('PTTS_FAKE_AHEAD', '0') == '1'          # (A/B switch)
     cfg.train_wgan_hoist_side_backward = os.environ.get('PTTS_HOIST_SIDE_BWD', '1') == '1'      # (A/B switch)
     cfg.train_wgan_side_backward_first = os.environ.get('PTTS_SIDE_BWD_FIRST', '0') == '1'     # (A/B switch) the BLSTM's autograd node created last

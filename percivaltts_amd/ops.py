@@ -1710,17 +1710,47 @@ class _C1FFT(object):
             planes = ent[4]
         else:
             planes = torch.empty(NB * npb, dtype=torch.uint8, device=w.device)
+        cls._build_kernel_planes(w, c, planes)
+        if len(cls.w_hat) >= 8 and (id(w), sid) not in cls.w_hat:
+            cls.w_hat = {k: e for k, e in cls.w_hat.items() if id(getattr(e[0], '_ptts_flat', None)) in cls.frozen}      # kernels of optimisers long gone would otherwise keep their plane sets alive
+        cls.w_hat[(id(w), sid)] = (w, w._version, epoch, None, planes, geo, T)
+        return planes
+
+    @classmethod
+    def _build_kernel_planes(cls, w, c, planes):
+        KW, Cin, N = w.shape
+        NB, Kh = c['NB'], c['Kh']
         if KW in cls.KWS:
             call('ptts_conv1d_freq_kernel_planes', ptr(w), ptr(c['Tw']), ptr(planes), NB, KW, Cin, N, Kh, stream(), tag=(NB, KW, Cin, N))
         else:
             # any other odd kernel size: the twiddle product as a GEMM (pad rows zero), then one strided split
+            npb = _hip.lib().ptts_dense_planes_bytes(N, 2 * Kh)
             What = torch.zeros(c['R'] * Kh * N, dtype=torch.float32, device=w.device)
             gemm_raw(c['Tw'], w.view(KW, Cin * N), What, c['R'], Cin * N, KW, lda=KW, ldb=Cin * N, ldc=Kh * N)
             call('ptts_split3_dense_weight_strided', ptr(What), 2 * Kh * N, ptr(planes), npb, NB, N, 2 * Kh, N, 0, stream(), tag=('w', NB))
-        if len(cls.w_hat) >= 8 and (id(w), sid) not in cls.w_hat:
-            cls.w_hat = {}                     # kernels of optimisers long gone would otherwise keep their plane sets alive
-        cls.w_hat[(id(w), sid)] = (w, w._version, epoch, None, planes, geo)
-        return planes
+
+    # Kernels of a network that is FROZEN inside a replayed step (the generator inside the critic step's hipGraph): ids of their flat
+    # parameter buffers.  Their planes on a stream survive clear() -- a capture then finds them and does NOT rebuild them inside the
+    # graph, where they would be rebuilt on every replay although the weights change once per generator update (42 us a replay for the
+    # generator's context kernel) -- and the owner of the graph refreshes them before a replay when the weights have changed.
+    frozen = set()
+
+    @classmethod
+    def refresh_frozen(cls, flat, sid):
+        """Rebuild, on the CURRENT stream, the planes that stream `sid`'s entries hold for the kernels of `flat` if its weights changed
+        since they were made (the buffers stay: a graph captured on `sid` reads them).  Returns the number rebuilt."""
+        n = 0
+        for k, e in list(cls.w_hat.items()):
+            w = e[0]
+            if k[1] != sid or getattr(w, '_ptts_flat', None) is not flat or len(e) < 7:
+                continue
+            if e[1] == w._version and e[2] == flat.epoch:
+                continue
+            KW, Cin, N = w.shape
+            cls._build_kernel_planes(w, cls.const(e[6], KW, Cin, w.device), e[4])
+            cls.w_hat[k] = (w, w._version, flat.epoch, None, e[4], e[5], e[6])
+            n += 1
+        return n
 
     @classmethod
     def forward(cls, a, w, b, y):
@@ -1791,7 +1821,9 @@ class _C1FFT(object):
     def clear(cls):
         cls.x_src = cls.x_key = cls.x_hat = None
         cls.xw_src = cls.xw_key = cls.xw_planes = None
-        cls.w_hat = {k: (e[0], None, None, e[3], e[4], e[5]) for k, e in cls.w_hat.items()}
+        # (the planes of frozen networks' kernels stay valid: refresh_frozen keeps them current)
+        cls.w_hat = {k: (e if id(getattr(e[0], '_ptts_flat', None)) in cls.frozen else (e[0], None, None, e[3], e[4], e[5]) + tuple(e[6:]))
+                     for k, e in cls.w_hat.items()}
 
 
 def conv1d_fft(on):

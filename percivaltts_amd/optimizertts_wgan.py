@@ -135,6 +135,7 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
         cfg.train_wgan_parallel_streams = False      # the critic evaluations on separate HIP streams
         cfg.train_wgan_side_backward_first = False   # generator step: the BLSTM's autograd node created last (its launches go out first), so that its backward chain is enqueued first.  Measured: the chain then ends 1 ms earlier, the step does not (the main stream's backward becomes the tail): off
         cfg.train_wgan_stack_real_fake = True        # critic(real) and critic(fake) as one stacked 2B pass (exact: no BatchNorm)
+        cfg.train_wgan_graph_frozen_planes = True    # a replayed critic step reads the frozen generator's context-kernel planes from a buffer refreshed per generator update instead of rebuilding them in every replay
         cfg.train_wgan_fake_ahead = False            # (measured, off) the frozen generator's sample of the NEXT critic-only batch drawn on a side stream beside this batch's critic step: cycle 29.55 -> 29.85 ms -- the step's graph then transforms the context input a second time, and the overlap does not pay for it
         cfg.train_wgan_generator_lookahead = True    # a generator step's forward launched one batch ahead when the caller names the next batch (hint_next_batch / device_step(nxt=...))
         cfg.train_wgan_pair_forward = True           # critic step: the forward of the stacked real / fake batch (2B) and of x^ (B) as ONE launch per layer over 3B rows (their backward passes stay separate)
@@ -643,13 +644,23 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
                     self.wait_updates()
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
+            # ... except those of the FROZEN generator inside a critic step: its context kernel's frequency-domain planes (42 us to
+            # rebuild) change once per generator update, not per replay -- the capture reads the planes the warm-up left on this stream
+            # and every replay is preceded by ops._C1FFT.refresh_frozen (below)
+            frozen_prev = ops._C1FFT.frozen
+            if kind == 'critic' and bool(getattr(self.cfg, 'train_wgan_graph_frozen_planes', True)):
+                ops._C1FFT.frozen = {id(self.gen_opti.flat)}
             ops.clear_caches()         # every derived operand (bf16 planes, Toeplitz tables) must be rebuilt inside the graph
             try:
                 with torch.cuda.graph(g, stream=side):      # the stream of the warm-up: stream-keyed operand caches (weight planes) keep their entries and are refreshed grouped
                     out = fn()
             finally:
                 ops.clear_caches()         # ... and the graph's private copies are not for eager code
+                ops._C1FFT.frozen = frozen_prev
                 self.cfg.train_wgan_parallel_streams, self._model.kerasmodel.parallel_branches = saved_streams
+            if not hasattr(self, '_graph_sids'):
+                self._graph_sids = {}
+            self._graph_sids[key] = side.cuda_stream
             ent = (g, sX, sY, sA, out, sF)
             self._graphs[key] = ent
             self._state_restore(snap)
@@ -661,6 +672,9 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             if alpha is None: sA.uniform_(0.0, 1.0)
             else: sA.copy_(alpha.reshape(-1))
         self.wait_updates()            # the replay reads (and, in one process, writes) both networks' weights
+        if kind == 'critic':
+            # the frozen generator's kernel planes the graph reads (see the capture): current again if the generator has been updated
+            ops._C1FFT.refresh_frozen(self.gen_opti.flat, getattr(self, '_graph_sids', {}).get(key))
         g.replay()
         if whole:
             # the replayed Adam / clip kernels changed the weights behind every weight-keyed cache (bf16 planes, Toeplitz

@@ -588,6 +588,61 @@ def test_batchnorm_statistics_taken_from_the_convolutions_sums(setup):
         close(a, b, 1e-5, 1e-6, 'BatchNorm moving statistics')
 
 
+def test_replayed_critic_step_follows_the_generators_updates(setup):
+    """cfg.train_wgan_graph_frozen_planes (default on): the critic step's hipGraph does not rebuild the FROZEN generator's frequency-domain
+    kernel planes in every replay -- it reads the buffer the capture's warm-up left, and ops._C1FFT.refresh_frozen rebuilds that buffer
+    before a replay when the generator's weights have changed.  A stale buffer would be a silently wrong fake sample: the replay is
+    compared with the eager step at the captured weights, after the generator's weights were changed, and after they changed again."""
+    from percivaltts_amd import ops
+    cfg, opt, crit, X, Y = setup
+    state = (opt.critic_opti.flat.flat, opt.critic_opti.m, opt.critic_opti.v, opt.critic_opti.step_count, opt.gen_opti.flat.flat)
+    snap = [t.detach().clone() for t in state]
+    moving = [t for k, t in opt._model.kerasmodel.weights() if 'moving' in k]
+    moving0 = [t.detach().clone() for t in moving]
+    alpha = torch.rand(X.shape[0], generator=torch.Generator().manual_seed(7)).cuda()
+
+    def load(gen_factor):
+        opt.wait_updates()
+        for dst, src in zip(state, snap):
+            dst.copy_(src)
+        for dst, src in zip(moving, moving0):
+            dst.copy_(src)
+        if gen_factor != 1.0:
+            # "a generator update": every weight of G moves, each its own way (a common factor on a kernel would be undone by the
+            # BatchNormalization behind it -- tools/neg_check_frozen.py: the test must fail when the refresh is switched off)
+            gpert = torch.Generator(device='cuda').manual_seed(int(gen_factor * 1000))
+            w = opt.gen_opti.flat.flat
+            w.add_(torch.randn(w.shape, generator=gpert, device='cuda') * (abs(gen_factor - 1.0) * float(w.std())))
+        opt.critic_opti.flat.epoch += 1; opt.gen_opti.flat.epoch += 1
+
+    graphs0 = dict(opt._graphs)
+    try:
+        load(1.0)
+        opt._graphed('critic', X, Y, alpha)                      # capture (its warm-up steps move the critic)
+        key = [k for k in opt._graphs if k not in graphs0 and k[0] == 'critic' and not k[-1]]
+        assert len(key) == 1
+        sid = opt._graph_sids[key[0]]
+        rebuilt = []
+        for factor in (1.0, 1.05, 0.97):
+            load(factor)
+            lc_e = float(opt.critic_step(X, Y, alpha)); opt.wait_updates()
+            ge = opt.critic_opti.flat.grad.detach().clone()
+            load(factor)
+            pending = sum(1 for k, e in ops._C1FFT.w_hat.items() if k[1] == sid and getattr(e[0], '_ptts_flat', None) is opt.gen_opti.flat
+                          and (e[1] != e[0]._version or e[2] != opt.gen_opti.flat.epoch))
+            rebuilt.append(pending)
+            lc_g = float(opt._graphed('critic', X, Y, alpha)); opt.wait_updates(); torch.cuda.synchronize()
+            gg = opt.critic_opti.flat.grad.detach().clone()
+            assert abs(lc_g - lc_e) <= 1e-4 * max(1.0, abs(lc_e)), (factor, lc_g, lc_e)
+            assert rel_l2(gg, ge) < 3e-4, (factor, rel_l2(gg, ge))
+            assert ops._C1FFT.refresh_frozen(opt.gen_opti.flat, sid) == 0          # current after the replay's refresh
+        assert all(p >= 1 for p in rebuilt), rebuilt                     # the generator owns a context kernel whose planes the graph reads
+    finally:
+        load(1.0)
+        for k in [k for k in opt._graphs if k not in graphs0]:
+            del opt._graphs[k]
+
+
 def test_train_step_with_the_bf16x6_context_conv_matches_the_fp32_one(setup):
     """device_step at BASELINE configs[1] sizes with the context-Conv1D forward as a bf16x6 split product in the time domain
     (cfg.train_wgan_split_bf16, csrc/split.hip) and in the frequency domain (ops._C1FFT, the default) against the same step on
