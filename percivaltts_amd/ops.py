@@ -1703,6 +1703,8 @@ class _C1FFT(object):
         geo = (c['S'], NB, Kh)
         ent = cls.w_hat.get((id(w), sid))
         if ent is not None and ent[0] is w and ent[1] == w._version and ent[2] == epoch and flat is not None and ent[5] == geo:
+            if cls.frozen_log is not None and id(flat) in cls.frozen:
+                cls.frozen_log.append((w, ent[4], T))        # (a capture reads this buffer: its owner keeps it current, refresh_planes)
             return ent[4]
         lib = _hip.lib()
         npb = lib.ptts_dense_planes_bytes(N, 2 * Kh)
@@ -1734,23 +1736,16 @@ class _C1FFT(object):
     # graph, where they would be rebuilt on every replay although the weights change once per generator update (42 us a replay for the
     # generator's context kernel) -- and the owner of the graph refreshes them before a replay when the weights have changed.
     frozen = set()
+    frozen_log = None      # a list while a capture runs: (kernel, planes buffer, T) of every frozen kernel's planes the capture reads
 
     @classmethod
-    def refresh_frozen(cls, flat, sid):
-        """Rebuild, on the CURRENT stream, the planes that stream `sid`'s entries hold for the kernels of `flat` if its weights changed
-        since they were made (the buffers stay: a graph captured on `sid` reads them).  Returns the number rebuilt."""
-        n = 0
-        for k, e in list(cls.w_hat.items()):
-            w = e[0]
-            if k[1] != sid or getattr(w, '_ptts_flat', None) is not flat or len(e) < 7:
-                continue
-            if e[1] == w._version and e[2] == flat.epoch:
-                continue
+    def refresh_planes(cls, items):
+        """Rebuild, on the CURRENT stream, the planes buffers a captured graph reads for frozen kernels: items = [(w, planes, T)] as
+        logged during its capture (the buffers are the graph's inputs; the cache may meanwhile hold other buffers for these kernels)."""
+        for w, planes, T in items:
             KW, Cin, N = w.shape
-            cls._build_kernel_planes(w, cls.const(e[6], KW, Cin, w.device), e[4])
-            cls.w_hat[k] = (w, w._version, flat.epoch, None, e[4], e[5], e[6])
-            n += 1
-        return n
+            cls._build_kernel_planes(w, cls.const(T, KW, Cin, w.device), planes)
+        return len(items)
 
     @classmethod
     def forward(cls, a, w, b, y):
@@ -1821,7 +1816,7 @@ class _C1FFT(object):
     def clear(cls):
         cls.x_src = cls.x_key = cls.x_hat = None
         cls.xw_src = cls.xw_key = cls.xw_planes = None
-        # (the planes of frozen networks' kernels stay valid: refresh_frozen keeps them current)
+        # (the planes of frozen networks' kernels stay valid: the owner of a graph that reads them keeps them current, refresh_planes)
         cls.w_hat = {k: (e if id(getattr(e[0], '_ptts_flat', None)) in cls.frozen else (e[0], None, None, e[3], e[4], e[5]) + tuple(e[6:]))
                      for k, e in cls.w_hat.items()}
 

@@ -646,21 +646,25 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             g = torch.cuda.CUDAGraph()
             # ... except those of the FROZEN generator inside a critic step: its context kernel's frequency-domain planes (42 us to
             # rebuild) change once per generator update, not per replay -- the capture reads the planes the warm-up left on this stream
-            # and every replay is preceded by ops._C1FFT.refresh_frozen (below)
+            # and every replay is preceded by ops._C1FFT.refresh_planes when the weights have changed (below)
             frozen_prev = ops._C1FFT.frozen
+            frozen_items = []
             if kind == 'critic' and bool(getattr(self.cfg, 'train_wgan_graph_frozen_planes', True)):
                 ops._C1FFT.frozen = {id(self.gen_opti.flat)}
+                ops._C1FFT.frozen_log = frozen_items
             ops.clear_caches()         # every derived operand (bf16 planes, Toeplitz tables) must be rebuilt inside the graph
             try:
                 with torch.cuda.graph(g, stream=side):      # the stream of the warm-up: stream-keyed operand caches (weight planes) keep their entries and are refreshed grouped
                     out = fn()
             finally:
+                ops._C1FFT.frozen_log = None
                 ops.clear_caches()         # ... and the graph's private copies are not for eager code
                 ops._C1FFT.frozen = frozen_prev
                 self.cfg.train_wgan_parallel_streams, self._model.kerasmodel.parallel_branches = saved_streams
-            if not hasattr(self, '_graph_sids'):
-                self._graph_sids = {}
-            self._graph_sids[key] = side.cuda_stream
+            if not hasattr(self, '_graph_frozen'):
+                self._graph_frozen = {}
+            # the buffers this graph reads for the frozen generator's kernels, and the state of its weights they were built from
+            self._graph_frozen[key] = {'items': frozen_items, 'epoch': self.gen_opti.flat.epoch}
             ent = (g, sX, sY, sA, out, sF)
             self._graphs[key] = ent
             self._state_restore(snap)
@@ -672,9 +676,11 @@ class OptimizerTTSWGAN(optimizertts.OptimizerTTS):
             if alpha is None: sA.uniform_(0.0, 1.0)
             else: sA.copy_(alpha.reshape(-1))
         self.wait_updates()            # the replay reads (and, in one process, writes) both networks' weights
-        if kind == 'critic':
-            # the frozen generator's kernel planes the graph reads (see the capture): current again if the generator has been updated
-            ops._C1FFT.refresh_frozen(self.gen_opti.flat, getattr(self, '_graph_sids', {}).get(key))
+        fz = getattr(self, '_graph_frozen', {}).get(key)
+        if fz is not None and fz['items'] and fz['epoch'] != self.gen_opti.flat.epoch:
+            # the frozen generator's kernel planes the graph reads (see the capture): rebuilt if the generator's weights have changed
+            ops._C1FFT.refresh_planes(fz['items'])
+            fz['epoch'] = self.gen_opti.flat.epoch
         g.replay()
         if whole:
             # the replayed Adam / clip kernels changed the weights behind every weight-keyed cache (bf16 planes, Toeplitz
