@@ -472,8 +472,18 @@ __global__ __launch_bounds__(256) void bn_finalize_partials_kernel(const double*
     const int tid = threadIdx.x, n2c = 2 * C, G = 256 / n2c;
     const int j = tid % n2c, g = tid / n2c;
     double t = 0.0;
-    if (g < G)
-        for (int b = g; b < nrows; b += G) t += partials[(size_t)b * n2c + j];
+    if (g < G) {
+        // eight rows in flight per lane (one load, one add, the next load made this 1-workgroup kernel 5 us: eight dependent round trips)
+        int b = g;
+        for (; b + 7 * G < nrows; b += 8 * G) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partials[(size_t)(b + u * G) * n2c + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += v[u];
+        }
+        for (; b < nrows; b += G) t += partials[(size_t)b * n2c + j];
+    }
     sh[tid] = (g < G) ? t : 0.0;
     __syncthreads();
     if (tid < n2c) {
@@ -519,10 +529,12 @@ __global__ __launch_bounds__(256) void bn_finalize_partials_wide_kernel(const do
     double t = 0.0;
     if (c < C) {
         int b = g;
-        for (; b + 48 < nrows; b += 64) {
-            const double v0 = partials[(size_t)b * 2 * C + col], v1 = partials[(size_t)(b + 16) * 2 * C + col];
-            const double v2 = partials[(size_t)(b + 32) * 2 * C + col], v3 = partials[(size_t)(b + 48) * 2 * C + col];
-            t += v0; t += v1; t += v2; t += v3;
+        for (; b + 7 * 16 < nrows; b += 8 * 16) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partials[(size_t)(b + u * 16) * 2 * C + col];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += v[u];
         }
         for (; b < nrows; b += 16) t += partials[(size_t)b * 2 * C + col];
     }
